@@ -1,0 +1,181 @@
+"""Synthetic weights and the flat weight blob the C-ABI consumes.
+
+The reference ships no trained weights (/root/reference/.gitignore:16), so parity and
+benchmarks run on seeded synthetic parameters.  Names and shapes follow the
+VarStore layout of /root/reference/src/text_detection/model.rs:65-105 and
+/root/reference/src/char_recognition/model.rs:13-24.
+
+Blob layout (little endian):
+    0   char[4]  "OCRW"
+    4   u32      version (1)
+    8   u32      n_tensors
+    12  u32      reserved
+    16  n_tensors x record{ char name[64]; u32 ndim; u32 dims[4]; u64 offset; u64 count }
+    ..  f32 data, each tensor 64-byte aligned, `offset` is from the blob start
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+_REC = struct.Struct("<64sI4IQQ")
+
+
+def det_param_specs() -> List[Tuple[str, Tuple[int, ...]]]:
+    specs: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def bn(prefix: str, c: int) -> None:
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            specs.append((f"{prefix}.{leaf}", (c,)))
+
+    specs.append(("conv1.weight", (64, 1, 7, 7)))
+    bn("bn1", 64)
+    cin = 64
+    for li, cout in enumerate((64, 128, 256, 512), start=1):
+        for b in range(2):
+            p = f"layer{li}.{b}"
+            c_in = cin if b == 0 else cout
+            specs.append((f"{p}.conv1.weight", (cout, c_in, 3, 3)))
+            bn(f"{p}.bn1", cout)
+            specs.append((f"{p}.conv2.weight", (cout, cout, 3, 3)))
+            bn(f"{p}.bn2", cout)
+            if b == 0 and li > 1:
+                specs.append((f"{p}.downsample.0.weight", (cout, c_in, 1, 1)))
+                bn(f"{p}.downsample.1", cout)
+        cin = cout
+    specs += [("in5.weight", (256, 512, 1, 1)), ("in4.weight", (256, 256, 1, 1)),
+              ("in3.weight", (256, 128, 1, 1)), ("in2.weight", (256, 64, 1, 1))]
+    for n in ("out5", "out4", "out3", "out2", "bin_conv1"):
+        specs.append((f"{n}.weight", (64, 256, 3, 3)))
+    bn("bin_bn1", 64)
+    specs += [("bin_conv_tr1.weight", (64, 64, 2, 2)), ("bin_conv_tr1.bias", (64,))]
+    bn("bin_bn2", 64)
+    specs += [("bin_conv_tr2.weight", (64, 1, 2, 2)), ("bin_conv_tr2.bias", (1,))]
+    return specs
+
+
+def rec_param_specs() -> List[Tuple[str, Tuple[int, ...]]]:
+    return [("conv1.weight", (32, 1, 5, 5)), ("conv1.bias", (32,)),
+            ("conv2.weight", (64, 32, 5, 5)), ("conv2.bias", (64,)),
+            ("fc1.weight", (512, 1024)), ("fc1.bias", (512,)),
+            ("fc2.weight", (62, 512)), ("fc2.bias", (62,))]
+
+
+def _uniform01(seed: int, tensor_index: int, count: int) -> np.ndarray:
+    """Counter-based generator (splitmix64 finaliser): 24-bit uniforms in [0,1)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(count, dtype=np.uint64)
+        z = i + np.uint64((seed * 0x9E3779B97F4A7C15 + (tensor_index + 1) * 0xD1B54A32D192ED03) % (1 << 64))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))).astype(np.float32)
+
+
+def synth_image_batch(seed: int, n: int, h: int, w: int) -> np.ndarray:
+    """Synthetic detection frames: integers 0..255 as f32 (the reference feeds raw
+    0..255 luma, /root/reference/src/text_detection/mod.rs:46-54), N x 1 x H x W."""
+    u = _uniform01(seed, 1000, n * h * w)
+    return np.floor(u * 256.0).astype(np.float32).reshape(n, 1, h, w)
+
+
+def synth_crops(seed: int, n: int) -> np.ndarray:
+    """Synthetic recognition crops: U{0..255}/255 as f32, N x 784
+    (/root/reference/src/image_ops.rs:73-85 divides by 255)."""
+    u = _uniform01(seed, 2000, n * 784)
+    keep = _uniform01(seed, 2001, n * 784) < np.float32(0.06)   # sparse "strokes": varied labels
+    return (np.where(keep, np.floor(u * 256.0), 0.0).astype(np.float32) / np.float32(255.0)).reshape(n, 784)
+
+
+# Gains that keep synthetic activations O(1) from raw 0..255 input to the logits
+# (measured once with oracle/torch_ref.py; they are part of the synthetic
+# distribution, not of the reference).
+_DET_GAIN = {"conv1": 1.0 / 128.0, "out5": 0.25, "out4": 0.25, "out3": 0.25, "out2": 0.25,
+             "bin_conv_tr2": 0.5}
+
+
+def make_det_weights(seed: int = 0) -> Dict[str, np.ndarray]:
+    """Kaiming-uniform convolutions, BN gamma ~ U(0.5,1.5), beta ~ U(-.1,.1),
+    running_mean ~ U(-.1,.1), running_var ~ U(0.5,1.5): every BN term is
+    exercised (tch's own defaults, mean 0 / var 1 / beta 0, would hide bugs).
+    The last transposed convolution is scaled so that sigmoid outputs straddle
+    the 0.6 binarisation threshold on synthetic frames."""
+    out: Dict[str, np.ndarray] = {}
+    for ti, (name, shape) in enumerate(det_param_specs()):
+        count = int(np.prod(shape))
+        u = _uniform01(seed, ti, count)
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "weight" and len(shape) == 4:
+            if name.startswith("bin_conv_tr"):
+                fan_in = shape[0]  # [Cin, Cout, kh, kw], one tap per output pixel
+            else:
+                fan_in = shape[1] * shape[2] * shape[3]
+            bound = np.sqrt(6.0 / fan_in)
+            if name.startswith("in") or name.startswith("out"):
+                bound = np.sqrt(3.0 / fan_in)  # linear layers (no ReLU after them)
+            v = (u * 2.0 - 1.0) * np.float32(bound) * np.float32(_DET_GAIN.get(name.split(".")[0], 1.0))
+        elif leaf == "weight":                    # BN gamma
+            v = u + np.float32(0.5)
+            if name.startswith("layer") and ".bn2." in name:
+                v = v * np.float32(0.4)           # damp the residual branch
+        elif leaf == "bias" and name.startswith("bin_conv_tr"):
+            v = (u * 2.0 - 1.0) * np.float32(0.1)
+        elif leaf in ("bias", "running_mean"):
+            v = (u * 2.0 - 1.0) * np.float32(0.1)
+        elif leaf == "running_var":
+            v = u + np.float32(0.5)
+        else:
+            raise AssertionError(name)
+        out[name] = v.astype(np.float32).reshape(shape)
+    return out
+
+
+def make_rec_weights(seed: int = 0) -> Dict[str, np.ndarray]:
+    out: Dict[str, np.ndarray] = {}
+    for ti, (name, shape) in enumerate(rec_param_specs()):
+        count = int(np.prod(shape))
+        u = _uniform01(seed, 500 + ti, count)
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else None
+        if fan_in is not None:
+            gain = 8.0 if name == "fc2.weight" else 1.4   # spreads the 62 logits (top-2 gap >> fp32 noise)
+            v = (u * 2.0 - 1.0) * np.float32(np.sqrt(3.0 / fan_in) * gain)
+        else:
+            v = (u * 2.0 - 1.0) * np.float32(0.01)
+        out[name] = v.astype(np.float32).reshape(shape)
+    return out
+
+
+def pack_blob(params: Dict[str, np.ndarray]) -> bytes:
+    names = list(params.keys())
+    header = 16 + _REC.size * len(names)
+    off = (header + 63) // 64 * 64
+    recs, chunks = [], []
+    for name in names:
+        a = np.ascontiguousarray(params[name], dtype=np.float32)
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        recs.append(_REC.pack(name.encode(), a.ndim, *dims, off, a.size))
+        chunks.append((off, a.tobytes()))
+        off = (off + a.size * 4 + 63) // 64 * 64
+    buf = bytearray(off)
+    buf[0:16] = struct.pack("<4sIII", b"OCRW", 1, len(names), 0)
+    pos = 16
+    for r in recs:
+        buf[pos:pos + _REC.size] = r
+        pos += _REC.size
+    for o, data in chunks:
+        buf[o:o + len(data)] = data
+    return bytes(buf)
+
+
+def unpack_blob(blob: bytes) -> Dict[str, np.ndarray]:
+    magic, ver, n, _ = struct.unpack_from("<4sIII", blob, 0)
+    if magic != b"OCRW" or ver != 1:
+        raise ValueError("not an OCRW v1 weight blob")
+    out: Dict[str, np.ndarray] = {}
+    for i in range(n):
+        name, ndim, d0, d1, d2, d3, off, count = _REC.unpack_from(blob, 16 + i * _REC.size)
+        shape = (d0, d1, d2, d3)[:ndim]
+        out[name.rstrip(b"\0").decode()] = np.frombuffer(blob, dtype=np.float32, count=count, offset=off).reshape(shape)
+    return out
