@@ -1,0 +1,146 @@
+/* ocr_amd.h - C ABI of the MI355X-native OCR inference hot path.
+ *
+ * This is the FFI surface a maintainer of lazareviczoran/ocr-rs binds instead of
+ * tch/libtorch for the two inference stages (INTEGRATION.md shows the Rust side).
+ * Plain pointers and sizes only; no torch types; nothing unwinds across the
+ * boundary (the reference builds with panic = "abort", Cargo.toml:12-15): every
+ * entry point returns an int status (0 = OK) and records a thread-local message
+ * readable through ocr_last_error().
+ *
+ * Tensors are dense row-major f32, NCHW as tch hands them to ATen.  Handles are
+ * bound to one GPU and one HIP stream, are not thread-safe, and calls are
+ * synchronous unless the name ends in _async (mirrors the reference's blocking,
+ * single-threaded calls).
+ */
+#ifndef OCR_AMD_H
+#define OCR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCR_OK 0
+#define OCR_ERR_INVALID 1   /* bad argument / shape                      */
+#define OCR_ERR_WEIGHTS 2   /* weight blob malformed or tensor missing   */
+#define OCR_ERR_HIP 3       /* HIP runtime error (message has the call)  */
+#define OCR_ERR_NOGPU 4     /* no usable gfx950 device: there is NO CPU fallback */
+#define OCR_ERR_INTERNAL 5
+
+/* memory kind of the data pointers handed to a call */
+#define OCR_MEM_HOST 0
+#define OCR_MEM_DEVICE 1
+
+typedef struct ocr_det ocr_det_t;     /* detector: resnet18() graph + its weights  */
+typedef struct ocr_rec ocr_rec_t;     /* recogniser: char_recognition::Net         */
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* ocr_last_error(void);
+/* Library / ABI version, "ocr_amd <major>.<minor> gfx950". */
+const char* ocr_version(void);
+/* Number of visible HIP devices (never throws; 0 when there is no GPU). */
+int ocr_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Detector.  Replaces, for inference:
+ *   let net = resnet18(&vs.root()); vs.load(file)      text_detection/mod.rs:35-44
+ *   net.forward_t(&x.view((n,1,h,w)), false)           text_detection/mod.rs:52-54, :196-197
+ * graph definition: text_detection/model.rs:65-156.
+ * `weights` is an OCRW v1 blob (ocr-rs_amd/weights.py documents the layout) whose
+ * tensor names are the VarStore names of model.rs:68-105; it is copied.
+ * ------------------------------------------------------------------------- */
+int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_det_t** out);
+void ocr_det_destroy(ocr_det_t* det);
+
+/* Run all later work of this handle on an existing hipStream_t (e.g. the stream
+ * of a torch.cuda.Stream).  NULL restores the handle's own stream. */
+int ocr_det_set_stream(ocr_det_t* det, void* hip_stream);
+
+/* forward_t(xs, train=false): x is N x 1 x H x W f32 (raw 0..255 luma, no
+ * normalisation - text_detection/mod.rs:46-54), prob is N x 1 x H x W f32 in
+ * (0,1).  H and W must be multiples of 32.  Blocking. */
+int ocr_det_forward(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, int mem_kind);
+
+/* Same, device pointers only, returns after enqueueing on the handle's stream.
+ * If bitmap != NULL it also receives binarize(prob, thresh) (metrics.rs:129-131)
+ * as N x 1 x H x W u8, fused into the last kernel. */
+int ocr_det_forward_async(ocr_det_t* det, const float* x_dev, int n, int h, int w, float* prob_dev,
+                          uint8_t* bitmap_dev, float thresh);
+int ocr_det_synchronize(ocr_det_t* det);
+
+/* Per-kernel timing of one forward (hipEvents on the handle's stream around every
+ * launch).  names[i] points to a static string; ms/flops/bytes are per launch:
+ * algorithmic 2*MAC FLOPs and compulsory read+write bytes of that launch.
+ * Returns the number of launches written (<= max_entries) through n_entries. */
+int ocr_det_forward_profile(ocr_det_t* det, const float* x_dev, int n, int h, int w, float* prob_dev,
+                            int max_entries, const char** names, float* ms, double* flops,
+                            double* bytes, int* n_entries);
+
+/* ---------------------------------------------------------------------------
+ * Detection post-processing.  Replaces
+ *   get_boxes_and_box_scores(pred, adjust_values) -> Result<PolygonScores>
+ *                                                  text_detection/metrics.rs:37-56
+ * (binarize :129, get_polygons_from_bitmap :58-127, box_score_fast :150-184,
+ *  get_min_area_bounding_box :133-148, polygon.rs expand_polygon :51-56).
+ * PolygonScores{ polygons: Vec<MultiPolygon<u32>>, scores: Vec<Vec<f64>> } is
+ * returned as one CSR block owned by the library.
+ * ------------------------------------------------------------------------- */
+typedef struct ocr_postproc_params {
+  double thresh;        /* 0.6  metrics.rs:38  */
+  double box_thresh;    /* 0.7  metrics.rs:64  */
+  double min_size;      /* 5.0  metrics.rs:66  */
+  double unclip_ratio;  /* 2.0  metrics.rs:103 */
+} ocr_postproc_params_t;
+
+typedef struct ocr_polygons {
+  int32_t n_images;
+  int32_t n_polygons;          /* total over the batch                       */
+  int32_t n_vertices;          /* total over the batch                       */
+  const int32_t* img_offsets;  /* [n_images+1]   polygon range of each image */
+  const int32_t* poly_offsets; /* [n_polygons+1] vertex range of each polygon */
+  const uint32_t* xy;          /* [2*n_vertices] x,y in ORIGINAL-image pixels (round(p/adj) as u32) */
+  const double* scores;        /* [n_polygons]   box_score_fast of each kept polygon */
+} ocr_polygons_t;
+
+void ocr_postproc_default_params(ocr_postproc_params_t* p);
+
+/* prob: N x 1 x H x W f32, adj_xy: N x 2 f64 (host memory, x then y scale =
+ * resized/original, image_ops.rs:200-202).  params == NULL -> reference constants.
+ * `det` supplies the GPU and stream (binarisation and box scores run as HIP
+ * kernels; contour tracing and Clipper-style offsetting run on host threads).
+ * Blocking.  *out must be released with ocr_polygons_free. */
+int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, int mem_kind,
+                        const double* adj_xy, const ocr_postproc_params_t* params,
+                        ocr_polygons_t** out);
+void ocr_polygons_free(ocr_polygons_t* p);
+
+/* ---------------------------------------------------------------------------
+ * Recogniser.  Replaces
+ *   let net = Net::new(&weights.root()); weights.load(file)   char_recognition/mod.rs:44-46
+ *   net.forward_t(&image_tensor, false)                       char_recognition/mod.rs:53-54
+ *   .softmax(-1, Kind::Double); topk(&res, 1)                 mod.rs:55-56, utils.rs:28-43
+ * graph: char_recognition/model.rs:13-39.
+ * ------------------------------------------------------------------------- */
+int ocr_rec_create(const void* weights, size_t weights_bytes, int device, ocr_rec_t** out);
+void ocr_rec_destroy(ocr_rec_t* rec);
+int ocr_rec_set_stream(ocr_rec_t* rec, void* hip_stream);
+int ocr_rec_synchronize(ocr_rec_t* rec);
+
+/* forward_t: crops N x 784 (28x28, values in [0,1]) -> logits N x 62.  Blocking. */
+int ocr_rec_forward(ocr_rec_t* rec, const float* crops, int n, float* logits, int mem_kind);
+/* forward_t + softmax(-1, f64) + top-1: label index into VALUES (utils.rs:7) and
+ * its probability.  logits may be NULL.  Device pointers; enqueues and returns. */
+int ocr_rec_classify_async(ocr_rec_t* rec, const float* crops_dev, int n, float* logits_dev,
+                           int32_t* labels_dev, double* probs_dev);
+/* Blocking convenience over either memory kind. */
+int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels, double* probs,
+                     int mem_kind);
+/* The label alphabet, utils.rs:7 ("A-Za-z0-9", 62 symbols, NUL terminated). */
+const char* ocr_rec_alphabet(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCR_AMD_H */

@@ -1,0 +1,272 @@
+"""ctypes binding of include/ocr_amd.h (the same C ABI the Rust shim of
+INTEGRATION.md binds).  No torch types cross this boundary: device tensors are
+passed as raw pointers (`tensor.data_ptr()`).
+
+The product has NO CPU fallback: every compute entry point needs libocr_amd.so
+and a gfx950 device and raises OcrError otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libocr_amd.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+EXPORTS = [
+    "ocr_last_error", "ocr_version", "ocr_device_count",
+    "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_forward",
+    "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
+    "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
+    "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
+    "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify", "ocr_rec_alphabet",
+]
+
+
+class OcrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ocr_amd error {code}: {msg}")
+        self.code = code
+
+
+class PostprocParams(C.Structure):
+    _fields_ = [("thresh", C.c_double), ("box_thresh", C.c_double), ("min_size", C.c_double),
+                ("unclip_ratio", C.c_double)]
+
+
+class Polygons(C.Structure):
+    _fields_ = [("n_images", C.c_int32), ("n_polygons", C.c_int32), ("n_vertices", C.c_int32),
+                ("img_offsets", C.POINTER(C.c_int32)), ("poly_offsets", C.POINTER(C.c_int32)),
+                ("xy", C.POINTER(C.c_uint32)), ("scores", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libocr_amd.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OcrError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.ocr_last_error.restype = C.c_char_p
+        L.ocr_version.restype = C.c_char_p
+        L.ocr_rec_alphabet.restype = C.c_char_p
+        L.ocr_det_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.ocr_det_destroy.argtypes = [C.c_void_p]
+        L.ocr_det_destroy.restype = None
+        L.ocr_det_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.ocr_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ocr_det_forward_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_float]
+        L.ocr_det_synchronize.argtypes = [C.c_void_p]
+        L.ocr_det_forward_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                              C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ocr_postproc_default_params.argtypes = [C.POINTER(PostprocParams)]
+        L.ocr_postproc_default_params.restype = None
+        L.ocr_det_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(PostprocParams),
+                                          C.POINTER(C.POINTER(Polygons))]
+        L.ocr_polygons_free.argtypes = [C.POINTER(Polygons)]
+        L.ocr_polygons_free.restype = None
+        L.ocr_rec_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.ocr_rec_destroy.argtypes = [C.c_void_p]
+        L.ocr_rec_destroy.restype = None
+        L.ocr_rec_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.ocr_rec_synchronize.argtypes = [C.c_void_p]
+        L.ocr_rec_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.ocr_rec_classify_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ocr_rec_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        # host-geometry test hooks
+        L.ocr_test_contour_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.c_int, C.POINTER(C.c_int)]
+        L.ocr_test_expand_polygon.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                              C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.ocr_test_min_area_box.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _lib = L
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise OcrError(code, lib().ocr_last_error().decode())
+
+
+def _ptr(a) -> int:
+    """Raw address of a numpy array or of a torch tensor (host or device)."""
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+def polygons_to_python(pp) -> Tuple[List[List[List[Tuple[int, int]]]], List[List[float]]]:
+    """CSR block -> PolygonScores{polygons: Vec<MultiPolygon<u32>>, scores: Vec<Vec<f64>>}."""
+    p = pp.contents
+    polys, scores = [], []
+    for b in range(p.n_images):
+        ip, isc = [], []
+        for k in range(p.img_offsets[b], p.img_offsets[b + 1]):
+            v0, v1 = p.poly_offsets[k], p.poly_offsets[k + 1]
+            ip.append([(int(p.xy[2 * v]), int(p.xy[2 * v + 1])) for v in range(v0, v1)])
+            isc.append(float(p.scores[k]))
+        polys.append(ip)
+        scores.append(isc)
+    return polys, scores
+
+
+class Detector:
+    """Owns an ocr_det_t.  Mirrors `resnet18(&vs.root())` + `vs.load(..)`
+    (/root/reference/src/text_detection/mod.rs:35-44)."""
+
+    def __init__(self, weights_blob: bytes, device: int = 0):
+        self._h = C.c_void_p()
+        self._blob = weights_blob
+        check(lib().ocr_det_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ocr_det_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, raw_stream: Optional[int]) -> None:
+        check(lib().ocr_det_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def synchronize(self) -> None:
+        check(lib().ocr_det_synchronize(self._h))
+
+    def forward_host(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n, c, h, w = x.shape
+        assert c == 1
+        prob = np.empty((n, 1, h, w), np.float32)
+        check(lib().ocr_det_forward(self._h, _ptr(x), n, h, w, _ptr(prob), MEM_HOST))
+        return prob
+
+    def forward_device(self, x_ptr: int, n: int, h: int, w: int, prob_ptr: int, bitmap_ptr: int = 0,
+                       thresh: float = 0.6) -> None:
+        """Enqueue only (device pointers)."""
+        check(lib().ocr_det_forward_async(self._h, x_ptr, n, h, w, prob_ptr, bitmap_ptr or None, thresh))
+
+    def forward_profile(self, x_ptr: int, n: int, h: int, w: int, prob_ptr: int):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        by = (C.c_double * cap)()
+        cnt = C.c_int(0)
+        check(lib().ocr_det_forward_profile(self._h, x_ptr, n, h, w, prob_ptr, cap, names, ms, fl, by, C.byref(cnt)))
+        return [(names[i].decode(), float(ms[i]), float(fl[i]), float(by[i])) for i in range(cnt.value)]
+
+    def debug_stage(self, stage_id: int, shape_nhwc) -> np.ndarray:
+        """Test hook: NHWC intermediate of the last forward, returned as NCHW."""
+        n = C.c_size_t(0)
+        check(lib().ocr_test_det_stage(self._h, stage_id, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        check(lib().ocr_test_det_stage(self._h, stage_id, _ptr(out), n.value, C.byref(n)))
+        return np.ascontiguousarray(out.reshape(shape_nhwc).transpose(0, 3, 1, 2))
+
+    def postprocess(self, prob, n: int, h: int, w: int, adjust_values: np.ndarray, mem_kind: int = MEM_HOST,
+                    params: Optional[PostprocParams] = None):
+        adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_postprocess(self._h, _ptr(prob), n, h, w, mem_kind,
+                                        adj.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(params) if params is not None else None, C.byref(out)))
+        try:
+            return polygons_to_python(out)
+        finally:
+            lib().ocr_polygons_free(out)
+
+
+class Recognizer:
+    """Owns an ocr_rec_t.  Mirrors `Net::new(&weights.root())` + `weights.load(..)`
+    (/root/reference/src/char_recognition/mod.rs:44-46)."""
+
+    def __init__(self, weights_blob: bytes, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib().ocr_rec_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ocr_rec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, raw_stream: Optional[int]) -> None:
+        check(lib().ocr_rec_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def synchronize(self) -> None:
+        check(lib().ocr_rec_synchronize(self._h))
+
+    def forward_host(self, crops: np.ndarray) -> np.ndarray:
+        crops = np.ascontiguousarray(crops, dtype=np.float32).reshape(-1, 784)
+        n = crops.shape[0]
+        logits = np.empty((n, 62), np.float32)
+        check(lib().ocr_rec_forward(self._h, _ptr(crops), n, _ptr(logits), MEM_HOST))
+        return logits
+
+    def classify_host(self, crops: np.ndarray):
+        crops = np.ascontiguousarray(crops, dtype=np.float32).reshape(-1, 784)
+        n = crops.shape[0]
+        labels = np.empty(n, np.int32)
+        probs = np.empty(n, np.float64)
+        check(lib().ocr_rec_classify(self._h, _ptr(crops), n, _ptr(labels), _ptr(probs), MEM_HOST))
+        return labels, probs
+
+    def classify_device(self, crops_ptr: int, n: int, logits_ptr: int, labels_ptr: int, probs_ptr: int) -> None:
+        check(lib().ocr_rec_classify_async(self._h, crops_ptr, n, logits_ptr or None, labels_ptr or None,
+                                           probs_ptr or None))
+
+
+# ---- host-geometry hooks (CPU only; used by tests to pin the C++ geometry to the KATs)
+def host_contour_candidates(bitmap01: np.ndarray) -> List[List[Tuple[int, int]]]:
+    bm = np.ascontiguousarray(bitmap01, dtype=np.uint8)
+    h, w = bm.shape
+    max_pts, max_polys = 1 << 20, 1 << 16
+    xy = np.empty(2 * max_pts, np.int32)
+    cnt = np.empty(max_polys, np.int32)
+    n = C.c_int(0)
+    check(lib().ocr_test_contour_candidates(_ptr(bm), h, w, _ptr(xy), _ptr(cnt), max_pts, max_polys, C.byref(n)))
+    out, pos = [], 0
+    for k in range(n.value):
+        c = int(cnt[k])
+        out.append([(int(xy[2 * (pos + i)]), int(xy[2 * (pos + i) + 1])) for i in range(c)])
+        pos += c
+    return out
+
+
+def host_expand_polygon(pts: Sequence[Tuple[int, int]], factor: float = 2.0):
+    a = np.asarray(pts, dtype=np.int32).reshape(-1)
+    out = np.empty(8192, np.int32)
+    n = C.c_int(0)
+    ss = C.c_double(0.0)
+    check(lib().ocr_test_expand_polygon(_ptr(a), len(pts), factor, _ptr(out), 4096, C.byref(n), C.byref(ss)))
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)], ss.value
+
+
+def host_min_area_box(pts: Sequence[Tuple[int, int]]):
+    a = np.asarray(pts, dtype=np.int32).reshape(-1)
+    box = np.empty(8, np.int32)
+    ss = C.c_double(0.0)
+    check(lib().ocr_test_min_area_box(_ptr(a), len(pts), _ptr(box), C.byref(ss)))
+    return [(int(box[2 * i]), int(box[2 * i + 1])) for i in range(4)], ss.value

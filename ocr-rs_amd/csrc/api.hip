@@ -1,0 +1,388 @@
+// extern "C" boundary (include/ocr_amd.h).  Nothing throws across it.
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+#include "engine.hpp"
+#include "postproc_geom.hpp"
+
+struct ocr_det {
+  ocr::Detector impl;
+  ocr_det(const void* b, size_t n, int d) : impl(b, n, d) {}
+};
+struct ocr_rec {
+  ocr::Recognizer impl;
+  ocr_rec(const void* b, size_t n, int d) : impl(b, n, d) {}
+};
+
+namespace {
+thread_local std::string g_err;
+
+template <typename F>
+int guard(F&& f) {
+  try {
+    g_err.clear();
+    f();
+    return OCR_OK;
+  } catch (const ocr::Error& e) {
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return OCR_ERR_INTERNAL;
+  } catch (...) {
+    g_err = "unknown failure";
+    return OCR_ERR_INTERNAL;
+  }
+}
+
+struct PolygonsOwned {
+  ocr_polygons_t view;
+  std::vector<int32_t> img_offsets, poly_offsets;
+  std::vector<uint32_t> xy;
+  std::vector<double> scores;
+};
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// get_boxes_and_box_scores (metrics.rs:37-56) over the whole batch.
+void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
+                 const ocr_postproc_params_t& prm, ocr_polygons_t** out) {
+  using namespace ocr;
+  if (!prob || !adj || !out) fail(OCR_ERR_INVALID, "det_postprocess: null argument");
+  if (n <= 0 || h <= 0 || w <= 0) fail(OCR_ERR_INVALID, "det_postprocess: bad shape");
+  OCR_HIP(hipSetDevice(det.device()));
+  hipStream_t s = det.stream();
+  const size_t px = (size_t)n * h * w;
+  // scratch: [prob copy if host] [bitmap]
+  const size_t off_bitmap = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
+  char* scratch = static_cast<char*>(det.scratch(off_bitmap + align256(px)));
+  const float* prob_dev = prob;
+  if (mem_kind == OCR_MEM_HOST) {
+    OCR_HIP(hipMemcpyAsync(scratch, prob, px * 4, hipMemcpyHostToDevice, s));
+    prob_dev = reinterpret_cast<const float*>(scratch);
+  }
+  uint8_t* bitmap_dev = reinterpret_cast<uint8_t*>(scratch + off_bitmap);
+  launch_binarize(prob_dev, bitmap_dev, (float)prm.thresh, px, s);  // metrics.rs:41,129
+  std::vector<uint8_t> bitmap(px);
+  OCR_HIP(hipMemcpyAsync(bitmap.data(), bitmap_dev, px, hipMemcpyDeviceToHost, s));
+  OCR_HIP(hipStreamSynchronize(s));
+
+  // contour tracing + Douglas-Peucker on host threads, one image at a time per thread
+  std::vector<std::vector<std::vector<geom::Pt>>> cands(n);
+  {
+    std::atomic<int> next{0};
+    std::string err;
+    std::atomic<bool> failed{false};
+    auto work = [&]() {
+      try {
+        for (int b = next++; b < n; b = next++) geom::contour_candidates(bitmap.data() + (size_t)b * h * w, h, w, cands[b]);
+      } catch (const std::exception& e) {
+        if (!failed.exchange(true)) err = e.what();
+      }
+    };
+    const int nt = std::max(1, std::min<int>(n, (int)std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (failed) fail(OCR_ERR_INTERNAL, "contour stage: %s", err.c_str());
+  }
+
+  // box scores on the GPU (metrics.rs:99 -> :150-184)
+  std::vector<BoxScoreJob> jobs;
+  std::vector<int32_t> pts;
+  for (int b = 0; b < n; ++b)
+    for (const auto& c : cands[b]) {
+      if ((int)c.size() > kBoxScoreMaxPts) fail(OCR_ERR_INVALID, "polygon with %zu vertices exceeds %d", c.size(), kBoxScoreMaxPts);
+      int mnx = INT32_MAX, mxx = 0, mny = INT32_MAX, mxy = 0;
+      for (const auto& p : c) {
+        mnx = std::min(mnx, p.x);
+        mxx = std::max(mxx, p.x);
+        mny = std::min(mny, p.y);
+        mxy = std::max(mxy, p.y);
+      }
+      // the reference clamps x by size[-2] (=H) and y by size[-1] (=W): metrics.rs:151-166
+      const int cw = h, ch = w;
+      mnx = std::clamp(mnx, 0, cw - 1);
+      mxx = std::clamp(mxx, 0, cw - 1);
+      mny = std::clamp(mny, 0, ch - 1);
+      mxy = std::clamp(mxy, 0, ch - 1);
+      if (mxx >= w || mxy >= h) fail(OCR_ERR_INVALID, "non-square map: box (%d,%d) leaves the %dx%d map (the reference would fail in narrow())", mxx, mxy, w, h);
+      BoxScoreJob j{b, (int)(pts.size() / 2), (int)c.size(), mnx, mny, mxx - mnx + 1, mxy - mny + 1};
+      jobs.push_back(j);
+      for (const auto& p : c) {
+        pts.push_back(p.x);
+        pts.push_back(p.y);
+      }
+    }
+  const int nj = (int)jobs.size();
+  std::vector<double> sums(nj), counts(nj);
+  if (nj > 0) {
+    const size_t o_jobs = off_bitmap + align256(px);
+    const size_t o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
+    const size_t o_sum = o_pts + align256(pts.size() * 4);
+    const size_t o_cnt = o_sum + align256((size_t)nj * 8);
+    const size_t total = o_cnt + align256((size_t)nj * 8);
+    // growing the scratch may move it: the probability copy must survive
+    if (mem_kind == OCR_MEM_HOST) {
+      char* ns = static_cast<char*>(det.scratch(total));
+      if (ns != scratch) {
+        scratch = ns;
+        OCR_HIP(hipMemcpyAsync(scratch, prob, px * 4, hipMemcpyHostToDevice, s));
+        prob_dev = reinterpret_cast<const float*>(scratch);
+      }
+    } else {
+      scratch = static_cast<char*>(det.scratch(total));
+    }
+    OCR_HIP(hipMemcpyAsync(scratch + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
+    OCR_HIP(hipMemcpyAsync(scratch + o_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice, s));
+    launch_box_scores(prob_dev, h, w, reinterpret_cast<const BoxScoreJob*>(scratch + o_jobs),
+                      reinterpret_cast<const int32_t*>(scratch + o_pts), nj, reinterpret_cast<double*>(scratch + o_sum),
+                      reinterpret_cast<double*>(scratch + o_cnt), s);
+    OCR_HIP(hipMemcpyAsync(sums.data(), scratch + o_sum, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipMemcpyAsync(counts.data(), scratch + o_cnt, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
+  }
+
+  // unclip + filters + coordinate adjustment (metrics.rs:100-123), assemble the CSR block
+  auto res = std::make_unique<PolygonsOwned>();
+  res->img_offsets.push_back(0);
+  res->poly_offsets.push_back(0);
+  int j = 0;
+  for (int b = 0; b < n; ++b) {
+    for (const auto& c : cands[b]) {
+      const double score = sums[j] / counts[j];
+      ++j;
+      if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, res->xy)) {
+        res->poly_offsets.push_back((int32_t)(res->xy.size() / 2));
+        res->scores.push_back(score);
+      }
+    }
+    res->img_offsets.push_back((int32_t)res->scores.size());
+  }
+  res->view.n_images = n;
+  res->view.n_polygons = (int32_t)res->scores.size();
+  res->view.n_vertices = (int32_t)(res->xy.size() / 2);
+  res->view.img_offsets = res->img_offsets.data();
+  res->view.poly_offsets = res->poly_offsets.data();
+  res->view.xy = res->xy.data();
+  res->view.scores = res->scores.data();
+  *out = &res.release()->view;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ocr_last_error(void) { return g_err.c_str(); }
+const char* ocr_version(void) { return "ocr_amd 0.1 gfx950"; }
+int ocr_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int ocr_det_create(const void* weights, size_t bytes, int device, ocr_det_t** out) {
+  return guard([&] {
+    if (!out) ocr::fail(OCR_ERR_INVALID, "ocr_det_create: out is null");
+    *out = nullptr;
+    *out = new ocr_det(weights, bytes, device);
+  });
+}
+void ocr_det_destroy(ocr_det_t* det) { delete det; }
+
+int ocr_det_set_stream(ocr_det_t* det, void* s) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
+    det->impl.set_stream(static_cast<hipStream_t>(s));
+  });
+}
+
+int ocr_det_forward(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, int mem_kind) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
+    if (mem_kind == OCR_MEM_HOST) {
+      if (!x || !prob) ocr::fail(OCR_ERR_INVALID, "det_forward: null tensor");
+      if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32) ocr::fail(OCR_ERR_INVALID, "det_forward: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
+      det->impl.forward_host(x, n, h, w, prob);
+    } else if (mem_kind == OCR_MEM_DEVICE) {
+      det->impl.forward(x, n, h, w, prob, nullptr, 0.f, nullptr);
+      det->impl.synchronize();
+    } else {
+      ocr::fail(OCR_ERR_INVALID, "mem_kind %d", mem_kind);
+    }
+  });
+}
+
+int ocr_det_forward_async(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
+    det->impl.forward(x, n, h, w, prob, bitmap, thresh, nullptr);
+  });
+}
+
+int ocr_det_synchronize(ocr_det_t* det) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
+    det->impl.synchronize();
+  });
+}
+
+int ocr_det_forward_profile(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, int max_entries,
+                            const char** names, float* ms, double* flops, double* bytes, int* n_entries) {
+  return guard([&] {
+    if (!det || !n_entries) ocr::fail(OCR_ERR_INVALID, "null argument");
+    std::vector<ocr::ProfileEntry> prof;
+    det->impl.forward(x, n, h, w, prob, nullptr, 0.f, &prof);
+    const int k = std::min<int>(max_entries, (int)prof.size());
+    for (int i = 0; i < k; ++i) {
+      if (names) names[i] = prof[i].name;
+      if (ms) ms[i] = prof[i].ms;
+      if (flops) flops[i] = prof[i].flops;
+      if (bytes) bytes[i] = prof[i].bytes;
+    }
+    *n_entries = k;
+  });
+}
+
+void ocr_postproc_default_params(ocr_postproc_params_t* p) {
+  if (!p) return;
+  p->thresh = 0.6;        // metrics.rs:38
+  p->box_thresh = 0.7;    // metrics.rs:64
+  p->min_size = 5.0;      // metrics.rs:66
+  p->unclip_ratio = 2.0;  // metrics.rs:103
+}
+
+int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
+                        const ocr_postproc_params_t* params, ocr_polygons_t** out) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "det_postprocess needs a detector handle (GPU + stream)");
+    if (mem_kind != OCR_MEM_HOST && mem_kind != OCR_MEM_DEVICE) ocr::fail(OCR_ERR_INVALID, "mem_kind %d", mem_kind);
+    ocr_postproc_params_t prm;
+    ocr_postproc_default_params(&prm);
+    if (params) prm = *params;
+    if (out) *out = nullptr;
+    postprocess(det->impl, prob, n, h, w, mem_kind, adj, prm, out);
+  });
+}
+
+void ocr_polygons_free(ocr_polygons_t* p) {
+  if (!p) return;
+  delete reinterpret_cast<PolygonsOwned*>(reinterpret_cast<char*>(p) - offsetof(PolygonsOwned, view));
+}
+
+int ocr_rec_create(const void* weights, size_t bytes, int device, ocr_rec_t** out) {
+  return guard([&] {
+    if (!out) ocr::fail(OCR_ERR_INVALID, "ocr_rec_create: out is null");
+    *out = nullptr;
+    *out = new ocr_rec(weights, bytes, device);
+  });
+}
+void ocr_rec_destroy(ocr_rec_t* rec) { delete rec; }
+int ocr_rec_set_stream(ocr_rec_t* rec, void* s) {
+  return guard([&] {
+    if (!rec) ocr::fail(OCR_ERR_INVALID, "null handle");
+    rec->impl.set_stream(static_cast<hipStream_t>(s));
+  });
+}
+int ocr_rec_synchronize(ocr_rec_t* rec) {
+  return guard([&] {
+    if (!rec) ocr::fail(OCR_ERR_INVALID, "null handle");
+    rec->impl.synchronize();
+  });
+}
+int ocr_rec_forward(ocr_rec_t* rec, const float* crops, int n, float* logits, int mem_kind) {
+  return guard([&] {
+    if (!rec || !crops || !logits) ocr::fail(OCR_ERR_INVALID, "null argument");
+    if (n < 0) ocr::fail(OCR_ERR_INVALID, "negative crop count");
+    if (mem_kind == OCR_MEM_HOST) rec->impl.forward_host(crops, n, logits, nullptr, nullptr);
+    else {
+      rec->impl.classify(crops, n, logits, nullptr, nullptr);
+      rec->impl.synchronize();
+    }
+  });
+}
+int ocr_rec_classify_async(ocr_rec_t* rec, const float* crops, int n, float* logits, int32_t* labels, double* probs) {
+  return guard([&] {
+    if (!rec) ocr::fail(OCR_ERR_INVALID, "null handle");
+    rec->impl.classify(crops, n, logits, labels, probs);
+  });
+}
+int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels, double* probs, int mem_kind) {
+  return guard([&] {
+    if (!rec || !crops) ocr::fail(OCR_ERR_INVALID, "null argument");
+    if (n < 0) ocr::fail(OCR_ERR_INVALID, "negative crop count");
+    if (mem_kind == OCR_MEM_HOST) rec->impl.forward_host(crops, n, nullptr, labels, probs);
+    else {
+      rec->impl.classify(crops, n, nullptr, labels, probs);
+      rec->impl.synchronize();
+    }
+  });
+}
+const char* ocr_rec_alphabet(void) { return "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"; }
+
+/* ---- host-geometry test hooks (no GPU needed): used by the CPU test-suite to pin the
+ * product's C++ geometry against the reference KATs.  Not part of the drop-in surface. */
+int ocr_test_contour_candidates(const uint8_t* bitmap01, int h, int w, int32_t* xy_out, int32_t* counts_out,
+                                int max_pts, int max_polys, int* n_polys) {
+  return guard([&] {
+    std::vector<std::vector<ocr::geom::Pt>> cands;
+    ocr::geom::contour_candidates(bitmap01, h, w, cands);
+    int np = 0, used = 0;
+    for (const auto& c : cands) {
+      if (np >= max_polys || used + (int)c.size() > max_pts) ocr::fail(OCR_ERR_INVALID, "test buffer too small");
+      counts_out[np++] = (int)c.size();
+      for (const auto& p : c) {
+        xy_out[2 * used] = p.x;
+        xy_out[2 * used + 1] = p.y;
+        ++used;
+      }
+    }
+    *n_polys = np;
+  });
+}
+int ocr_test_expand_polygon(const int32_t* xy, int n, double factor, int32_t* xy_out, int max_out, int* n_out,
+                            double* sside_out) {
+  return guard([&] {
+    std::vector<ocr::geom::Pt> in(n), out;
+    for (int i = 0; i < n; ++i) in[i] = {xy[2 * i], xy[2 * i + 1]};
+    if (!ocr::geom::expand_polygon(in, factor, out)) {
+      *n_out = 0;
+      return;
+    }
+    if ((int)out.size() > max_out) ocr::fail(OCR_ERR_INVALID, "test buffer too small");
+    for (size_t i = 0; i < out.size(); ++i) {
+      xy_out[2 * i] = out[i].x;
+      xy_out[2 * i + 1] = out[i].y;
+    }
+    *n_out = (int)out.size();
+    ocr::geom::Pt box[4];
+    if (sside_out) *sside_out = ocr::geom::min_area_bounding_box(out, box);
+  });
+}
+int ocr_test_det_stage(ocr_det_t* det, int id, float* out_host, size_t capacity, size_t* elems) {
+  return guard([&] {
+    if (!det || !elems) ocr::fail(OCR_ERR_INVALID, "null argument");
+    const float* p = det->impl.stage(id, elems);
+    if (out_host) {
+      if (*elems > capacity) ocr::fail(OCR_ERR_INVALID, "stage %d needs %zu floats", id, *elems);
+      det->impl.synchronize();
+      OCR_HIP(hipMemcpy(out_host, p, *elems * sizeof(float), hipMemcpyDeviceToHost));
+    }
+  });
+}
+int ocr_test_min_area_box(const int32_t* xy, int n, int32_t* box_xy, double* sside) {
+  return guard([&] {
+    std::vector<ocr::geom::Pt> in(n);
+    for (int i = 0; i < n; ++i) in[i] = {xy[2 * i], xy[2 * i + 1]};
+    ocr::geom::Pt box[4];
+    *sside = ocr::geom::min_area_bounding_box(in, box);
+    for (int i = 0; i < 4; ++i) {
+      box_xy[2 * i] = box[i].x;
+      box_xy[2 * i + 1] = box[i].y;
+    }
+  });
+}
+
+}  // extern "C"

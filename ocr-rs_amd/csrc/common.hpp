@@ -1,0 +1,91 @@
+// Shared declarations of the MI355X-native OCR hot path (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/ocr_amd.h"
+
+namespace ocr {
+
+// Error carried to the C boundary; never crosses it as an exception.
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+#define OCR_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      ::ocr::fail(OCR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+// ---- kernel launch descriptors ------------------------------------------------
+
+enum SrcMode { SRC_PLAIN = 0, SRC_UPADD = 1, SRC_CAT4 = 2 };
+enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1 };
+
+// One convolution as an implicit GEMM: M = N*Ho*Wo pixels, N = Cout, K = ks*ks*Cin.
+// Activations are NHWC f32, weights [Cout][ks*ks][Cin] f32.
+struct ConvDesc {
+  const float* src[4];    // PLAIN: src[0]; UPADD: src[0] + up2(src[1]); CAT4: p5,p4,p3,p2
+  int src_mode;
+  int N, Hin, Win, Cin;   // logical input grid of this conv
+  int Ho, Wo, Cout;
+  int ks, stride, pad;
+  const float* wgt;
+  const float* scale;     // per output column, may be null (then scale 1 / bias 0)
+  const float* bias;
+  const float* residual;  // NHWC, shape of the output, may be null
+  int relu;
+  int store_mode;
+  float* out;
+  const char* name;
+};
+
+void launch_conv_igemm(const ConvDesc& d, hipStream_t s);
+const char* conv_igemm_kernel_name(const ConvDesc& d);
+
+// stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
+void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,
+                 float* out, int N, int H, int W, hipStream_t s);
+// tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
+void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
+                           uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);
+void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n, hipStream_t s);
+
+// recognition net, fused
+struct RecWeights {
+  const float *c1w, *c1b, *c2w, *c2b, *f1w, *f1b, *f2w, *f2b;
+};
+void launch_rec_forward(const RecWeights& w, const float* crops, int n, float* logits,
+                        int32_t* labels, double* probs, hipStream_t s);
+
+// box score: masked mean of prob over rasterised polygons (metrics.rs:150-184)
+struct BoxScoreJob {
+  int image;      // batch index
+  int pt_offset;  // first point in the shared point array (x,y pairs, map coordinates)
+  int n_pts;
+  int min_x, min_y, bw, bh;  // mask canvas = clamped bounding box (metrics.rs:151-166)
+};
+constexpr int kBoxScoreMaxPts = 2048;
+void launch_box_scores(const float* prob, int H, int W, const BoxScoreJob* jobs_dev,
+                       const int32_t* pts_xy_dev, int n_jobs, double* sums_dev, double* counts_dev,
+                       hipStream_t s);
+
+}  // namespace ocr

@@ -1,0 +1,320 @@
+// NHWC f32 convolution as an implicit GEMM on the CDNA4 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32 FMA chain, 157 TF/s chip peak).
+//
+// Implements every conv of /root/reference/src/text_detection/model.rs:107-151:
+//   3x3 s1/s2 p1 (basic_block :40-55, out2..5 :80-98, bin_conv1 :100), 1x1 s1/s2
+//   (downsample :30-38, in2..in5 :75-78) and, as a 1x1 GEMM with a pixel-shuffle
+//   store, conv_transpose2d k=2 s=2 (bin_conv_tr1 :103).
+// Fused into the A-operand gather: nearest-upsample(x2) + add (:126-137) and the
+// channel concat of the four FPN outputs with their x8/x4/x2 upsamples (:140).
+// Fused into the epilogue: eval-mode batch norm as scale/bias, residual add, ReLU.
+//
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 32; each wave owns
+// (BM/2) x (BN/2) as 32x32 MFMA tiles.  Operands are staged global -> VGPR -> LDS
+// (K-contiguous rows, stride 36 floats: conflict-free ds_read_b128), next K-step's
+// global loads are in flight while the current step's MFMAs run.
+#include "common.hpp"
+
+namespace ocr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* src[4];
+  const float* wgt;
+  const float* scale;
+  const float* bias;
+  const float* residual;
+  float* out;
+  int N, Hin, Win, Cin;
+  int Ho, Wo, Cout;
+  int M;        // N*Ho*Wo
+  int pad;
+  int relu;
+  int nblk_n;   // Cout / BN
+  int nblk;     // total blocks
+};
+
+// Consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its
+// own L2).  Remap so that every XCD walks a contiguous run of tiles: neighbouring
+// tiles share input halos and weight panels (bijective for any block count).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+constexpr int BK = 32;
+constexpr int LDSK = 36;  // row stride in floats (144 B): 16-lane groups hit 16 distinct bank quads
+
+template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDSK];
+  float* As = lds;
+  float* Bs = lds + BM * LDSK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  const int tile_n = bid % p.nblk_n;
+  const int tile_m = bid / p.nblk_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-thread gather coordinates: row r (+32 i), 16-byte chunk q of the K slab
+  const int r = tid >> 3;
+  const int q = tid & 7;
+  int img[AI], ih0[AI], iw0[AI];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r + 32 * i;
+    if (m < p.M) {
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int oh = rem / p.Wo;
+      const int ow = rem - oh * p.Wo;
+      img[i] = n;
+      ih0[i] = oh * STRIDE - p.pad;
+      iw0[i] = ow * STRIDE - p.pad;
+    } else {
+      img[i] = 0;
+      ih0[i] = -(1 << 20);  // every tap out of range -> zeros
+      iw0[i] = 0;
+    }
+  }
+  const float* wrow[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i)
+    wrow[i] = p.wgt + (size_t)(n0 + r + 32 * i) * (KS * KS) * p.Cin + q * 4;
+
+  f32x4 areg[AI], breg[BI];
+
+  auto load_tiles = [&](int tap, int c0) {
+    const int kh = tap / KS, kw = tap - kh * KS;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int ih = ih0[i] + kh, iw = iw0[i] + kw;
+      const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        if constexpr (SRC == SRC_PLAIN) {
+          const size_t pix = ((size_t)img[i] * p.Hin + ih) * p.Win + iw;
+          v = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
+        } else if constexpr (SRC == SRC_UPADD) {
+          const size_t pix = ((size_t)img[i] * p.Hin + ih) * p.Win + iw;
+          const size_t pix1 = ((size_t)img[i] * (p.Hin >> 1) + (ih >> 1)) * (p.Win >> 1) + (iw >> 1);
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.src[1] + pix1 * p.Cin + c0 + q * 4);
+          v = b + a;  // reference order: upsample(x_in{k+1}) + x_in{k}
+        } else {      // SRC_CAT4: channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
+          const int s = c0 >> 6;
+          const int sh = 3 - s;
+          const size_t pix = ((size_t)img[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh);
+          v = *reinterpret_cast<const f32x4*>(p.src[s] + pix * 64 + (c0 & 63) + q * 4);
+        }
+      }
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      breg[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)tap * p.Cin + c0);
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      *reinterpret_cast<f32x4*>(&As[(r + 32 * i) * LDSK + q * 4]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      *reinterpret_cast<f32x4*>(&Bs[(r + 32 * i) * LDSK + q * 4]) = breg[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int csteps = p.Cin / BK;
+  const int nsteps = KS * KS * csteps;
+  int tap = 0, c0 = 0;
+
+  load_tiles(0, 0);
+  store_tiles();
+  __syncthreads();
+
+  // MFMA operand fetch: lane l supplies row (l & 31); lanes 0-31 hold k = 8g+j,
+  // lanes 32-63 hold k = 8g+4+j for the j-th MFMA of K-group g (same map for A and B).
+  const float* a_base = As + (wm * WM + (lane & 31)) * LDSK + (lane >> 5) * 4;
+  const float* b_base = Bs + (wn * WN + (lane & 31)) * LDSK + (lane >> 5) * 4;
+
+  for (int step = 0; step < nsteps; ++step) {
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      c0 += BK;
+      if (c0 == p.Cin) {
+        c0 = 0;
+        ++tap;
+      }
+      load_tiles(tap, c0);
+    }
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDSK + g * 8);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDSK + g * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const int colq = lane & 31;
+  const int rowq = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * WN + j * 32 + colq;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float bi = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq;
+        if (m < p.M) {
+          float v = acc[i][j][e] * sc + bi;
+          if constexpr (STORE == STORE_NHWC) {
+            const size_t o = (size_t)m * p.Cout + col;
+            if (p.residual) v += p.residual[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.out[o] = v;
+          } else {
+            // conv_transpose2d k=2 s=2: column = (a*2+b)*64 + co -> out[n][2i+a][2j+b][co]
+            if (p.relu) v = fmaxf(v, 0.f);
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int oh = rem / p.Wo;
+            const int ow = rem - oh * p.Wo;
+            const int t = col >> 6, co = col & 63;
+            const size_t o = (((size_t)n * (2 * p.Ho) + 2 * oh + (t >> 1)) * (2 * p.Wo) + 2 * ow + (t & 1)) * 64 + co;
+            p.out[o] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
+void launch_inst(const ConvDesc& d, hipStream_t s) {
+  ConvArgs a;
+  for (int i = 0; i < 4; ++i) a.src[i] = d.src[i];
+  a.wgt = d.wgt;
+  a.scale = d.scale;
+  a.bias = d.bias;
+  a.residual = d.residual;
+  a.out = d.out;
+  a.N = d.N;
+  a.Hin = d.Hin;
+  a.Win = d.Win;
+  a.Cin = d.Cin;
+  a.Ho = d.Ho;
+  a.Wo = d.Wo;
+  a.Cout = d.Cout;
+  a.M = d.N * d.Ho * d.Wo;
+  a.pad = d.pad;
+  a.relu = d.relu;
+  a.nblk_n = d.Cout / BN;
+  const int nblk_m = (a.M + BM - 1) / BM;
+  a.nblk = nblk_m * a.nblk_n;
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), 0, s, a);
+  OCR_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+// Host-side shape checks: the kernel assumes exactly these, and an out-of-bounds
+// access on the GPU can take the whole node down.
+static void check(const ConvDesc& d) {
+  if (d.Cin % BK != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, BK);
+  if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
+  if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
+  if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);
+  if (d.pad != (d.ks - 1) / 2) fail(OCR_ERR_INVALID, "%s: pad %d", d.name, d.pad);
+  if (d.Ho != (d.Hin + 2 * d.pad - d.ks) / d.stride + 1 || d.Wo != (d.Win + 2 * d.pad - d.ks) / d.stride + 1)
+    fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
+  if ((long long)d.N * d.Ho * d.Wo >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: M overflows int", d.name);
+  if (d.src_mode == SRC_UPADD && ((d.Hin | d.Win) & 1)) fail(OCR_ERR_INVALID, "%s: UPADD needs even grid", d.name);
+  if (d.src_mode == SRC_CAT4 && (d.Cin != 256 || ((d.Hin | d.Win) & 7)))
+    fail(OCR_ERR_INVALID, "%s: CAT4 needs Cin 256 and a grid divisible by 8", d.name);
+  if (d.store_mode == STORE_SHUFFLE2 && (d.Cout != 256 || d.ks != 1 || d.residual))
+    fail(OCR_ERR_INVALID, "%s: SHUFFLE2 store needs a 1x1 conv with Cout 4*64", d.name);
+  if (!d.src[0] || !d.wgt || !d.out) fail(OCR_ERR_INVALID, "%s: null operand", d.name);
+}
+
+enum Variant { V_3x3_S1_64, V_3x3_S1_128, V_3x3_S2_128, V_1x1_S1_128, V_1x1_S2_128, V_UPADD_64, V_CAT4_64, V_SHUFFLE_128, V_NONE };
+
+static Variant pick(const ConvDesc& d) {
+  if (d.store_mode == STORE_SHUFFLE2) return V_SHUFFLE_128;
+  if (d.src_mode == SRC_UPADD) return (d.ks == 3 && d.stride == 1 && d.Cout == 64) ? V_UPADD_64 : V_NONE;
+  if (d.src_mode == SRC_CAT4) return (d.ks == 3 && d.stride == 1 && d.Cout == 64) ? V_CAT4_64 : V_NONE;
+  if (d.ks == 3 && d.stride == 1) return d.Cout == 64 ? V_3x3_S1_64 : (d.Cout % 128 == 0 ? V_3x3_S1_128 : V_NONE);
+  if (d.ks == 3 && d.stride == 2) return d.Cout % 128 == 0 ? V_3x3_S2_128 : V_NONE;
+  if (d.ks == 1 && d.stride == 1) return d.Cout % 128 == 0 ? V_1x1_S1_128 : V_NONE;
+  if (d.ks == 1 && d.stride == 2) return d.Cout % 128 == 0 ? V_1x1_S2_128 : V_NONE;
+  return V_NONE;
+}
+
+const char* conv_igemm_kernel_name(const ConvDesc& d) {
+  switch (pick(d)) {
+    case V_3x3_S1_64: return "conv_igemm_f32<128,64,3,1,PLAIN>";
+    case V_3x3_S1_128: return "conv_igemm_f32<128,128,3,1,PLAIN>";
+    case V_3x3_S2_128: return "conv_igemm_f32<128,128,3,2,PLAIN>";
+    case V_1x1_S1_128: return "conv_igemm_f32<128,128,1,1,PLAIN>";
+    case V_1x1_S2_128: return "conv_igemm_f32<128,128,1,2,PLAIN>";
+    case V_UPADD_64: return "conv_igemm_f32<128,64,3,1,UPADD>";
+    case V_CAT4_64: return "conv_igemm_f32<128,64,3,1,CAT4>";
+    case V_SHUFFLE_128: return "conv_igemm_f32<128,128,1,1,PLAIN,SHUFFLE2>";
+    default: return "conv_igemm_f32<?>";
+  }
+}
+
+void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
+  check(d);
+  switch (pick(d)) {
+    case V_3x3_S1_64: launch_inst<128, 64, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s); break;
+    case V_3x3_S1_128: launch_inst<128, 128, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s); break;
+    case V_3x3_S2_128: launch_inst<128, 128, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s); break;
+    case V_1x1_S1_128: launch_inst<128, 128, 1, 1, SRC_PLAIN, STORE_NHWC>(d, s); break;
+    case V_1x1_S2_128: launch_inst<128, 128, 1, 2, SRC_PLAIN, STORE_NHWC>(d, s); break;
+    case V_UPADD_64: launch_inst<128, 64, 3, 1, SRC_UPADD, STORE_NHWC>(d, s); break;
+    case V_CAT4_64: launch_inst<128, 64, 3, 1, SRC_CAT4, STORE_NHWC>(d, s); break;
+    case V_SHUFFLE_128: launch_inst<128, 128, 1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s); break;
+    default: fail(OCR_ERR_INVALID, "%s: no conv_igemm variant for ks=%d stride=%d Cout=%d mode=%d", d.name, d.ks, d.stride, d.Cout, d.src_mode);
+  }
+}
+
+}  // namespace ocr

@@ -1,0 +1,422 @@
+// Host-side schedule of the detection / recognition graphs.
+//   /root/reference/src/text_detection/model.rs:65-152   (resnet18, eval mode)
+//   /root/reference/src/char_recognition/model.rs:13-39
+// Weights are re-laid out once at create time (OIHW -> OHWI, eval batch norm folded
+// to per-channel scale/bias); activations live in NHWC f32 workspaces in HBM.
+#include "engine.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace ocr {
+
+void check_device(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    fail(OCR_ERR_NOGPU, "no HIP device visible: this library has no CPU fallback");
+  if (device < 0 || device >= count) fail(OCR_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+  hipDeviceProp_t prop;
+  OCR_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    fail(OCR_ERR_NOGPU, "device %d is %s; the kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  OCR_HIP(hipSetDevice(device));
+}
+
+DeviceArena::~DeviceArena() {
+  if (base_) (void)hipFree(base_);
+}
+void DeviceArena::reserve(size_t bytes) {
+  OCR_HIP(hipMalloc(reinterpret_cast<void**>(&base_), bytes));
+  cap_ = bytes;
+  used_ = 0;
+}
+float* DeviceArena::upload(const std::vector<float>& host) {
+  const size_t bytes = (host.size() * sizeof(float) + 255) / 256 * 256;
+  if (used_ + bytes > cap_) fail(OCR_ERR_INTERNAL, "weight arena overflow");
+  float* p = reinterpret_cast<float*>(base_ + used_);
+  OCR_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  used_ += bytes;
+  return p;
+}
+
+// eval batch norm (tch batch_norm2d default eps 1e-5) -> y = x*scale + bias
+static void fold_bn(const WeightBlob& wb, const std::string& p, int c, std::vector<float>& scale, std::vector<float>& bias) {
+  const float* g = wb.get(p + ".weight", {c}).data;
+  const float* b = wb.get(p + ".bias", {c}).data;
+  const float* m = wb.get(p + ".running_mean", {c}).data;
+  const float* v = wb.get(p + ".running_var", {c}).data;
+  scale.resize(c);
+  bias.resize(c);
+  for (int i = 0; i < c; ++i) {
+    const float invstd = 1.0f / std::sqrt(v[i] + 1e-5f);
+    scale[i] = g[i] * invstd;
+    bias[i] = b[i] - m[i] * scale[i];
+  }
+}
+
+ConvW Detector::make_conv(const WeightBlob& wb, const std::string& wname, const std::string& bn, int cout, int cin, int ks) {
+  const float* w = wb.get(wname, {cout, cin, ks, ks}).data;
+  std::vector<float> t((size_t)cout * ks * ks * cin);
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < cin; ++c)
+      for (int k = 0; k < ks * ks; ++k) t[((size_t)o * ks * ks + k) * cin + c] = w[((size_t)o * cin + c) * ks * ks + k];
+  ConvW cw;
+  cw.w = arena_.upload(t);
+  cw.cin = cin;
+  cw.cout = cout;
+  cw.ks = ks;
+  if (!bn.empty()) {
+    std::vector<float> s, b;
+    fold_bn(wb, bn, cout, s, b);
+    cw.scale = arena_.upload(s);
+    cw.bias = arena_.upload(b);
+  }
+  return cw;
+}
+
+Detector::Detector(const void* blob, size_t bytes, int device) : device_(device) {
+  check_device(device);
+  WeightBlob wb(blob, bytes);
+  OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  stream_ = own_stream_;
+  arena_.reserve((size_t)64 << 20);  // 12.2 M parameters = 48.7 MB + padding
+
+  {  // conv1 [64,1,7,7] -> [49][64]; bn1
+    const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
+    std::vector<float> t(49 * 64);
+    for (int c = 0; c < 64; ++c)
+      for (int k = 0; k < 49; ++k) t[k * 64 + c] = w[c * 49 + k];
+    stem_w_ = arena_.upload(t);
+    std::vector<float> s, b;
+    fold_bn(wb, "bn1", 64, s, b);
+    stem_scale_ = arena_.upload(s);
+    stem_bias_ = arena_.upload(b);
+  }
+  int cin = 64;
+  for (int l = 0; l < 4; ++l) {
+    const int cout = 64 << l;
+    for (int b = 0; b < 2; ++b) {
+      const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(b);
+      layer_[l][b][0] = make_conv(wb, p + ".conv1.weight", p + ".bn1", cout, b == 0 ? cin : cout, 3);
+      layer_[l][b][1] = make_conv(wb, p + ".conv2.weight", p + ".bn2", cout, cout, 3);
+    }
+    if (l > 0) {
+      const std::string p = "layer" + std::to_string(l + 1) + ".0.downsample";
+      down_[l] = make_conv(wb, p + ".0.weight", p + ".1", cout, cin, 1);
+    }
+    cin = cout;
+  }
+  for (int l = 0; l < 4; ++l) {
+    in_[l] = make_conv(wb, "in" + std::to_string(l + 2) + ".weight", "", 256, 64 << l, 1);
+    out_[l] = make_conv(wb, "out" + std::to_string(l + 2) + ".weight", "", 64, 256, 3);
+  }
+  bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
+  {  // bin_conv_tr1 [Cin=64][Cout=64][2][2] + bias, then bin_bn2:
+     // GEMM B rows = (a*2+b)*64 + co over K = ci; (acc + bias)*s + t = acc*s + (bias*s + t)
+    const float* w = wb.get("bin_conv_tr1.weight", {64, 64, 2, 2}).data;
+    const float* bias = wb.get("bin_conv_tr1.bias", {64}).data;
+    std::vector<float> t(256 * 64), s, b, s4(256), b4(256);
+    for (int ci = 0; ci < 64; ++ci)
+      for (int co = 0; co < 64; ++co)
+        for (int k = 0; k < 4; ++k) t[((size_t)k * 64 + co) * 64 + ci] = w[((size_t)ci * 64 + co) * 4 + k];
+    fold_bn(wb, "bin_bn2", 64, s, b);
+    for (int k = 0; k < 4; ++k)
+      for (int co = 0; co < 64; ++co) {
+        s4[k * 64 + co] = s[co];
+        b4[k * 64 + co] = bias[co] * s[co] + b[co];
+      }
+    tr1_.w = arena_.upload(t);
+    tr1_.scale = arena_.upload(s4);
+    tr1_.bias = arena_.upload(b4);
+    tr1_.cin = 64;
+    tr1_.cout = 256;
+    tr1_.ks = 1;
+  }
+  {  // bin_conv_tr2 [64][1][2][2] -> [4][64]
+    const float* w = wb.get("bin_conv_tr2.weight", {64, 1, 2, 2}).data;
+    std::vector<float> t(4 * 64);
+    for (int ci = 0; ci < 64; ++ci)
+      for (int k = 0; k < 4; ++k) t[k * 64 + ci] = w[ci * 4 + k];
+    tr2_w_ = arena_.upload(t);
+    tr2_bias_ = wb.get("bin_conv_tr2.bias", {1}).data[0];
+  }
+}
+
+void Detector::free_workspace() {
+  for (void* p : ws_allocs_) (void)hipFree(p);
+  ws_allocs_.clear();
+  ws_n_ = ws_h_ = ws_w_ = 0;
+}
+
+Detector::~Detector() {
+  (void)hipSetDevice(device_);
+  if (own_stream_) (void)hipStreamSynchronize(own_stream_);
+  free_workspace();
+  if (scratch_) (void)hipFree(scratch_);
+  if (stage_in_) (void)hipFree(stage_in_);
+  if (stage_out_) (void)hipFree(stage_out_);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void Detector::synchronize() {
+  OCR_HIP(hipSetDevice(device_));
+  OCR_HIP(hipStreamSynchronize(stream_));
+}
+
+void* Detector::scratch(size_t bytes) {
+  if (bytes > scratch_bytes_) {
+    OCR_HIP(hipStreamSynchronize(stream_));
+    if (scratch_) OCR_HIP(hipFree(scratch_));
+    scratch_ = nullptr;
+    scratch_bytes_ = 0;
+    OCR_HIP(hipMalloc(&scratch_, bytes));
+    scratch_bytes_ = bytes;
+  }
+  return scratch_;
+}
+
+void Detector::ensure_workspace(int n, int h, int w) {
+  if (n == ws_n_ && h == ws_h_ && w == ws_w_) return;
+  OCR_HIP(hipStreamSynchronize(stream_));
+  free_workspace();
+  auto alloc = [&](size_t elems) {
+    void* p = nullptr;
+    OCR_HIP(hipMalloc(&p, elems * sizeof(float)));
+    ws_allocs_.push_back(p);
+    return static_cast<float*>(p);
+  };
+  const size_t N = (size_t)n;
+  s_ = alloc(N * (h / 4) * (w / 4) * 64);
+  for (int l = 0; l < 4; ++l) {
+    const size_t px = N * (h >> (2 + l)) * (w >> (2 + l));
+    const size_t c = (size_t)64 << l;
+    t_[l] = alloc(px * c);
+    a_[l] = alloc(px * c);
+    x_[l] = alloc(px * c);
+    d_[l] = l > 0 ? alloc(px * c) : nullptr;
+    i_[l] = alloc(px * 256);
+    p_[l] = alloc(px * 64);
+  }
+  b1_ = alloc(N * (h / 4) * (w / 4) * 64);
+  tr1buf_ = alloc(N * (h / 2) * (w / 2) * 64);
+  ws_n_ = n;
+  ws_h_ = h;
+  ws_w_ = w;
+}
+
+namespace {
+struct Recorder {
+  std::vector<ProfileEntry>* prof;
+  hipStream_t s;
+  std::vector<hipEvent_t> ev;
+  void begin() {
+    if (!prof) return;
+    hipEvent_t e;
+    OCR_HIP(hipEventCreate(&e));
+    OCR_HIP(hipEventRecord(e, s));
+    ev.push_back(e);
+  }
+  void end(const char* name, double flops, double bytes) {
+    if (!prof) return;
+    hipEvent_t e;
+    OCR_HIP(hipEventCreate(&e));
+    OCR_HIP(hipEventRecord(e, s));
+    ev.push_back(e);
+    prof->push_back({name, 0.f, flops, bytes});
+  }
+  void finish() {
+    if (!prof) return;
+    OCR_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < prof->size(); ++i) OCR_HIP(hipEventElapsedTime(&(*prof)[i].ms, ev[2 * i], ev[2 * i + 1]));
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+  }
+};
+}  // namespace
+
+void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+                       std::vector<ProfileEntry>* prof) {
+  if (!x || !prob) fail(OCR_ERR_INVALID, "det_forward: null tensor");
+  if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32)
+    fail(OCR_ERR_INVALID, "det_forward: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
+  OCR_HIP(hipSetDevice(device_));
+  ensure_workspace(n, h, w);
+  Recorder rec{prof, stream_, {}};
+
+  auto conv = [&](const char* name, const ConvW& cw, const float* src, int hin, int win, int stride, float* out,
+                  const float* residual, bool relu, int src_mode = SRC_PLAIN, const float* s1 = nullptr,
+                  const float* s2 = nullptr, const float* s3 = nullptr, int store = STORE_NHWC) {
+    ConvDesc d{};
+    d.src[0] = src;
+    d.src[1] = s1;
+    d.src[2] = s2;
+    d.src[3] = s3;
+    d.src_mode = src_mode;
+    d.N = n;
+    d.Hin = hin;
+    d.Win = win;
+    d.Cin = cw.cin;
+    d.ks = cw.ks;
+    d.stride = stride;
+    d.pad = (cw.ks - 1) / 2;
+    d.Ho = (hin + 2 * d.pad - cw.ks) / stride + 1;
+    d.Wo = (win + 2 * d.pad - cw.ks) / stride + 1;
+    d.Cout = cw.cout;
+    d.wgt = cw.w;
+    d.scale = cw.scale;
+    d.bias = cw.bias;
+    d.residual = residual;
+    d.relu = relu ? 1 : 0;
+    d.store_mode = store;
+    d.out = out;
+    d.name = name;
+    rec.begin();
+    launch_conv_igemm(d, stream_);
+    const double M = (double)n * d.Ho * d.Wo;
+    const double K = (double)cw.ks * cw.ks * cw.cin;
+    double in_bytes = (double)n * hin * win * cw.cin * 4.0;
+    if (src_mode == SRC_UPADD) in_bytes *= 1.25;
+    if (src_mode == SRC_CAT4) in_bytes = (double)n * hin * win * 64 * 4.0 * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
+    const double bytes = in_bytes + M * cw.cout * 4.0 * (residual ? 2.0 : 1.0) + K * cw.cout * 4.0;
+    rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, bytes);
+  };
+
+  const int h4 = h / 4, w4 = w / 4;
+  rec.begin();
+  launch_stem(x, stem_w_, stem_scale_, stem_bias_, s_, n, h, w, stream_);
+  rec.end("stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
+          (double)n * h * w * 4 + (double)n * h4 * w4 * 64 * 4);
+
+  // ResNet-18 trunk, model.rs:113-120 (basic_block :40-55)
+  const float* cur = s_;
+  for (int l = 0; l < 4; ++l) {
+    const int hin = l == 0 ? h4 : (h >> (1 + l)), win = l == 0 ? w4 : (w >> (1 + l));
+    const int ho = h >> (2 + l), wo = w >> (2 + l);
+    const int stride = l == 0 ? 1 : 2;
+    conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], nullptr, true);
+    const float* shortcut = cur;
+    if (l > 0) {
+      conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], nullptr, false);
+      shortcut = d_[l];
+    }
+    conv("layer.conv2", layer_[l][0][1], t_[l], ho, wo, 1, a_[l], shortcut, true);
+    conv("layer.conv1", layer_[l][1][0], a_[l], ho, wo, 1, t_[l], nullptr, true);
+    conv("layer.conv2", layer_[l][1][1], t_[l], ho, wo, 1, x_[l], a_[l], true);
+    cur = x_[l];
+  }
+  // FPN laterals in2..in5, model.rs:115-123
+  for (int l = 0; l < 4; ++l) conv("in", in_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, i_[l], nullptr, false);
+  // p_k = out_k(up2(in_{k+1}) + in_k), p5 = out5(in5), model.rs:126-138
+  for (int l = 0; l < 3; ++l)
+    conv("out", out_[l], i_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], nullptr, false, SRC_UPADD, i_[l + 1]);
+  conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], nullptr, false);
+  // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
+  conv("bin_conv1", bin1_, p_[3], h4, w4, 1, b1_, nullptr, true, SRC_CAT4, p_[2], p_[1], p_[0]);
+  // bin_conv_tr1 + bias + bin_bn2 + relu, model.rs:146-148
+  conv("bin_conv_tr1", tr1_, b1_, h4, w4, 1, tr1buf_, nullptr, true, SRC_PLAIN, nullptr, nullptr, nullptr,
+       STORE_SHUFFLE2);
+  // bin_conv_tr2 + bias + sigmoid (+ binarize), model.rs:149-150
+  rec.begin();
+  launch_convt2_sigmoid(tr1buf_, tr2_w_, tr2_bias_, prob, bitmap, thresh, n, h / 2, w / 2, stream_);
+  rec.end("convt2x2_sigmoid", 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
+          (double)n * (h / 2) * (w / 2) * 64 * 4 + (double)n * h * w * 4);
+  rec.finish();
+}
+
+const float* Detector::stage(int id, size_t* elems) const {
+  if (ws_n_ == 0) fail(OCR_ERR_INVALID, "no forward has run yet");
+  const size_t N = (size_t)ws_n_;
+  auto px = [&](int shift) { return N * (ws_h_ >> shift) * (ws_w_ >> shift); };
+  if (id == 0) { *elems = px(2) * 64; return s_; }
+  if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return x_[id - 1]; }
+  if (id >= 5 && id <= 8) { *elems = px(id - 3) * 256; return i_[id - 5]; }
+  if (id >= 9 && id <= 12) { *elems = px(id - 7) * 64; return p_[id - 9]; }
+  if (id == 13) { *elems = px(2) * 64; return b1_; }
+  if (id == 14) { *elems = px(1) * 64; return tr1buf_; }
+  fail(OCR_ERR_INVALID, "unknown stage %d", id);
+}
+
+void Detector::forward_host(const float* x, int n, int h, int w, float* prob) {
+  OCR_HIP(hipSetDevice(device_));
+  const size_t elems = (size_t)n * h * w;
+  if (elems > stage_elems_) {
+    OCR_HIP(hipStreamSynchronize(stream_));
+    if (stage_in_) OCR_HIP(hipFree(stage_in_));
+    if (stage_out_) OCR_HIP(hipFree(stage_out_));
+    stage_in_ = stage_out_ = nullptr;
+    stage_elems_ = 0;
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&stage_in_), elems * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&stage_out_), elems * 4));
+    stage_elems_ = elems;
+  }
+  OCR_HIP(hipMemcpyAsync(stage_in_, x, elems * 4, hipMemcpyHostToDevice, stream_));
+  forward(stage_in_, n, h, w, stage_out_, nullptr, 0.f, nullptr);
+  OCR_HIP(hipMemcpyAsync(prob, stage_out_, elems * 4, hipMemcpyDeviceToHost, stream_));
+  OCR_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------------------
+
+Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(device) {
+  check_device(device);
+  WeightBlob wb(blob, bytes);
+  OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  stream_ = own_stream_;
+  arena_.reserve((size_t)4 << 20);
+  auto up = [&](const char* name, std::initializer_list<int> shape) {
+    const TensorView& t = wb.get(name, shape);
+    return arena_.upload(std::vector<float>(t.data, t.data + t.count));
+  };
+  w_.c1w = up("conv1.weight", {32, 1, 5, 5});
+  w_.c1b = up("conv1.bias", {32});
+  w_.c2w = up("conv2.weight", {64, 32, 5, 5});
+  w_.c2b = up("conv2.bias", {64});
+  w_.f1w = up("fc1.weight", {512, 1024});
+  w_.f1b = up("fc1.bias", {512});
+  w_.f2w = up("fc2.weight", {62, 512});
+  w_.f2b = up("fc2.bias", {62});
+}
+
+Recognizer::~Recognizer() {
+  (void)hipSetDevice(device_);
+  if (own_stream_) (void)hipStreamSynchronize(own_stream_);
+  if (stage_) (void)hipFree(stage_);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void Recognizer::synchronize() {
+  OCR_HIP(hipSetDevice(device_));
+  OCR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Recognizer::classify(const float* crops, int n, float* logits, int32_t* labels, double* probs) {
+  if (!crops || n < 0) fail(OCR_ERR_INVALID, "rec: null crops or negative count");
+  OCR_HIP(hipSetDevice(device_));
+  launch_rec_forward(w_, crops, n, logits, labels, probs, stream_);
+}
+
+void Recognizer::forward_host(const float* crops, int n, float* logits, int32_t* labels, double* probs) {
+  if (n <= 0) return;
+  OCR_HIP(hipSetDevice(device_));
+  const size_t b_in = (size_t)n * 784 * 4, b_lg = (size_t)n * 62 * 4, b_lab = (size_t)n * 4, b_pr = (size_t)n * 8;
+  const size_t o_lg = (b_in + 255) / 256 * 256, o_pr = o_lg + (b_lg + 255) / 256 * 256, o_lab = o_pr + (b_pr + 255) / 256 * 256;
+  const size_t total = o_lab + b_lab;
+  if (total > stage_bytes_) {
+    OCR_HIP(hipStreamSynchronize(stream_));
+    if (stage_) OCR_HIP(hipFree(stage_));
+    stage_ = nullptr;
+    stage_bytes_ = 0;
+    OCR_HIP(hipMalloc(&stage_, total));
+    stage_bytes_ = total;
+  }
+  char* base = static_cast<char*>(stage_);
+  OCR_HIP(hipMemcpyAsync(base, crops, b_in, hipMemcpyHostToDevice, stream_));
+  classify(reinterpret_cast<float*>(base), n, reinterpret_cast<float*>(base + o_lg),
+           reinterpret_cast<int32_t*>(base + o_lab), reinterpret_cast<double*>(base + o_pr));
+  if (logits) OCR_HIP(hipMemcpyAsync(logits, base + o_lg, b_lg, hipMemcpyDeviceToHost, stream_));
+  if (labels) OCR_HIP(hipMemcpyAsync(labels, base + o_lab, b_lab, hipMemcpyDeviceToHost, stream_));
+  if (probs) OCR_HIP(hipMemcpyAsync(probs, base + o_pr, b_pr, hipMemcpyDeviceToHost, stream_));
+  OCR_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace ocr

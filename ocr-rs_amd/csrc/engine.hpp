@@ -1,0 +1,101 @@
+// Detector / recogniser engines behind the C ABI (one GPU + one stream each).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "weights_blob.hpp"
+
+namespace ocr {
+
+struct ProfileEntry {
+  const char* name;
+  float ms;
+  double flops;
+  double bytes;
+};
+
+class DeviceArena {  // bump allocator over one hipMalloc (weights)
+ public:
+  ~DeviceArena();
+  void reserve(size_t bytes);
+  float* upload(const std::vector<float>& host);
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, used_ = 0;
+};
+
+struct ConvW {
+  float* w = nullptr;      // [Cout][ks*ks][Cin]
+  float* scale = nullptr;  // folded eval batch norm, may stay null
+  float* bias = nullptr;
+  int cin = 0, cout = 0, ks = 0;
+};
+
+class Detector {
+ public:
+  Detector(const void* blob, size_t bytes, int device);
+  ~Detector();
+  void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+  void synchronize();
+  // device pointers; enqueues on stream().  prof != null -> per-launch events.
+  void forward(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+               std::vector<ProfileEntry>* prof);
+  void forward_host(const float* x, int n, int h, int w, float* prob);
+  // scratch shared with post-processing
+  void* scratch(size_t bytes);
+  // test hook: NHWC intermediate of the last forward (0 stem, 1-4 layer1-4, 5-8 in2-5,
+  // 9-12 p2-p5 (before upsampling), 13 bin_conv1, 14 bin_conv_tr1)
+  const float* stage(int id, size_t* elems) const;
+
+ private:
+  void ensure_workspace(int n, int h, int w);
+  void free_workspace();
+  ConvW make_conv(const WeightBlob& wb, const std::string& wname, const std::string& bn, int cout, int cin, int ks);
+
+  int device_;
+  hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+  DeviceArena arena_;
+  float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
+  ConvW layer_[4][2][2];  // [layer][block][conv1|conv2]
+  ConvW down_[4];         // [layer] (layer 0 unused)
+  ConvW in_[4];           // in2..in5
+  ConvW out_[4];          // out2..out5
+  ConvW bin1_, tr1_;
+  float* tr2_w_ = nullptr;
+  float tr2_bias_ = 0.f;
+
+  int ws_n_ = 0, ws_h_ = 0, ws_w_ = 0;
+  std::vector<void*> ws_allocs_;
+  float *s_ = nullptr, *t_[4] = {}, *a_[4] = {}, *d_[4] = {}, *x_[4] = {};
+  float *i_[4] = {}, *p_[4] = {}, *b1_ = nullptr, *tr1buf_ = nullptr;
+  void* scratch_ = nullptr;
+  size_t scratch_bytes_ = 0;
+  float *stage_in_ = nullptr, *stage_out_ = nullptr;
+  size_t stage_elems_ = 0;
+};
+
+class Recognizer {
+ public:
+  Recognizer(const void* blob, size_t bytes, int device);
+  ~Recognizer();
+  void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
+  void synchronize();
+  void classify(const float* crops_dev, int n, float* logits_dev, int32_t* labels_dev, double* probs_dev);
+  void forward_host(const float* crops, int n, float* logits, int32_t* labels, double* probs);
+  int device() const { return device_; }
+
+ private:
+  int device_;
+  hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+  DeviceArena arena_;
+  RecWeights w_{};
+  void* stage_ = nullptr;
+  size_t stage_bytes_ = 0;
+};
+
+void check_device(int device);
+
+}  // namespace ocr

@@ -1,0 +1,34 @@
+// Host geometry of the detection post-processing (see postproc_geom.cpp).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/ocr_amd.h"
+
+namespace ocr {
+namespace geom {
+
+struct Pt {
+  int x, y;
+  bool operator==(const Pt& o) const { return x == o.x && y == o.y; }
+};
+
+void find_contours(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& out);
+double arc_length(const std::vector<Pt>& p, bool closed);
+void approximate_polygon_dp(const std::vector<Pt>& curve, double eps, bool closed, std::vector<Pt>& out);
+double min_area_bounding_box(const std::vector<Pt>& pts, Pt res[4]);
+double offset_distance(const std::vector<Pt>& poly, double factor);
+void raw_offset_ring(const std::vector<Pt>& poly, double delta, std::vector<Pt>& out);
+void positive_union_outer(const std::vector<Pt>& ring, std::vector<Pt>& out);
+bool expand_polygon(const std::vector<Pt>& pts, double factor, std::vector<Pt>& out);
+
+// contours -> Douglas-Peucker polygons with >= 4 points (metrics.rs:78-98)
+void contour_candidates(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& cands);
+// score threshold, unclip, min-size filter, round(p/adj) as u32 (metrics.rs:100-123).
+// Appends x,y pairs to xy_out and returns true when the polygon is kept.
+bool finish_polygon(const std::vector<Pt>& cand, double score, double adj_x, double adj_y,
+                    const ocr_postproc_params_t& prm, std::vector<uint32_t>& xy_out);
+
+}  // namespace geom
+}  // namespace ocr

@@ -1,0 +1,144 @@
+// Memory-bound ends of the detection graph (HBM roofline, not MFMA):
+//   stem : conv1 7x7 s2 p3 (1->64) + bn1 + ReLU + max_pool2d(3,2,1), one pass
+//          /root/reference/src/text_detection/model.rs:108-112
+//   tail : bin_conv_tr2 convT 2x2 s2 (64->1) + bias + sigmoid, optional fused
+//          binarize(pred, thresh)      model.rs:149-150, metrics.rs:129-131
+#include "common.hpp"
+
+namespace ocr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TPH = 4, TPW = 8;                 // pooled output tile per workgroup
+constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1;  // conv rows/cols feeding it (3x3 s2 window)
+constexpr int IR = 2 * (CR - 1) + 7, IC = 2 * (CC - 1) + 7;  // input rows/cols feeding those (7x7 s2)
+
+// grid (Wp/TPW, Hp/TPH, N), 256 threads: lane = output channel, wave = conv pixel slot.
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
+                                                   const float* __restrict__ scale, const float* __restrict__ bias,
+                                                   float* __restrict__ out, int H, int W) {
+  __shared__ float in_s[IR][IC + 1];
+  __shared__ float conv_s[CR * CC][64];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z;
+  const int ph0 = blockIdx.y * TPH, pw0 = blockIdx.x * TPW;
+  const int Hc = H >> 1, Wc = W >> 1, Hp = H >> 2, Wp = W >> 2;
+  const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;
+  const int ir0 = 2 * cr0 - 3, ic0 = 2 * cc0 - 3;
+  const float* xin = x + (size_t)n * H * W;
+  for (int i = tid; i < IR * IC; i += 256) {
+    const int rr = i / IC, cc = i - rr * IC;
+    const int ih = ir0 + rr, iw = ic0 + cc;
+    float v = 0.f;  // zero padding of conv1
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[(size_t)ih * W + iw];
+    in_s[rr][cc] = v;
+  }
+  const int c = tid & 63, wv = tid >> 6;
+  float wreg[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) wreg[t] = w49x64[t * 64 + c];
+  const float sc = scale[c], bi = bias[c];
+  __syncthreads();
+  for (int pix = wv; pix < CR * CC; pix += 4) {
+    const int pr = pix / CC, pc = pix - pr * CC;
+    const int cr = cr0 + pr, cc = cc0 + pc;
+    // conv positions outside the conv grid are max-pool padding: they never win
+    // against the always-valid window centre because ReLU output is >= 0.
+    float v = 0.f;
+    if ((unsigned)cr < (unsigned)Hc && (unsigned)cc < (unsigned)Wc) {
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) acc = fmaf(in_s[2 * pr + kh][2 * pc + kw], wreg[kh * 7 + kw], acc);
+      v = fmaxf(acc * sc + bi, 0.f);
+    }
+    conv_s[pix][c] = v;
+  }
+  __syncthreads();
+  for (int o = tid; o < TPH * TPW * 64; o += 256) {
+    const int ch = o & 63, pp = o >> 6;
+    const int py = pp / TPW, px = pp - py * TPW;
+    const int ph = ph0 + py, pw = pw0 + px;
+    if (ph < Hp && pw < Wp) {
+      float m = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, conv_s[(2 * py + dy) * CC + 2 * px + dx][ch]);
+      out[(((size_t)n * Hp + ph) * Wp + pw) * 64 + ch] = m;
+    }
+  }
+}
+
+// 16 lanes per input pixel (64 channels as 16 x float4, coalesced), xor-reduce, 4 taps out.
+__global__ __launch_bounds__(256) void convt2_sigmoid_kernel(const float* __restrict__ in, const float* __restrict__ w4x64,
+                                                             float bias, float* __restrict__ prob,
+                                                             uint8_t* __restrict__ bitmap, float thresh, int H2,
+                                                             int W2, long long P) {
+  const int l16 = threadIdx.x & 15;
+  f32x4 wt[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wt[t] = *reinterpret_cast<const f32x4*>(w4x64 + t * 64 + 4 * l16);
+  const long long stride = (long long)gridDim.x * 16;
+  for (long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4; pix < P; pix += stride) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + pix * 64 + 4 * l16);
+    float s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = v[0] * wt[t][0] + v[1] * wt[t][1] + v[2] * wt[t][2] + v[3] * wt[t][3];
+#pragma unroll
+    for (int k = 8; k >= 1; k >>= 1)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[t] += __shfl_xor(s[t], k, 16);
+    if (l16 < 4) {
+      const float z = (l16 == 0 ? s[0] : l16 == 1 ? s[1] : l16 == 2 ? s[2] : s[3]) + bias;
+      const float pr = 1.0f / (1.0f + expf(-z));
+      const long long hw = (long long)H2 * W2;
+      const long long n = pix / hw;
+      const long long rem = pix - n * hw;
+      const int i = (int)(rem / W2), j = (int)(rem - (long long)i * W2);
+      const size_t o = ((size_t)n * (2 * H2) + 2 * i + (l16 >> 1)) * (size_t)(2 * W2) + 2 * j + (l16 & 1);
+      prob[o] = pr;
+      if (bitmap) bitmap[o] = pr > thresh ? 1 : 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void binarize_kernel(const float* __restrict__ prob, uint8_t* __restrict__ bitmap,
+                                                       float thresh, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bitmap[i] = prob[i] > thresh ? 1 : 0;
+}
+
+}  // namespace
+
+void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias, float* out, int N,
+                 int H, int W, hipStream_t s) {
+  if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
+  const int Hp = H / 4, Wp = W / 4;
+  dim3 grid((Wp + TPW - 1) / TPW, (Hp + TPH - 1) / TPH, N);
+  hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, s, x, w49x64, scale, bias, out, H, W);
+  OCR_HIP(hipGetLastError());
+}
+
+void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob, uint8_t* bitmap,
+                           float thresh, int N, int H2, int W2, hipStream_t s) {
+  if (W2 % 4) fail(OCR_ERR_INVALID, "convt2: W/2 = %d must be a multiple of 4", W2);
+  const long long P = (long long)N * H2 * W2;
+  long long blocks = (P * 16 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(convt2_sigmoid_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w4x64, bias, prob, bitmap,
+                     thresh, H2, W2, P);
+  OCR_HIP(hipGetLastError());
+}
+
+void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(binarize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, prob, bitmap, thresh, n);
+  OCR_HIP(hipGetLastError());
+}
+
+}  // namespace ocr

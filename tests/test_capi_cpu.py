@@ -1,0 +1,133 @@
+"""CPU-side checks of the product library: it loads, exports every symbol that
+include/ocr_amd.h declares, refuses to compute without a GPU, and its host C++
+geometry reproduces the reference KATs (no oracle involved in the product path)."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import ocr_rs_amd  # noqa: F401
+from ocr_rs_amd import capi
+from ocr_rs_amd import weights as W
+from oracle import postproc_oracle as O
+from tests import kat_postproc as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "ocr_amd.h")).read()
+    declared = set(re.findall(r"\b(ocr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.EXPORTS)
+    L = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.ocr_version().decode().startswith("ocr_amd")
+    assert L.ocr_rec_alphabet().decode() == "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"
+
+
+def test_no_cpu_fallback_without_gpu():
+    if capi.lib().ocr_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    blob = W.pack_blob(W.make_rec_weights(0))
+    with pytest.raises(capi.OcrError) as e:
+        capi.Recognizer(blob, 0)
+    assert e.value.code == 4 and "no CPU fallback" in str(e.value)
+
+
+def test_bad_blob_rejected_before_gpu():
+    h = capi.C.c_void_p()
+    code = capi.lib().ocr_det_create(b"nope", 4, 0, capi.C.byref(h))
+    assert code != 0 and not h
+
+
+def test_default_params_are_reference_constants():
+    p = capi.PostprocParams()
+    capi.lib().ocr_postproc_default_params(capi.C.byref(p))
+    assert (p.thresh, p.box_thresh, p.min_size, p.unclip_ratio) == (0.6, 0.7, 5.0, 2.0)   # metrics.rs:38,64,66,103
+
+
+def test_host_min_area_box_kat():
+    box, sside = capi.host_min_area_box(K.MIN_AREA_BOX_IN)
+    assert box == K.MIN_AREA_BOX_OUT
+    assert abs(sside - K.MIN_AREA_BOX_SSIDE) < np.finfo(np.float64).eps
+
+
+def _bitmap(golden_dir, name):
+    return (np.array(Image.open(os.path.join(golden_dir, name)).convert("L")) // 255).astype(np.uint8)
+
+
+def test_host_geometry_reproduces_img55_kat(golden_dir):
+    bm = _bitmap(golden_dir, "gt_shrinked_img55.png")
+    cands = capi.host_contour_candidates(bm)
+    assert len(cands) == 4
+    out = []
+    for c in cands:
+        ex, sside = capi.host_expand_polygon(c, 2.0)
+        assert sside >= 5.0
+        out.append(ex)
+    assert out == K.IMG55_POLYS_ADJ1      # metrics.rs:519-568 (adj = 1)
+
+
+@pytest.mark.parametrize("name", ["gt_shrinked_img224.png", "gt_shrinked_img494.png", "gt_shrinked_img545.png"])
+def test_host_geometry_matches_oracle_on_other_fixtures(golden_dir, name):
+    bm = _bitmap(golden_dir, name)
+    cands = capi.host_contour_candidates(bm)
+    ocands = []
+    for c in O.find_contours(bm * 255):
+        eps = 0.01 * O.arc_length(c, True) or 0.01
+        pts = O.approximate_polygon_dp(c, eps, True)
+        if len(pts) > 1 and pts[0] == pts[-1]:
+            pts.pop()
+        if len(pts) >= 4:
+            ocands.append(pts)
+    assert cands == ocands
+    for c in cands:
+        assert capi.host_expand_polygon(c, 2.0)[0] == O.expand_polygon(c, 2.0)
+
+
+def test_host_geometry_matches_oracle_on_random_blobs():
+    rng = np.random.RandomState(5)
+    # noise blobs: many tiny contours, holes, border-touching shapes
+    f = rng.rand(96, 128)
+    for _ in range(3):
+        f = (f + np.roll(f, 1, 0) + np.roll(f, -1, 0) + np.roll(f, 1, 1) + np.roll(f, -1, 1)) / 5
+    bm = (f > np.median(f)).astype(np.uint8)
+    cands = capi.host_contour_candidates(bm)
+    ocands = []
+    for c in O.find_contours(bm * 255):
+        eps = 0.01 * O.arc_length(c, True) or 0.01
+        pts = O.approximate_polygon_dp(c, eps, True)
+        if len(pts) > 1 and pts[0] == pts[-1]:
+            pts.pop()
+        if len(pts) >= 4:
+            ocands.append(pts)
+    assert len(cands) > 3 and cands == ocands
+    for c in cands:
+        assert capi.host_expand_polygon(c, 2.0)[0] == (O.expand_polygon(c, 2.0) or [])
+
+
+def test_expand_random_star_polygons_match_oracle():
+    rnd = random.Random(11)
+    import math
+    for _ in range(60):
+        k = rnd.randint(4, 14)
+        cx, cy = rnd.randint(200, 400), rnd.randint(200, 400)
+        pts = []
+        for i in range(k):
+            ang = 2 * math.pi * i / k
+            r = rnd.uniform(15, 120)
+            pts.append((int(cx + r * math.cos(ang)), int(cy + r * math.sin(ang))))
+        if len(set(pts)) < len(pts):
+            continue
+        assert capi.host_expand_polygon(pts, 2.0)[0] == (O.expand_polygon(pts, 2.0) or [])
