@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the detection hot path on MI355X (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the detector (stem .. sigmoid, with the fused binarize) over
+one batch of 32 synthetic 640x640 frames that are already resident in HBM, per GPU
+(weak scaling: every rank owns its own batch and its own replica of the 48.7 MB
+weights; there is no data-path collective - results are gathered once, after the
+timed region, to show the exchange step).  Prints ONE JSON line on rank 0.
+
+Extra objects in that line:
+  roofline      dominant kernel (largest summed time), measured live with HIP events
+                on the launch stream: algorithmic FLOPs of its launches / their time,
+                against the 157.3 TF/s dense f32 MFMA peak of MI355X.
+  cpu_baseline  the same graph on the host cores through ATen-CPU (oracle/torch_ref.py,
+                the operator library the reference reaches through tch), bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ocr_rs_amd  # noqa: E402,F401
+from ocr_rs_amd import capi  # noqa: E402
+from ocr_rs_amd import weights as W  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_640_IMAGE = 48.365568  # SURVEY.md section 8(d) / BASELINE.md section 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip recognition / post-processing side numbers")
+    return ap.parse_args()
+
+
+def cpu_baseline(det_w, size: int, budget_s: float):
+    """Reference stand-in on the host cores: same graph through ATen CPU kernels."""
+    from oracle import torch_ref as T
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    x = W.synth_image_batch(1, 2, size, size)
+    T.det_forward(det_w, x[:1])  # warm the thread pool / allocator
+    done, t0 = 0, time.perf_counter()
+    while True:
+        T.det_forward(det_w, x)
+        done += x.shape[0]
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 64:
+            break
+    return {"value": round(done / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{done} frames of {size}x{size} f32 in batches of 2 through oracle/torch_ref.py "
+                      f"(ATen CPU, {cores} threads), {el:.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+
+    n, s = a.batch, a.size
+    det_w = W.make_det_weights(0)
+    det = capi.Detector(W.pack_blob(det_w), local)
+    stream = torch.cuda.Stream(device=local)
+    det.set_stream(stream.cuda_stream)
+    x = torch.from_numpy(W.synth_image_batch(1 + rank, n, s, s)).to(f"cuda:{local}")
+    prob = torch.empty_like(x)
+    bitmap = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+
+    def step():
+        det.forward_device(x.data_ptr(), n, s, s, prob.data_ptr(), bitmap.data_ptr(), 0.6)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(a.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream
+    roof = None
+    if rank == 0:
+        agg = {}
+        reps = 3
+        for _ in range(reps):
+            for name, ms, fl, by in det.forward_profile(x.data_ptr(), n, s, s, prob.data_ptr()):
+                e = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+                e[0] += ms
+                e[1] += fl
+                e[2] += by
+                e[3] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (ms, fl, by, cnt) = dom
+        achieved = fl / (ms * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
+                "avg_launch_gflop": round(fl / cnt / 1e9, 3),
+                "all_kernels": {k: {"ms_per_step": round(v[0] / reps, 4),
+                                    "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None,
+                                    "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+
+    # ---- the exchange step of the sharded path: gather per-image results over RCCL (outside the timed region)
+    gathered = None
+    if dist is not None:
+        counts = bitmap.view(n, -1).sum(dim=1, dtype=torch.int32)
+        out = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(out, counts)
+        gathered = int(torch.stack(out).numel())
+
+    extras = {}
+    if rank == 0 and not a.no_extras:
+        try:
+            rec_w = W.make_rec_weights(0)
+            rec = capi.Recognizer(W.pack_blob(rec_w), local)
+            rec.set_stream(stream.cuda_stream)
+            nc = 256
+            crops = torch.from_numpy(W.synth_crops(2, nc)).to(x.device)
+            labels = torch.empty(nc, dtype=torch.int32, device=x.device)
+            probs = torch.empty(nc, dtype=torch.float64, device=x.device)
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    rec.classify_device(crops.data_ptr(), nc, 0, labels.data_ptr(), probs.data_ptr())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                it = 50
+                for _ in range(it):
+                    rec.classify_device(crops.data_ptr(), nc, 0, labels.data_ptr(), probs.data_ptr())
+                torch.cuda.synchronize()
+                extras["rec_crops_per_s_b256"] = round(nc * it / (time.perf_counter() - t1), 1)
+        except Exception as e:  # side numbers never hide the headline
+            extras["rec_error"] = str(e)
+
+    total_images = n * world * a.steps
+    if rank == 0:
+        line = {
+            "metric": "images/sec (640x640 detect)", "value": round(total_images / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"detection forward (ResNet18+FPN+prob head, fused binarize), batch {n} x 1x{s}x{s} "
+                                   f"f32 frames per GPU, BASELINE configs[1]",
+                       "global_batch": n * world, "frame": [s, s], "parallelism": f"replica x{world}, frames sharded"},
+            "tflops_algorithmic": round(total_images * GFLOP_PER_640_IMAGE * (s * s) / (640 * 640) / elapsed / 1e3, 2),
+            "roofline": roof,
+        }
+        if gathered is not None:
+            line["rccl_all_gather_results"] = gathered
+        line.update(extras)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(det_w, s, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    det.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

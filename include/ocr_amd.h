@@ -28,6 +28,7 @@ extern "C" {
 #define OCR_ERR_HIP 3       /* HIP runtime error (message has the call)  */
 #define OCR_ERR_NOGPU 4     /* no usable gfx950 device: there is NO CPU fallback */
 #define OCR_ERR_INTERNAL 5
+#define OCR_ERR_DEGENERATE 6 /* expand_polygon gave None: the reference unwraps it and aborts (metrics.rs:103) */
 
 /* memory kind of the data pointers handed to a call */
 #define OCR_MEM_HOST 0
@@ -92,6 +93,11 @@ typedef struct ocr_postproc_params {
   double box_thresh;    /* 0.7  metrics.rs:64  */
   double min_size;      /* 5.0  metrics.rs:66  */
   double unclip_ratio;  /* 2.0  metrics.rs:103 */
+  /* A candidate whose offset polygon is empty (zero-area contour) makes the reference
+   * abort: `expand_polygon(..).unwrap()`, metrics.rs:103 with panic = "abort".
+   * 0 (default) = report it as OCR_ERR_DEGENERATE; 1 = drop that candidate and go on. */
+  int32_t skip_degenerate;
+  int32_t reserved;
 } ocr_postproc_params_t;
 
 typedef struct ocr_polygons {

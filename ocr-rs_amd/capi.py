@@ -36,7 +36,7 @@ class OcrError(RuntimeError):
 
 class PostprocParams(C.Structure):
     _fields_ = [("thresh", C.c_double), ("box_thresh", C.c_double), ("min_size", C.c_double),
-                ("unclip_ratio", C.c_double)]
+                ("unclip_ratio", C.c_double), ("skip_degenerate", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Polygons(C.Structure):
@@ -91,6 +91,8 @@ def lib() -> C.CDLL:
         L.ocr_test_expand_polygon.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.ocr_test_min_area_box.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        L.ocr_test_box_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p]
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
@@ -121,6 +123,13 @@ def polygons_to_python(pp) -> Tuple[List[List[List[Tuple[int, int]]]], List[List
         polys.append(ip)
         scores.append(isc)
     return polys, scores
+
+
+def default_params(skip_degenerate: bool = False) -> PostprocParams:
+    p = PostprocParams()
+    lib().ocr_postproc_default_params(C.byref(p))
+    p.skip_degenerate = 1 if skip_degenerate else 0
+    return p
 
 
 class Detector:
@@ -179,6 +188,18 @@ class Detector:
         out = np.empty(n.value, np.float32)
         check(lib().ocr_test_det_stage(self._h, stage_id, _ptr(out), n.value, C.byref(n)))
         return np.ascontiguousarray(out.reshape(shape_nhwc).transpose(0, 3, 1, 2))
+
+    def debug_box_scores(self, pred_hw: np.ndarray, polys):
+        """Test hook: raw (sum, count) of the GPU box-score kernel for given polygons."""
+        pred = np.ascontiguousarray(pred_hw, dtype=np.float32)
+        h, w = pred.shape
+        xy = np.asarray([c for p in polys for pt in p for c in pt], dtype=np.int32)
+        cnt = np.asarray([len(p) for p in polys], dtype=np.int32)
+        sums = np.empty(len(polys), np.float64)
+        counts = np.empty(len(polys), np.float64)
+        check(lib().ocr_test_box_scores(self._h, _ptr(pred), h, w, _ptr(xy), _ptr(cnt), len(polys), _ptr(sums),
+                                        _ptr(counts)))
+        return sums, counts
 
     def postprocess(self, prob, n: int, h: int, w: int, adjust_values: np.ndarray, mem_kind: int = MEM_HOST,
                     params: Optional[PostprocParams] = None):

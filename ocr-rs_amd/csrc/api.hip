@@ -28,6 +28,9 @@ int guard(F&& f) {
   } catch (const ocr::Error& e) {
     g_err = e.what();
     return e.code;
+  } catch (const ocr::geom::DegeneratePolygon& e) {
+    g_err = e.what();
+    return OCR_ERR_DEGENERATE;
   } catch (const std::exception& e) {
     g_err = e.what();
     return OCR_ERR_INTERNAL;
@@ -252,6 +255,8 @@ void ocr_postproc_default_params(ocr_postproc_params_t* p) {
   p->box_thresh = 0.7;    // metrics.rs:64
   p->min_size = 5.0;      // metrics.rs:66
   p->unclip_ratio = 2.0;  // metrics.rs:103
+  p->skip_degenerate = 0; // faithful: the reference aborts on such a candidate
+  p->reserved = 0;
 }
 
 int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
@@ -370,6 +375,46 @@ int ocr_test_det_stage(ocr_det_t* det, int id, float* out_host, size_t capacity,
       det->impl.synchronize();
       OCR_HIP(hipMemcpy(out_host, p, *elems * sizeof(float), hipMemcpyDeviceToHost));
     }
+  });
+}
+// raw GPU box scores of given polygons over a host map (sum and pixel count per polygon)
+int ocr_test_box_scores(ocr_det_t* det, const float* prob_host, int h, int w, const int32_t* xy, const int32_t* counts,
+                        int n_polys, double* sums_out, double* counts_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det) fail(OCR_ERR_INVALID, "null handle");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    std::vector<BoxScoreJob> jobs;
+    int pos = 0;
+    for (int k = 0; k < n_polys; ++k) {
+      int mnx = INT32_MAX, mxx = 0, mny = INT32_MAX, mxy = 0;
+      for (int i = 0; i < counts[k]; ++i) {
+        mnx = std::min(mnx, xy[2 * (pos + i)]);
+        mxx = std::max(mxx, xy[2 * (pos + i)]);
+        mny = std::min(mny, xy[2 * (pos + i) + 1]);
+        mxy = std::max(mxy, xy[2 * (pos + i) + 1]);
+      }
+      mnx = std::clamp(mnx, 0, h - 1);
+      mxx = std::clamp(mxx, 0, h - 1);
+      mny = std::clamp(mny, 0, w - 1);
+      mxy = std::clamp(mxy, 0, w - 1);
+      if (mxx >= w || mxy >= h || counts[k] > kBoxScoreMaxPts) fail(OCR_ERR_INVALID, "bad test polygon");
+      jobs.push_back({0, pos, counts[k], mnx, mny, mxx - mnx + 1, mxy - mny + 1});
+      pos += counts[k];
+    }
+    const size_t o_jobs = align256((size_t)h * w * 4), o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
+    const size_t o_sum = o_pts + align256((size_t)pos * 8), o_cnt = o_sum + align256((size_t)n_polys * 8);
+    char* sc = static_cast<char*>(det->impl.scratch(o_cnt + align256((size_t)n_polys * 8)));
+    OCR_HIP(hipMemcpyAsync(sc, prob_host, (size_t)h * w * 4, hipMemcpyHostToDevice, s));
+    OCR_HIP(hipMemcpyAsync(sc + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
+    OCR_HIP(hipMemcpyAsync(sc + o_pts, xy, (size_t)pos * 8, hipMemcpyHostToDevice, s));
+    launch_box_scores(reinterpret_cast<const float*>(sc), h, w, reinterpret_cast<const BoxScoreJob*>(sc + o_jobs),
+                      reinterpret_cast<const int32_t*>(sc + o_pts), n_polys, reinterpret_cast<double*>(sc + o_sum),
+                      reinterpret_cast<double*>(sc + o_cnt), s);
+    OCR_HIP(hipMemcpyAsync(sums_out, sc + o_sum, (size_t)n_polys * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipMemcpyAsync(counts_out, sc + o_cnt, (size_t)n_polys * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
   });
 }
 int ocr_test_min_area_box(const int32_t* xy, int n, int32_t* box_xy, double* sside) {

@@ -11,7 +11,7 @@
 // min_area_rect), geo 0.15.0 (area, length) and Clipper 6.x through geo-clipper
 // (offset).  Their published algorithms are implemented here from their
 // descriptions; the reference's known-answer tests
-// (metrics.rs:406-646) are reproduced by tests/test_postproc_host.py.
+// (metrics.rs:406-646) are reproduced by tests/test_capi_cpu.py.
 #include "postproc_geom.hpp"
 
 #include <algorithm>
@@ -568,8 +568,10 @@ bool finish_polygon(const std::vector<Pt>& cand, double score, double adj_x, dou
                     std::vector<uint32_t>& xy_out) {
   if (prm.box_thresh > score) return false;  // metrics.rs:100 (NaN passes, as in the reference)
   std::vector<Pt> expanded;
-  if (!expand_polygon(cand, prm.unclip_ratio, expanded))
-    throw std::runtime_error("expand_polygon produced no polygon (the reference unwraps None and aborts)");
+  if (!expand_polygon(cand, prm.unclip_ratio, expanded)) {
+    if (prm.skip_degenerate) return false;
+    throw DegeneratePolygon();
+  }
   Pt box[4];
   if (min_area_bounding_box(expanded, box) < prm.min_size) return false;
   for (const Pt& p : expanded) {

@@ -14,6 +14,11 @@ struct Pt {
   bool operator==(const Pt& o) const { return x == o.x && y == o.y; }
 };
 
+// expand_polygon returned None: the reference `.unwrap()`s it (metrics.rs:103) and aborts.
+struct DegeneratePolygon : std::runtime_error {
+  DegeneratePolygon() : std::runtime_error("expand_polygon produced no polygon for a zero-area candidate; the reference unwraps None here and aborts (metrics.rs:103)") {}
+};
+
 void find_contours(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& out);
 double arc_length(const std::vector<Pt>& p, bool closed);
 void approximate_polygon_dp(const std::vector<Pt>& curve, double eps, bool closed, std::vector<Pt>& out);

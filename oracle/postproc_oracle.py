@@ -635,9 +635,13 @@ def _as_u32(v: float) -> int:
     return int(min(v, 4294967295.0))
 
 
+class DegeneratePolygon(RuntimeError):
+    """expand_polygon returned None; the reference unwraps it (metrics.rs:103) and aborts."""
+
+
 def get_polygons_from_bitmap(pred: np.ndarray, bitmap: np.ndarray, adj: Sequence[float],
                              box_thresh: float = 0.7, min_size: float = 5.0,
-                             unclip: float = 2.0):
+                             unclip: float = 2.0, skip_degenerate: bool = False):
     """pred: HxW float, bitmap: HxW u8 (0/1).  Returns (polygons, scores)."""
     image = (bitmap.astype(np.int64) * 255).astype(np.uint8)  # metrics.rs:69
     contours = find_contours(image)
@@ -656,7 +660,9 @@ def get_polygons_from_bitmap(pred: np.ndarray, bitmap: np.ndarray, adj: Sequence
             continue
         expanded = expand_polygon(points, unclip)
         if expanded is None:
-            raise RuntimeError("expand_polygon returned None (reference unwraps -> abort)")
+            if skip_degenerate:
+                continue
+            raise DegeneratePolygon("expand_polygon returned None (reference unwraps -> abort)")
         _, sside = get_min_area_bounding_box(expanded)
         if sside < min_size:
             continue
@@ -666,12 +672,13 @@ def get_polygons_from_bitmap(pred: np.ndarray, bitmap: np.ndarray, adj: Sequence
     return boxes, scores
 
 
-def get_boxes_and_box_scores(pred: np.ndarray, adjust_values: np.ndarray, thresh: float = 0.6):
+def get_boxes_and_box_scores(pred: np.ndarray, adjust_values: np.ndarray, thresh: float = 0.6,
+                             skip_degenerate: bool = False):
     """pred: Nx1xHxW float32, adjust_values: Nx2 float64 -> (polygons[N], scores[N])."""
     seg = binarize(pred, thresh)
     polys, scores = [], []
     for b in range(pred.shape[0]):
-        p, s = get_polygons_from_bitmap(pred[b, 0], seg[b, 0], adjust_values[b])
+        p, s = get_polygons_from_bitmap(pred[b, 0], seg[b, 0], adjust_values[b], skip_degenerate=skip_degenerate)
         polys.append(p)
         scores.append(s)
     return polys, scores

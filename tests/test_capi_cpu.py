@@ -55,6 +55,7 @@ def test_default_params_are_reference_constants():
     p = capi.PostprocParams()
     capi.lib().ocr_postproc_default_params(capi.C.byref(p))
     assert (p.thresh, p.box_thresh, p.min_size, p.unclip_ratio) == (0.6, 0.7, 5.0, 2.0)   # metrics.rs:38,64,66,103
+    assert p.skip_degenerate == 0
 
 
 def test_host_min_area_box_kat():

@@ -102,9 +102,17 @@ def test_det_preprocessed_img55_plumbing(det, det_w, golden_dir):
     ref = T.det_forward(det_w, x)
     assert np.abs(prob - ref).max() < TOL
     adj = np.array([[800 / 300, 533 / 200]])          # image_ops.rs:910-916
-    polys, scores = det.postprocess(prob, 1, 800, 800, adj)
-    opolys, oscores = O.get_boxes_and_box_scores(prob, adj)
-    assert polys == opolys
+    # a random-weight map is noise: it holds zero-area contours on which the reference
+    # itself aborts (metrics.rs:103 unwrap); both sides must report exactly that ...
+    with pytest.raises(O.DegeneratePolygon):
+        O.get_boxes_and_box_scores(prob, adj)
+    with pytest.raises(capi.OcrError) as e:
+        det.postprocess(prob, 1, 800, 800, adj)
+    assert e.value.code == 6
+    # ... and agree on everything else when such candidates are dropped
+    polys, scores = det.postprocess(prob, 1, 800, 800, adj, params=capi.default_params(skip_degenerate=True))
+    opolys, oscores = O.get_boxes_and_box_scores(prob, adj, skip_degenerate=True)
+    assert polys == opolys and len(polys[0]) > 10
     assert np.allclose(scores[0], oscores[0], rtol=0, atol=1e-12)
 
 
@@ -140,10 +148,40 @@ def test_postprocess_reference_kat(det, golden_dir, adj, expected):
     assert scores[0] == K.IMG55_SCORES
 
 
-def test_postprocess_box_score_kats(det):
-    """metrics.rs:426-484: the three box_score_fast KATs, reached through a map whose
-    contour is the KAT polygon is not possible (the API takes maps, not polygons), so
-    they are pinned via the oracle-equivalence test below plus the img55 scores."""
+def test_box_score_kernel_reference_kats(det):
+    """metrics.rs:426-484: box_score_fast on the 5x5 map, straight on the GPU kernel."""
+    pred = np.array(K.BOX_SCORE_MAP, dtype=np.float32).reshape(5, 5)
+    sums, counts = det.debug_box_scores(pred, [pts for pts, _ in K.BOX_SCORE_CASES])
+    assert (sums / counts).tolist() == [exp for _, exp in K.BOX_SCORE_CASES]
+    assert counts.tolist() == [25.0, 16.0, 12.0]
+
+
+def test_box_score_kernel_matches_oracle_masks(det):
+    """Mask pixel counts and f64 sums of thin / degenerate / concave polygons."""
+    rng = np.random.RandomState(1)
+    pred = rng.rand(96, 96).astype(np.float32)
+    polys = [[(76, 36), (74, 38), (74, 39), (74, 38)],                       # zero-area line
+             [(10, 10), (40, 12), (38, 30), (25, 18), (12, 33)],              # concave
+             [(50, 50), (90, 50), (90, 90), (50, 90)],                        # square
+             [(5, 60), (30, 61), (29, 80), (6, 95), (5, 70), (20, 72)],       # self-touching
+             [(60, 5), (61, 30), (62, 5), (63, 30)]]                          # zig-zag sliver
+    sums, counts = det.debug_box_scores(pred, polys)
+    for k, p in enumerate(polys):
+        assert counts[k] == O.polygon_mask_count(p, pred.shape), (k, counts[k])
+        assert abs(sums[k] / counts[k] - O.box_score_fast(pred, p)) < 1e-13
+
+
+def test_box_score_large_polygon_bands(det):
+    """A bounding box larger than one 32 KiB mask band (row-banded path)."""
+    rng = np.random.RandomState(2)
+    pred = rng.rand(800, 800).astype(np.float32)
+    poly = [(20, 30), (770, 15), (790, 700), (400, 780), (30, 760), (200, 400)]
+    sums, counts = det.debug_box_scores(pred, [poly])
+    assert counts[0] == O.polygon_mask_count(poly, pred.shape)
+    assert abs(sums[0] / counts[0] - O.box_score_fast(pred, poly)) < 1e-13
+
+
+def test_postprocess_small_map_matches_oracle(det):
     pred = np.zeros((1, 1, 32, 32), np.float32)
     pred[0, 0, 4:20, 6:26] = 0.9
     polys, scores = det.postprocess(pred, 1, 32, 32, np.array([[1.0, 1.0]]))
@@ -179,8 +217,8 @@ def test_postprocess_noise_blobs_match_oracle(det):
     f = (f - f.min()) / (f.max() - f.min())
     pred = np.clip(0.6 + (f - np.median(f)) * 6, 0, 1).astype(np.float32)[:, None]
     adj = np.array([[1.0, 1.0], [1.4, 0.8]])
-    polys, scores = det.postprocess(pred, 2, 160, 224, adj)
-    opolys, oscores = O.get_boxes_and_box_scores(pred, adj)
+    polys, scores = det.postprocess(pred, 2, 160, 224, adj, params=capi.default_params(skip_degenerate=True))
+    opolys, oscores = O.get_boxes_and_box_scores(pred, adj, skip_degenerate=True)
     assert polys == opolys and sum(len(p) for p in polys) > 2
     for a, b in zip(scores, oscores):
         assert np.allclose(a, b, rtol=0, atol=1e-12)
