@@ -53,10 +53,22 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """CPU share of this container: cgroup quota if any (a 1-GPU box gets 16), else affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 16) if n > 64 else n
+
+
 def cpu_baseline(det_w, size: int, budget_s: float):
     """Reference stand-in on the host cores: same graph through ATen CPU kernels."""
     from oracle import torch_ref as T
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     x = W.synth_image_batch(1, 2, size, size)
     T.det_forward(det_w, x[:1])  # warm the thread pool / allocator

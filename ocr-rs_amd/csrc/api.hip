@@ -60,7 +60,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   const size_t px = (size_t)n * h * w;
   // scratch: [prob copy if host] [bitmap]
   const size_t off_bitmap = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
-  char* scratch = static_cast<char*>(det.scratch(off_bitmap + align256(px)));
+  char* scratch = static_cast<char*>(det.scratch(0, off_bitmap + align256(px)));
   const float* prob_dev = prob;
   if (mem_kind == OCR_MEM_HOST) {
     OCR_HIP(hipMemcpyAsync(scratch, prob, px * 4, hipMemcpyHostToDevice, s));
@@ -123,22 +123,12 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   const int nj = (int)jobs.size();
   std::vector<double> sums(nj), counts(nj);
   if (nj > 0) {
-    const size_t o_jobs = off_bitmap + align256(px);
+    const size_t o_jobs = 0;
     const size_t o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
     const size_t o_sum = o_pts + align256(pts.size() * 4);
     const size_t o_cnt = o_sum + align256((size_t)nj * 8);
     const size_t total = o_cnt + align256((size_t)nj * 8);
-    // growing the scratch may move it: the probability copy must survive
-    if (mem_kind == OCR_MEM_HOST) {
-      char* ns = static_cast<char*>(det.scratch(total));
-      if (ns != scratch) {
-        scratch = ns;
-        OCR_HIP(hipMemcpyAsync(scratch, prob, px * 4, hipMemcpyHostToDevice, s));
-        prob_dev = reinterpret_cast<const float*>(scratch);
-      }
-    } else {
-      scratch = static_cast<char*>(det.scratch(total));
-    }
+    scratch = static_cast<char*>(det.scratch(1, total));  // slot 0 (map copy) stays valid
     OCR_HIP(hipMemcpyAsync(scratch + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
     OCR_HIP(hipMemcpyAsync(scratch + o_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice, s));
     launch_box_scores(prob_dev, h, w, reinterpret_cast<const BoxScoreJob*>(scratch + o_jobs),
@@ -405,7 +395,7 @@ int ocr_test_box_scores(ocr_det_t* det, const float* prob_host, int h, int w, co
     }
     const size_t o_jobs = align256((size_t)h * w * 4), o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
     const size_t o_sum = o_pts + align256((size_t)pos * 8), o_cnt = o_sum + align256((size_t)n_polys * 8);
-    char* sc = static_cast<char*>(det->impl.scratch(o_cnt + align256((size_t)n_polys * 8)));
+    char* sc = static_cast<char*>(det->impl.scratch(0, o_cnt + align256((size_t)n_polys * 8)));
     OCR_HIP(hipMemcpyAsync(sc, prob_host, (size_t)h * w * 4, hipMemcpyHostToDevice, s));
     OCR_HIP(hipMemcpyAsync(sc + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
     OCR_HIP(hipMemcpyAsync(sc + o_pts, xy, (size_t)pos * 8, hipMemcpyHostToDevice, s));

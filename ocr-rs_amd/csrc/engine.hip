@@ -152,7 +152,8 @@ Detector::~Detector() {
   (void)hipSetDevice(device_);
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   free_workspace();
-  if (scratch_) (void)hipFree(scratch_);
+  for (void* p : scratch_)
+    if (p) (void)hipFree(p);
   if (stage_in_) (void)hipFree(stage_in_);
   if (stage_out_) (void)hipFree(stage_out_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
@@ -163,16 +164,18 @@ void Detector::synchronize() {
   OCR_HIP(hipStreamSynchronize(stream_));
 }
 
-void* Detector::scratch(size_t bytes) {
-  if (bytes > scratch_bytes_) {
+void* Detector::scratch(int slot, size_t bytes) {
+  if (slot < 0 || slot > 1) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
+  if (bytes > scratch_bytes_[slot]) {
     OCR_HIP(hipStreamSynchronize(stream_));
-    if (scratch_) OCR_HIP(hipFree(scratch_));
-    scratch_ = nullptr;
-    scratch_bytes_ = 0;
-    OCR_HIP(hipMalloc(&scratch_, bytes));
-    scratch_bytes_ = bytes;
+    if (scratch_[slot]) OCR_HIP(hipFree(scratch_[slot]));
+    scratch_[slot] = nullptr;
+    scratch_bytes_[slot] = 0;
+    const size_t want = bytes + bytes / 4;  // head room: fewer re-allocations as batches vary
+    OCR_HIP(hipMalloc(&scratch_[slot], want));
+    scratch_bytes_[slot] = want;
   }
-  return scratch_;
+  return scratch_[slot];
 }
 
 void Detector::ensure_workspace(int n, int h, int w) {

@@ -44,8 +44,9 @@ class Detector {
   void forward(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                std::vector<ProfileEntry>* prof);
   void forward_host(const float* x, int n, int h, int w, float* prob);
-  // scratch shared with post-processing
-  void* scratch(size_t bytes);
+  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results.
+  // Growing a slot invalidates only that slot's previous contents.
+  void* scratch(int slot, size_t bytes);
   // test hook: NHWC intermediate of the last forward (0 stem, 1-4 layer1-4, 5-8 in2-5,
   // 9-12 p2-p5 (before upsampling), 13 bin_conv1, 14 bin_conv_tr1)
   const float* stage(int id, size_t* elems) const;
@@ -71,8 +72,8 @@ class Detector {
   std::vector<void*> ws_allocs_;
   float *s_ = nullptr, *t_[4] = {}, *a_[4] = {}, *d_[4] = {}, *x_[4] = {};
   float *i_[4] = {}, *p_[4] = {}, *b1_ = nullptr, *tr1buf_ = nullptr;
-  void* scratch_ = nullptr;
-  size_t scratch_bytes_ = 0;
+  void* scratch_[2] = {nullptr, nullptr};
+  size_t scratch_bytes_[2] = {0, 0};
   float *stage_in_ = nullptr, *stage_out_ = nullptr;
   size_t stage_elems_ = 0;
 };

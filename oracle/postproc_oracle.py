@@ -266,8 +266,9 @@ def box_score_fast(pred: np.ndarray, points: Sequence[Pt]) -> float:
     m = (mask // 255).astype(np.uint8)
     part = pred[min_y:max_y + 1, min_x:max_x + 1]
     # f32 * u8 -> f32 (exact: mask is 0/1), summed in f64
-    s = float(np.sum((part * m).astype(np.float64)))
-    return s / float(np.sum(m, dtype=np.float64))
+    s = np.sum((part * m).astype(np.float64))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return float(s / np.sum(m, dtype=np.float64))   # empty mask: 0/0 = NaN, like tch (no error)
 
 
 def polygon_mask_count(points: Sequence[Pt], shape: Tuple[int, int]) -> int:
