@@ -98,31 +98,33 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 
   f32x4 areg[AI], breg[BI];
 
+  // Branch-free gather: out-of-image taps (zero padding) and rows past M read a clamped,
+  // always valid address and are zeroed by a select, so all loads of a K-step issue together.
   auto load_tiles = [&](int tap, int c0) {
     const int kh = tap / KS, kw = tap - kh * KS;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int ih = ih0[i] + kh, iw = iw0[i] + kw;
       const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        if constexpr (SRC == SRC_PLAIN) {
-          const size_t pix = ((size_t)img[i] * p.Hin + ih) * p.Win + iw;
-          v = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
-        } else if constexpr (SRC == SRC_UPADD) {
-          const size_t pix = ((size_t)img[i] * p.Hin + ih) * p.Win + iw;
-          const size_t pix1 = ((size_t)img[i] * (p.Hin >> 1) + (ih >> 1)) * (p.Win >> 1) + (iw >> 1);
-          const f32x4 a = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.src[1] + pix1 * p.Cin + c0 + q * 4);
-          v = b + a;  // reference order: upsample(x_in{k+1}) + x_in{k}
-        } else {      // SRC_CAT4: channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
-          const int s = c0 >> 6;
-          const int sh = 3 - s;
-          const size_t pix = ((size_t)img[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh);
-          v = *reinterpret_cast<const f32x4*>(p.src[s] + pix * 64 + (c0 & 63) + q * 4);
-        }
+      const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
+      f32x4 v;
+      if constexpr (SRC == SRC_PLAIN) {
+        const size_t pix = ((size_t)img[i] * p.Hin + ihc) * p.Win + iwc;
+        v = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
+      } else if constexpr (SRC == SRC_UPADD) {
+        const size_t pix = ((size_t)img[i] * p.Hin + ihc) * p.Win + iwc;
+        const size_t pix1 = ((size_t)img[i] * (p.Hin >> 1) + (ihc >> 1)) * (p.Win >> 1) + (iwc >> 1);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.src[1] + pix1 * p.Cin + c0 + q * 4);
+        v = b + a;  // reference order: upsample(x_in{k+1}) + x_in{k}
+      } else {      // SRC_CAT4: channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
+        const int s = c0 >> 6;
+        const int sh = 3 - s;
+        const size_t pix = ((size_t)img[i] * (p.Hin >> sh) + (ihc >> sh)) * (p.Win >> sh) + (iwc >> sh);
+        v = *reinterpret_cast<const f32x4*>(p.src[s] + pix * 64 + (c0 & 63) + q * 4);
       }
-      areg[i] = v;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      areg[i] = ok ? v : z;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i)
@@ -191,9 +193,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     }
   }
 
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  // Per store instruction a wave writes 2 rows x 128 contiguous bytes.  A tile that lies fully
+  // inside M takes a branch-free path: all residual loads of a 32x32 tile are issued before
+  // they are consumed.
   const int colq = lane & 31;
   const int rowq = (lane >> 5) * 4;
+  const bool full_tile = m0 + BM <= p.M;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * WN + j * 32 + colq;
@@ -201,27 +207,41 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     const float bi = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      const int mbase = m0 + wm * WM + i * 32 + rowq;
+      if constexpr (STORE == STORE_NHWC) {
+        float res[16];
+        if (p.residual) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq;
-        if (m < p.M) {
-          float v = acc[i][j][e] * sc + bi;
-          if constexpr (STORE == STORE_NHWC) {
-            const size_t o = (size_t)m * p.Cout + col;
-            if (p.residual) v += p.residual[o];
-            if (p.relu) v = fmaxf(v, 0.f);
-            p.out[o] = v;
-          } else {
-            // conv_transpose2d k=2 s=2: column = (a*2+b)*64 + co -> out[n][2i+a][2j+b][co]
-            if (p.relu) v = fmaxf(v, 0.f);
-            const int n = m / HoWo;
-            const int rem = m - n * HoWo;
-            const int oh = rem / p.Wo;
-            const int ow = rem - oh * p.Wo;
-            const int t = col >> 6, co = col & 63;
-            const size_t o = (((size_t)n * (2 * p.Ho) + 2 * oh + (t >> 1)) * (2 * p.Wo) + 2 * ow + (t & 1)) * 64 + co;
-            p.out[o] = v;
+          for (int e = 0; e < 16; ++e) {
+            const int m = min(mbase + (e & 3) + 8 * (e >> 2), p.M - 1);
+            res[e] = p.residual[(size_t)m * p.Cout + col];
           }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) res[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mbase + (e & 3) + 8 * (e >> 2);
+          float v = acc[i][j][e] * sc + bi + res[e];
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (full_tile || m < p.M) p.out[(size_t)m * p.Cout + col] = v;
+        }
+      } else {
+        // conv_transpose2d k=2 s=2: column = (a*2+b)*64 + co -> out[n][2i+a][2j+b][co]
+        const int t = col >> 6, co = col & 63;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mbase + (e & 3) + 8 * (e >> 2);
+          float v = acc[i][j][e] * sc + bi;
+          if (p.relu) v = fmaxf(v, 0.f);
+          const int mm = min(m, p.M - 1);
+          const int n = mm / HoWo;
+          const int rem = mm - n * HoWo;
+          const int oh = rem / p.Wo;
+          const int ow = rem - oh * p.Wo;
+          const size_t o = (((size_t)n * (2 * p.Ho) + 2 * oh + (t >> 1)) * (2 * p.Wo) + 2 * ow + (t & 1)) * 64 + co;
+          if (full_tile || m < p.M) p.out[o] = v;
         }
       }
     }
