@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libocr_amd.so")
+LIB_PATH = os.environ.get("OCR_AMD_LIB") or os.path.join(_HERE, "lib", "libocr_amd.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
         L.ocr_test_min_area_box.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
         L.ocr_test_box_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_void_p]
+        L.ocr_test_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.POINTER(C.c_float)]
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
@@ -188,6 +189,12 @@ class Detector:
         out = np.empty(n.value, np.float32)
         check(lib().ocr_test_det_stage(self._h, stage_id, _ptr(out), n.value, C.byref(n)))
         return np.ascontiguousarray(out.reshape(shape_nhwc).transpose(0, 3, 1, 2))
+
+    def debug_conv_bench(self, n, h, w, cin, cout, ks=3, stride=1, src_mode=0, iters=5) -> float:
+        """Test hook: average milliseconds of one conv_igemm launch of this shape."""
+        ms = C.c_float(0.0)
+        check(lib().ocr_test_conv_bench(self._h, n, h, w, cin, cout, ks, stride, src_mode, iters, C.byref(ms)))
+        return ms.value
 
     def debug_box_scores(self, pred_hw: np.ndarray, polys):
         """Test hook: raw (sum, count) of the GPU box-score kernel for given polygons."""

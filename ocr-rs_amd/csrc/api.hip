@@ -407,6 +407,46 @@ int ocr_test_box_scores(ocr_det_t* det, const float* prob_host, int h, int w, co
     OCR_HIP(hipStreamSynchronize(s));
   });
 }
+// micro-benchmark of one conv_igemm launch shape on constant data (kernel tuning aid)
+int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, int ks, int stride, int src_mode,
+                        int iters, float* ms_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det) fail(OCR_ERR_INVALID, "null handle");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const int pad = (ks - 1) / 2;
+    const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
+    const size_t in_e = (size_t)n * h * w * cin, w_e = (size_t)cout * ks * ks * cin, out_e = (size_t)n * ho * wo * cout;
+    float *in = nullptr, *wt = nullptr, *out = nullptr;
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&in), in_e * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&wt), w_e * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&out), out_e * 4));
+    OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(in), 0x3f8ccccd, in_e, s));   // 1.1f
+    OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wt), 0x3c23d70a, w_e, s));    // 0.01f
+    ConvDesc d{};
+    d.src[0] = in; d.src[1] = in; d.src[2] = in; d.src[3] = in;
+    d.src_mode = src_mode; d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    d.ks = ks; d.stride = stride; d.pad = pad; d.wgt = wt; d.relu = 1; d.store_mode = STORE_NHWC; d.out = out;
+    d.name = "bench";
+    hipEvent_t e0, e1;
+    OCR_HIP(hipEventCreate(&e0));
+    OCR_HIP(hipEventCreate(&e1));
+    launch_conv_igemm(d, s);
+    OCR_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_conv_igemm(d, s);
+    OCR_HIP(hipEventRecord(e1, s));
+    OCR_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    OCR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(in);
+    (void)hipFree(wt);
+    (void)hipFree(out);
+  });
+}
 int ocr_test_min_area_box(const int32_t* xy, int n, int32_t* box_xy, double* sside) {
   return guard([&] {
     std::vector<ocr::geom::Pt> in(n);

@@ -46,6 +46,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+#ifndef PIPE_AT
+#define PIPE_AT 0      // K-group after whose fragment reads the staging registers are recycled
+#endif
+#ifndef PIPE_FENCE
+#define PIPE_FENCE 1   // scheduling fence after that group's MFMAs
+#endif
 constexpr int BK = 32;
 constexpr int LDSK = 36;  // row stride in floats (144 B): 16-lane groups hit 16 distinct bank quads
 
@@ -54,9 +60,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int AI = BM / 32, BI = BN / 32;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDSK];
-  float* As = lds;
-  float* Bs = lds + BM * LDSK;
+  constexpr int TILE = (BM + BN) * LDSK;  // floats per LDS stage
+  __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -69,10 +74,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
-  // ---- per-thread gather coordinates: row r (+32 i), 16-byte chunk q of the K slab
+  // ---- per-thread gather coordinates: row r (+32 i), 16-byte chunk q of the K slab.
+  // All offsets are 32-bit element offsets (the host checks every tensor < 2^31 elements).
   const int r = tid >> 3;
   const int q = tid & 7;
-  int img[AI], ih0[AI], iw0[AI];
+  int ih0[AI], iw0[AI], abase[AI], img[AI];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
@@ -85,59 +91,64 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       img[i] = n;
       ih0[i] = oh * STRIDE - p.pad;
       iw0[i] = ow * STRIDE - p.pad;
+      if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; pixel offsets depend on the source
+      else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin + q * 4;
     } else {
-      img[i] = 0;
       ih0[i] = -(1 << 20);  // every tap out of range -> zeros
       iw0[i] = 0;
+      abase[i] = 0;
+      img[i] = 0;
     }
   }
-  const float* wrow[BI];
+  int wbase[BI];
 #pragma unroll
-  for (int i = 0; i < BI; ++i)
-    wrow[i] = p.wgt + (size_t)(n0 + r + 32 * i) * (KS * KS) * p.Cin + q * 4;
+  for (int i = 0; i < BI; ++i) wbase[i] = (n0 + r + 32 * i) * (KS * KS) * p.Cin + q * 4;
 
+  // staging registers of the K-step in flight: raw loads only; zero padding (and the
+  // upsample+add of UPADD) are applied when the registers go to LDS, one K-step later,
+  // so nothing waits on a load right after issuing it.
   f32x4 areg[AI], breg[BI];
+  f32x4 areg1[SRC == SRC_UPADD ? AI : 1];
+  unsigned okmask = 0;
 
-  // Branch-free gather: out-of-image taps (zero padding) and rows past M read a clamped,
-  // always valid address and are zeroed by a select, so all loads of a K-step issue together.
   auto load_tiles = [&](int tap, int c0) {
     const int kh = tap / KS, kw = tap - kh * KS;
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int ih = ih0[i] + kh, iw = iw0[i] + kw;
       const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
-      f32x4 v;
+      okmask |= (ok ? 1u : 0u) << i;
       if constexpr (SRC == SRC_PLAIN) {
-        const size_t pix = ((size_t)img[i] * p.Hin + ihc) * p.Win + iwc;
-        v = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
+        const int off = abase[i] + (kh * p.Win + kw) * p.Cin + c0;
+        areg[i] = *reinterpret_cast<const f32x4*>(p.src[0] + (ok ? off : 0));
       } else if constexpr (SRC == SRC_UPADD) {
-        const size_t pix = ((size_t)img[i] * p.Hin + ihc) * p.Win + iwc;
-        const size_t pix1 = ((size_t)img[i] * (p.Hin >> 1) + (ihc >> 1)) * (p.Win >> 1) + (iwc >> 1);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p.src[0] + pix * p.Cin + c0 + q * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.src[1] + pix1 * p.Cin + c0 + q * 4);
-        v = b + a;  // reference order: upsample(x_in{k+1}) + x_in{k}
-      } else {      // SRC_CAT4: channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
+        const int off = abase[i] + (kh * p.Win + kw) * p.Cin + c0;
+        // src[1] is the half-resolution lateral: nearest upsample = index >> 1
+        const int off1 = ((img[i] * (p.Hin >> 1) + (ih >> 1)) * (p.Win >> 1) + (iw >> 1)) * p.Cin + c0 + q * 4;
+        areg[i] = *reinterpret_cast<const f32x4*>(p.src[0] + (ok ? off : 0));
+        areg1[i] = *reinterpret_cast<const f32x4*>(p.src[1] + (ok ? off1 : 0));
+      } else {  // SRC_CAT4: channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
         const int s = c0 >> 6;
         const int sh = 3 - s;
-        const size_t pix = ((size_t)img[i] * (p.Hin >> sh) + (ihc >> sh)) * (p.Win >> sh) + (iwc >> sh);
-        v = *reinterpret_cast<const f32x4*>(p.src[s] + pix * 64 + (c0 & 63) + q * 4);
+        const int off = ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + (c0 & 63) + q * 4;
+        areg[i] = *reinterpret_cast<const f32x4*>(p.src[s] + (ok ? off : 0));
       }
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      areg[i] = ok ? v : z;
     }
 #pragma unroll
-    for (int i = 0; i < BI; ++i)
-      breg[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)tap * p.Cin + c0);
+    for (int i = 0; i < BI; ++i) breg[i] = *reinterpret_cast<const f32x4*>(p.wgt + wbase[i] + tap * p.Cin + c0);
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](float* stage) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
-      *reinterpret_cast<f32x4*>(&As[(r + 32 * i) * LDSK + q * 4]) = areg[i];
+    for (int i = 0; i < AI; ++i) {
+      f32x4 v = areg[i];
+      if constexpr (SRC == SRC_UPADD) v = areg1[i] + v;  // reference order: upsample(x_in{k+1}) + x_in{k}
+      *reinterpret_cast<f32x4*>(&stage[(r + 32 * i) * LDSK + q * 4]) = ((okmask >> i) & 1u) ? v : z;
+    }
 #pragma unroll
-    for (int i = 0; i < BI; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[(r + 32 * i) * LDSK + q * 4]) = breg[i];
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&stage[(BM + r + 32 * i) * LDSK + q * 4]) = breg[i];
   };
 
   f32x16 acc[MT][NT];
@@ -150,34 +161,41 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 
   const int csteps = p.Cin / BK;
   const int nsteps = KS * KS * csteps;
-  int tap = 0, c0 = 0;
 
-  load_tiles(0, 0);
-  store_tiles();
+  // step -> (tap, c0), clamped to the last step so that the loop body needs no branch
+  auto load_step = [&](int step) {
+    step = min(step, nsteps - 1);
+    const int tap = step / csteps;
+    load_tiles(tap, (step - tap * csteps) * BK);
+  };
+
+  // Pipeline: LDS stage k&1 holds K-step k; registers hold K-step k+1 (in flight); inside the
+  // MFMA sequence of step k the registers are written to the other stage and the loads of step
+  // k+2 are issued.  One barrier per K-step.
+  load_step(0);
+  store_tiles(lds);
+  load_step(1);
   __syncthreads();
 
   // MFMA operand fetch: lane l supplies row (l & 31); lanes 0-31 hold k = 8g+j,
   // lanes 32-63 hold k = 8g+4+j for the j-th MFMA of K-group g (same map for A and B).
-  const float* a_base = As + (wm * WM + (lane & 31)) * LDSK + (lane >> 5) * 4;
-  const float* b_base = Bs + (wn * WN + (lane & 31)) * LDSK + (lane >> 5) * 4;
+  const int a_off = (wm * WM + (lane & 31)) * LDSK + (lane >> 5) * 4;
+  const int b_off = (BM + wn * WN + (lane & 31)) * LDSK + (lane >> 5) * 4;
 
   for (int step = 0; step < nsteps; ++step) {
-    const bool more = step + 1 < nsteps;
-    if (more) {
-      c0 += BK;
-      if (c0 == p.Cin) {
-        c0 = 0;
-        ++tap;
-      }
-      load_tiles(tap, c0);
-    }
+    const float* cur = lds + (step & 1) * TILE;
+    float* nxt = lds + ((step + 1) & 1) * TILE;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDSK + g * 8);
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * LDSK + g * 8);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDSK + g * 8);
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(cur + b_off + j * 32 * LDSK + g * 8);
+      if (g == PIPE_AT) {
+        store_tiles(nxt);      // K-step k+1 (loaded one iteration ago): registers -> other LDS stage
+        load_step(step + 2);   // K-step k+2: global -> registers, most of an iteration ahead of its use
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -185,12 +203,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      // Region fence after the first K-group: hipcc otherwise sinks the global loads to the end
+      // of the body, next to their consumer.  Pinned here they are issued within the first
+      // quarter of the MFMAs and have the other three quarters (plus the next iteration's first
+      // group) to land.
+      if (PIPE_FENCE && g == PIPE_AT) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    if (more) {
-      store_tiles();
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
@@ -287,6 +306,9 @@ static void check(const ConvDesc& d) {
   if (d.Ho != (d.Hin + 2 * d.pad - d.ks) / d.stride + 1 || d.Wo != (d.Win + 2 * d.pad - d.ks) / d.stride + 1)
     fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
   if ((long long)d.N * d.Ho * d.Wo >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: M overflows int", d.name);
+  // the kernel addresses with 32-bit element offsets
+  if ((long long)d.N * d.Hin * d.Win * d.Cin >= (1ll << 31) || (long long)d.N * d.Ho * d.Wo * d.Cout * (d.store_mode == STORE_SHUFFLE2 ? 1 : 1) >= (1ll << 31) * 4)
+    fail(OCR_ERR_INVALID, "%s: tensor exceeds 2^31 elements; split the batch", d.name);
   if (d.src_mode == SRC_UPADD && ((d.Hin | d.Win) & 1)) fail(OCR_ERR_INVALID, "%s: UPADD needs even grid", d.name);
   if (d.src_mode == SRC_CAT4 && (d.Cin != 256 || ((d.Hin | d.Win) & 7)))
     fail(OCR_ERR_INVALID, "%s: CAT4 needs Cin 256 and a grid divisible by 8", d.name);
