@@ -132,3 +132,26 @@ def test_expand_random_star_polygons_match_oracle():
         if len(set(pts)) < len(pts):
             continue
         assert capi.host_expand_polygon(pts, 2.0)[0] == (O.expand_polygon(pts, 2.0) or [])
+
+
+def test_cpp_host_mirror_compiles_and_reports_errors(tmp_path):
+    """ocr-rs_amd/host/ocr_rs.hpp (the C++ mirror of the reference's call sites) builds with
+    plain g++ against the C ABI and surfaces failures as ocr_rs::Error, not as a crash."""
+    import subprocess
+    host = os.path.join(ROOT, "ocr-rs_amd", "host")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    exe = str(tmp_path / "demo")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", os.path.join(host, "demo.cpp"), "-L" + libdir,
+                           "-locr_amd", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, "/nonexistent.ocrw", "/nonexistent.ocrw"], env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "doesn't exist" in r.stderr      # text_detection/mod.rs:36-39 wording
+    det = tmp_path / "det.ocrw"
+    rec = tmp_path / "rec.ocrw"
+    det.write_bytes(W.pack_blob(W.make_det_weights(0)))
+    rec.write_bytes(W.pack_blob(W.make_rec_weights(0)))
+    r = subprocess.run([exe, str(det), str(rec)], env=env, capture_output=True, text=True)
+    if capi.lib().ocr_device_count() == 0:
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    else:
+        assert r.returncode == 0 and "classified as" in r.stdout
