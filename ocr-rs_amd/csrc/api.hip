@@ -425,8 +425,11 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
     OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(in), 0x3f8ccccd, in_e, s));   // 1.1f
     OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wt), 0x3c23d70a, w_e, s));    // 0.01f
     ConvDesc d{};
-    d.src[0] = in; d.src[1] = in; d.src[2] = in; d.src[3] = in;
-    d.src_mode = src_mode; d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    d.src[0] = in;
+    d.src_mode = SRC_PLAIN;
+    (void)src_mode;
+    d.src_bytes = in_e * 4;
+    d.wgt_bytes = w_e * 4; d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
     d.ks = ks; d.stride = stride; d.pad = pad; d.wgt = wt; d.relu = 1; d.store_mode = STORE_NHWC; d.out = out;
     d.name = "bench";
     hipEvent_t e0, e1;

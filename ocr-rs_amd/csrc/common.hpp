@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/ocr_amd.h"
 
@@ -37,13 +38,16 @@ struct Error : std::runtime_error {
 
 // ---- kernel launch descriptors ------------------------------------------------
 
-enum SrcMode { SRC_PLAIN = 0, SRC_UPADD = 1, SRC_CAT4 = 2 };
+enum SrcMode { SRC_PLAIN = 0, SRC_CAT4 = 2 };
 enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1 };
 
 // One convolution as an implicit GEMM: M = N*Ho*Wo pixels, N = Cout, K = ks*ks*Cin.
 // Activations are NHWC f32, weights [Cout][ks*ks][Cin] f32.
 struct ConvDesc {
-  const float* src[4];    // PLAIN: src[0]; UPADD: src[0] + up2(src[1]); CAT4: p5,p4,p3,p2
+  const float* src[4];    // PLAIN: src[0]; CAT4: p5,p4,p3,p2 (all inside ONE allocation starting at src_base)
+  const float* src_base;  // CAT4: start of the allocation holding the four sources (else unused)
+  size_t src_bytes;       // bytes addressable from src[0] (PLAIN) / src_base (CAT4); must be < 2^31
+  size_t wgt_bytes;
   int src_mode;
   int N, Hin, Win, Cin;   // logical input grid of this conv
   int Ho, Wo, Cout;
@@ -52,6 +56,10 @@ struct ConvDesc {
   const float* scale;     // per output column, may be null (then scale 1 / bias 0)
   const float* bias;
   const float* residual;  // NHWC, shape of the output, may be null
+  // second output: out2 = value + nearest_upsample_x2(up_residual) (FPN top-down sum,
+  // model.rs:126-137); up_residual is [N][Ho/2][Wo/2][Cout].  out may be null when out2 is set.
+  const float* up_residual;
+  float* out2;
   int relu;
   int store_mode;
   float* out;

@@ -5,29 +5,43 @@
 //   3x3 s1/s2 p1 (basic_block :40-55, out2..5 :80-98, bin_conv1 :100), 1x1 s1/s2
 //   (downsample :30-38, in2..in5 :75-78) and, as a 1x1 GEMM with a pixel-shuffle
 //   store, conv_transpose2d k=2 s=2 (bin_conv_tr1 :103).
-// Fused into the A-operand gather: nearest-upsample(x2) + add (:126-137) and the
-// channel concat of the four FPN outputs with their x8/x4/x2 upsamples (:140).
-// Fused into the epilogue: eval-mode batch norm as scale/bias, residual add, ReLU.
+// Fused into the A-operand gather: the channel concat of the four FPN outputs with their
+//   x8/x4/x2 nearest upsamples (:140) - the 256-channel fuse tensor is never written.
+// Fused into the epilogue: eval-mode batch norm as scale/bias, residual add, ReLU, and the
+//   FPN top-down sum  up2(in_{k+1}) + in_k  (:126-137) as a second output of the lateral conv.
 //
-// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 32; each wave owns
-// (BM/2) x (BN/2) as 32x32 MFMA tiles.  Operands are staged global -> VGPR -> LDS
-// (K-contiguous rows, stride 36 floats: conflict-free ds_read_b128), next K-step's
-// global loads are in flight while the current step's MFMAs run.
+// Data movement: both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds):
+// no staging registers, no ds_write, no per-K-step address arithmetic (the K-step offset is
+// an SGPR), and zero padding is free - a lane whose tap lies outside the image carries an
+// out-of-range buffer offset and the hardware writes zeros into LDS (verified on gfx950 by
+// tools/probes/lds_dma_probe.hip).  An LDS stage holds BM + BN rows of 32 floats (128 B,
+// unpadded because a DMA instruction writes 1 KiB lane-linearly = 8 rows); the 16-byte
+// chunk c of row r lives in slot c ^ ((r >> 1) & 7), applied on the global-address side and
+// undone by the fragment read, which makes every 16-lane ds_read_b128 group conflict-free.
+// Two stages, one barrier per K-step: the DMA of step k+1 flies during the MFMAs of step k.
+//
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 32 with BM,BN in {64,128};
+// each wave owns (BM/2) x (BN/2) as 32x32 MFMA tiles.
 #include "common.hpp"
 
 namespace ocr {
-namespace {
+namespace igemm {  // named (not anonymous): the kernel stubs are referenced from templates below
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
 
 struct ConvArgs {
-  const float* src[4];
+  const float* src;       // PLAIN: the input tensor; CAT4: allocation holding p5,p4,p3,p2
   const float* wgt;
   const float* scale;
   const float* bias;
   const float* residual;
+  const float* up_residual;
   float* out;
+  float* out2;
+  unsigned src_bytes, wgt_bytes;
+  int src_off[4];         // CAT4: element offset of p5,p4,p3,p2 inside src
   int N, Hin, Win, Cin;
   int Ho, Wo, Cout;
   int M;        // N*Ho*Wo
@@ -46,26 +60,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
-#ifndef PIPE_AT
-#define PIPE_AT 0      // K-group after whose fragment reads the staging registers are recycled
-#endif
-#ifndef PIPE_FENCE
-#define PIPE_FENCE 1   // scheduling fence after that group's MFMAs
-#endif
-constexpr int BK = 32;
-constexpr int LDSK = 36;  // row stride in floats (144 B): 16-lane groups hit 16 distinct bank quads
+constexpr int BK = 32;                    // floats per LDS row (one 128-byte line)
+[[maybe_unused]] constexpr unsigned OOB = 0x80000000u;     // voffset beyond any tensor (< 2^31 bytes): reads as zero
 
 template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources, LDS address space):
+                                     // the host pass only needs the launch stub
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int AI = BM / 32, BI = BN / 32;
-  constexpr int TILE = (BM + BN) * LDSK;  // floats per LDS stage
-  __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+  constexpr int STAGE = (BM + BN) * BK;   // floats per LDS stage
+  constexpr int NS = SRC == SRC_CAT4 ? 4 : 1;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
   const int bid = xcd_remap(blockIdx.x, p.nblk);
@@ -74,11 +85,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
-  // ---- per-thread gather coordinates: row r (+32 i), 16-byte chunk q of the K slab.
-  // All offsets are 32-bit element offsets (the host checks every tensor < 2^31 elements).
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+  const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+
+  // ---- DMA coordinates: this lane fills LDS slot q of rows r + 32 i with global chunk q ^ f(r)
   const int r = tid >> 3;
   const int q = tid & 7;
-  int ih0[AI], iw0[AI], abase[AI], img[AI];
+  const int gq = q ^ ((r >> 1) & 7);  // f(row) only depends on row bits 1..3; row = r + 32 i
+  int ih0[AI], iw0[AI], abase[AI];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
@@ -88,67 +102,53 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       const int rem = m - n * HoWo;
       const int oh = rem / p.Wo;
       const int ow = rem - oh * p.Wo;
-      img[i] = n;
       ih0[i] = oh * STRIDE - p.pad;
       iw0[i] = ow * STRIDE - p.pad;
-      if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; pixel offsets depend on the source
-      else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin + q * 4;
+      if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; the pixel offset depends on the source
+      else abase[i] = (((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin + gq * 4) * 4;  // bytes
     } else {
       ih0[i] = -(1 << 20);  // every tap out of range -> zeros
       iw0[i] = 0;
       abase[i] = 0;
-      img[i] = 0;
     }
   }
-  int wbase[BI];
+  unsigned bvoff[BI];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) wbase[i] = (n0 + r + 32 * i) * (KS * KS) * p.Cin + q * 4;
+  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((n0 + r + 32 * i) * (KS * KS) * p.Cin + gq * 4) * 4);
 
-  // staging registers of the K-step in flight: raw loads only; zero padding (and the
-  // upsample+add of UPADD) are applied when the registers go to LDS, one K-step later,
-  // so nothing waits on a load right after issuing it.
-  f32x4 areg[AI], breg[BI];
-  f32x4 areg1[SRC == SRC_UPADD ? AI : 1];
-  unsigned okmask = 0;
-
-  auto load_tiles = [&](int tap, int c0) {
+  // K is walked as segments (tap, source) of seg_steps K-steps; only the SGPR offset changes
+  // inside a segment, the per-lane offsets are recomputed when a segment starts.
+  const int seg_steps = SRC == SRC_CAT4 ? 2 : p.Cin / BK;
+  const int nsteps = KS * KS * NS * seg_steps;
+  unsigned avoff[AI];
+  int seg_koff = 0;  // K offset (floats) of the current segment inside a weight row
+  auto prep_segment = [&](int seg) {
+    const int tap = seg / NS, s = seg - tap * NS;
     const int kh = tap / KS, kw = tap - kh * KS;
-    okmask = 0;
+    seg_koff = tap * p.Cin + s * 64;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int ih = ih0[i] + kh, iw = iw0[i] + kw;
       const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      okmask |= (ok ? 1u : 0u) << i;
-      if constexpr (SRC == SRC_PLAIN) {
-        const int off = abase[i] + (kh * p.Win + kw) * p.Cin + c0;
-        areg[i] = *reinterpret_cast<const f32x4*>(p.src[0] + (ok ? off : 0));
-      } else if constexpr (SRC == SRC_UPADD) {
-        const int off = abase[i] + (kh * p.Win + kw) * p.Cin + c0;
-        // src[1] is the half-resolution lateral: nearest upsample = index >> 1
-        const int off1 = ((img[i] * (p.Hin >> 1) + (ih >> 1)) * (p.Win >> 1) + (iw >> 1)) * p.Cin + c0 + q * 4;
-        areg[i] = *reinterpret_cast<const f32x4*>(p.src[0] + (ok ? off : 0));
-        areg1[i] = *reinterpret_cast<const f32x4*>(p.src[1] + (ok ? off1 : 0));
-      } else {  // SRC_CAT4: channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
-        const int s = c0 >> 6;
+      unsigned off;
+      if constexpr (SRC == SRC_CAT4) {  // channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
         const int sh = 3 - s;
-        const int off = ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + (c0 & 63) + q * 4;
-        areg[i] = *reinterpret_cast<const f32x4*>(p.src[s] + (ok ? off : 0));
+        off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + gq * 4) * 4);
+      } else {
+        off = (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * 4);
       }
+      avoff[i] = ok ? off : OOB;
     }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) breg[i] = *reinterpret_cast<const f32x4*>(p.wgt + wbase[i] + tap * p.Cin + c0);
   };
-
-  auto store_tiles = [&](float* stage) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int stage, int cs) {
+    float* st = lds + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      f32x4 v = areg[i];
-      if constexpr (SRC == SRC_UPADD) v = areg1[i] + v;  // reference order: upsample(x_in{k+1}) + x_in{k}
-      *reinterpret_cast<f32x4*>(&stage[(r + 32 * i) * LDSK + q * 4]) = ((okmask >> i) & 1u) ? v : z;
-    }
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, avoff[i], cs * (BK * 4), 0, 0);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&stage[(BM + r + 32 * i) * LDSK + q * 4]) = breg[i];
+    for (int i = 0; i < BI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * BK), 16, bvoff[i],
+                                               (seg_koff + cs * BK) * 4, 0, 0);
   };
 
   f32x16 acc[MT][NT];
@@ -159,43 +159,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int csteps = p.Cin / BK;
-  const int nsteps = KS * KS * csteps;
+  // MFMA operand fetch: lane l supplies row (l & 31); lanes 0-31 hold k = 8g+j, lanes 32-63
+  // hold k = 8g+4+j for the j-th MFMA of K-group g (same map for A and B): chunk c = 2g + (l>>5),
+  // stored in slot c ^ f(row).
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  int xoff[BK / 8];
+#pragma unroll
+  for (int g = 0; g < BK / 8; ++g) xoff[g] = ((2 * g + (lane >> 5)) ^ fsw) * 4;
+  const int a_row = (wm * WM + frow) * BK;
+  const int b_row = (BM + wn * WN + frow) * BK;
 
-  // step -> (tap, c0), clamped to the last step so that the loop body needs no branch
-  auto load_step = [&](int step) {
-    step = min(step, nsteps - 1);
-    const int tap = step / csteps;
-    load_tiles(tap, (step - tap * csteps) * BK);
-  };
-
-  // Pipeline: LDS stage k&1 holds K-step k; registers hold K-step k+1 (in flight); inside the
-  // MFMA sequence of step k the registers are written to the other stage and the loads of step
-  // k+2 are issued.  One barrier per K-step.
-  load_step(0);
-  store_tiles(lds);
-  load_step(1);
-  __syncthreads();
-
-  // MFMA operand fetch: lane l supplies row (l & 31); lanes 0-31 hold k = 8g+j,
-  // lanes 32-63 hold k = 8g+4+j for the j-th MFMA of K-group g (same map for A and B).
-  const int a_off = (wm * WM + (lane & 31)) * LDSK + (lane >> 5) * 4;
-  const int b_off = (BM + wn * WN + (lane & 31)) * LDSK + (lane >> 5) * 4;
-
-  for (int step = 0; step < nsteps; ++step) {
-    const float* cur = lds + (step & 1) * TILE;
-    float* nxt = lds + ((step + 1) & 1) * TILE;
+  auto compute = [&](int stage) {
+    const float* st = lds + stage * STAGE;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * LDSK + g * 8);
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_row + i * 32 * BK + xoff[g]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(cur + b_off + j * 32 * LDSK + g * 8);
-      if (g == PIPE_AT) {
-        store_tiles(nxt);      // K-step k+1 (loaded one iteration ago): registers -> other LDS stage
-        load_step(step + 2);   // K-step k+2: global -> registers, most of an iteration ahead of its use
-      }
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + b_row + j * 32 * BK + xoff[g]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -203,19 +186,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-      // Region fence after the first K-group: hipcc otherwise sinks the global loads to the end
-      // of the body, next to their consumer.  Pinned here they are issued within the first
-      // quarter of the MFMAs and have the other three quarters (plus the next iteration's first
-      // group) to land.
-      if (PIPE_FENCE && g == PIPE_AT) __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+  };
+
+  int seg = 0, cs = 0;
+  prep_segment(0);
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int j = 1; j < nsteps; ++j) {
+    if (++cs == seg_steps) {
+      cs = 0;
+      prep_segment(++seg);
+    }
+    issue(j & 1, cs);        // DMA of K-step j flies while step j-1 is multiplied
+    compute((j - 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
+    __syncthreads();                                   // ... and so has everyone's; stage j-1 is free
   }
+  compute((nsteps - 1) & 1);
 
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-  // Per store instruction a wave writes 2 rows x 128 contiguous bytes.  A tile that lies fully
-  // inside M takes a branch-free path: all residual loads of a 32x32 tile are issued before
-  // they are consumed.
+  // Per store instruction a wave writes 2 rows x 128 contiguous bytes.
   const int colq = lane & 31;
   const int rowq = (lane >> 5) * 4;
   const bool full_tile = m0 + BM <= p.M;
@@ -239,12 +231,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) res[e] = 0.f;
         }
+        float up[16];
+        if (p.out2) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = min(mbase + (e & 3) + 8 * (e >> 2), p.M - 1);
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int oh = rem / p.Wo;
+            const int ow = rem - oh * p.Wo;
+            up[e] = p.up_residual[(((size_t)n * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1)) * p.Cout + col];
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = mbase + (e & 3) + 8 * (e >> 2);
           float v = acc[i][j][e] * sc + bi + res[e];
           if (p.relu) v = fmaxf(v, 0.f);
-          if (full_tile || m < p.M) p.out[(size_t)m * p.Cout + col] = v;
+          if (full_tile || m < p.M) {
+            if (p.out) p.out[(size_t)m * p.Cout + col] = v;
+            if (p.out2) p.out2[(size_t)m * p.Cout + col] = up[e] + v;  // upsample(x_in{k+1}) + x_in{k}
+          }
         }
       } else {
         // conv_transpose2d k=2 s=2: column = (a*2+b)*64 + co -> out[n][2i+a][2j+b][co]
@@ -265,17 +272,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
 void launch_inst(const ConvDesc& d, hipStream_t s) {
-  ConvArgs a;
-  for (int i = 0; i < 4; ++i) a.src[i] = d.src[i];
+  ConvArgs a{};
+  a.src = d.src_mode == SRC_CAT4 ? d.src_base : d.src[0];
+  a.src_bytes = (unsigned)d.src_bytes;
+  a.wgt_bytes = (unsigned)d.wgt_bytes;
+  for (int i = 0; i < 4; ++i) a.src_off[i] = d.src_mode == SRC_CAT4 ? (int)(d.src[i] - d.src_base) : 0;
   a.wgt = d.wgt;
   a.scale = d.scale;
   a.bias = d.bias;
   a.residual = d.residual;
+  a.up_residual = d.up_residual;
   a.out = d.out;
+  a.out2 = d.out2;
   a.N = d.N;
   a.Hin = d.Hin;
   a.Win = d.Win;
@@ -293,7 +306,8 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   OCR_HIP(hipGetLastError());
 }
 
-}  // namespace
+}  // namespace igemm
+using namespace igemm;
 
 // Host-side shape checks: the kernel assumes exactly these, and an out-of-bounds
 // access on the GPU can take the whole node down.
@@ -306,57 +320,72 @@ static void check(const ConvDesc& d) {
   if (d.Ho != (d.Hin + 2 * d.pad - d.ks) / d.stride + 1 || d.Wo != (d.Win + 2 * d.pad - d.ks) / d.stride + 1)
     fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
   if ((long long)d.N * d.Ho * d.Wo >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: M overflows int", d.name);
-  // the kernel addresses with 32-bit element offsets
-  if ((long long)d.N * d.Hin * d.Win * d.Cin >= (1ll << 31) || (long long)d.N * d.Ho * d.Wo * d.Cout * (d.store_mode == STORE_SHUFFLE2 ? 1 : 1) >= (1ll << 31) * 4)
-    fail(OCR_ERR_INVALID, "%s: tensor exceeds 2^31 elements; split the batch", d.name);
-  if (d.src_mode == SRC_UPADD && ((d.Hin | d.Win) & 1)) fail(OCR_ERR_INVALID, "%s: UPADD needs even grid", d.name);
-  if (d.src_mode == SRC_CAT4 && (d.Cin != 256 || ((d.Hin | d.Win) & 7)))
-    fail(OCR_ERR_INVALID, "%s: CAT4 needs Cin 256 and a grid divisible by 8", d.name);
-  if (d.store_mode == STORE_SHUFFLE2 && (d.Cout != 256 || d.ks != 1 || d.residual))
-    fail(OCR_ERR_INVALID, "%s: SHUFFLE2 store needs a 1x1 conv with Cout 4*64", d.name);
-  if (!d.src[0] || !d.wgt || !d.out) fail(OCR_ERR_INVALID, "%s: null operand", d.name);
+  // the kernel addresses its operands with 32-bit BYTE offsets below the out-of-range marker 2^31
+  const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)d.N * d.Hin * d.Win * d.Cin * 4;
+  if (in_bytes >= (1ll << 31) || (long long)d.src_bytes >= (1ll << 31) || (long long)d.src_bytes < in_bytes)
+    fail(OCR_ERR_INVALID, "%s: input of %lld bytes (addressable %zu) must be < 2^31 bytes; split the batch", d.name, in_bytes, d.src_bytes);
+  if ((long long)d.wgt_bytes != (long long)d.Cout * d.ks * d.ks * d.Cin * 4) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if (d.src_mode != SRC_PLAIN && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: source mode %d", d.name, d.src_mode);
+  if (d.src_mode == SRC_CAT4) {
+    if (d.Cin != 256 || ((d.Hin | d.Win) & 7) || d.ks != 3 || d.stride != 1 || d.Cout != 64)
+      fail(OCR_ERR_INVALID, "%s: CAT4 needs a 3x3 s1 256->64 conv on a grid divisible by 8", d.name);
+    for (int i = 0; i < 4; ++i) {
+      const long long need = (long long)d.N * (d.Hin >> (3 - i)) * (d.Win >> (3 - i)) * 64 * 4;
+      if (!d.src[i] || d.src[i] < d.src_base || (d.src[i] - d.src_base) * 4ll + need > (long long)d.src_bytes)
+        fail(OCR_ERR_INVALID, "%s: CAT4 source %d lies outside the shared allocation", d.name, i);
+    }
+  }
+  if (d.store_mode == STORE_SHUFFLE2 && (d.Cout != 256 || d.ks != 1 || d.residual || d.out2))
+    fail(OCR_ERR_INVALID, "%s: SHUFFLE2 store needs a plain 1x1 conv with Cout 4*64", d.name);
+  if (d.out2 && (!d.up_residual || ((d.Ho | d.Wo) & 1))) fail(OCR_ERR_INVALID, "%s: out2 needs up_residual and an even grid", d.name);
+  if (!d.src[0] || !d.wgt || (!d.out && !d.out2)) fail(OCR_ERR_INVALID, "%s: null operand", d.name);
 }
 
-enum Variant { V_3x3_S1_64, V_3x3_S1_128, V_3x3_S2_128, V_1x1_S1_128, V_1x1_S2_128, V_UPADD_64, V_CAT4_64, V_SHUFFLE_128, V_NONE };
-
-static Variant pick(const ConvDesc& d) {
-  if (d.store_mode == STORE_SHUFFLE2) return V_SHUFFLE_128;
-  if (d.src_mode == SRC_UPADD) return (d.ks == 3 && d.stride == 1 && d.Cout == 64) ? V_UPADD_64 : V_NONE;
-  if (d.src_mode == SRC_CAT4) return (d.ks == 3 && d.stride == 1 && d.Cout == 64) ? V_CAT4_64 : V_NONE;
-  if (d.ks == 3 && d.stride == 1) return d.Cout == 64 ? V_3x3_S1_64 : (d.Cout % 128 == 0 ? V_3x3_S1_128 : V_NONE);
-  if (d.ks == 3 && d.stride == 2) return d.Cout % 128 == 0 ? V_3x3_S2_128 : V_NONE;
-  if (d.ks == 1 && d.stride == 1) return d.Cout % 128 == 0 ? V_1x1_S1_128 : V_NONE;
-  if (d.ks == 1 && d.stride == 2) return d.Cout % 128 == 0 ? V_1x1_S2_128 : V_NONE;
-  return V_NONE;
+// Tile choice: the largest tile that still leaves >= 8 tiles per CU (256 CUs), so that the
+// last partial round of tiles costs little; small tiles keep their MFMA rate because the
+// DMA loop has almost no per-step overhead.
+enum Tile { T128x128, T128x64, T64x64 };
+static Tile pick_tile(const ConvDesc& d) {
+  const long long M = (long long)d.N * d.Ho * d.Wo;
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn); };
+  if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
+  if (blocks(128, 64) >= 2048) return T128x64;
+  return T64x64;
 }
+
+static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T128x64 ? "128x64" : "64x64"; }
 
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
-  switch (pick(d)) {
-    case V_3x3_S1_64: return "conv_igemm_f32<128,64,3,1,PLAIN>";
-    case V_3x3_S1_128: return "conv_igemm_f32<128,128,3,1,PLAIN>";
-    case V_3x3_S2_128: return "conv_igemm_f32<128,128,3,2,PLAIN>";
-    case V_1x1_S1_128: return "conv_igemm_f32<128,128,1,1,PLAIN>";
-    case V_1x1_S2_128: return "conv_igemm_f32<128,128,1,2,PLAIN>";
-    case V_UPADD_64: return "conv_igemm_f32<128,64,3,1,UPADD>";
-    case V_CAT4_64: return "conv_igemm_f32<128,64,3,1,CAT4>";
-    case V_SHUFFLE_128: return "conv_igemm_f32<128,128,1,1,PLAIN,SHUFFLE2>";
-    default: return "conv_igemm_f32<?>";
+  static thread_local char buf[96];
+  snprintf(buf, sizeof buf, "conv_igemm_f32<%s,k%d,s%d,%s%s>", tile_name(pick_tile(d)), d.ks, d.stride,
+           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : "");
+  // names must outlive the call: intern them
+  static thread_local std::vector<std::string>* pool = new std::vector<std::string>();
+  for (const auto& s : *pool)
+    if (s == buf) return s.c_str();
+  pool->reserve(64);
+  pool->push_back(buf);
+  return pool->back().c_str();
+}
+
+template <int KS, int STRIDE, int SRC, int STORE>
+static void launch_tiles(const ConvDesc& d, hipStream_t s) {
+  switch (pick_tile(d)) {
+    case T128x128: launch_inst<128, 128, KS, STRIDE, SRC, STORE>(d, s); break;
+    case T128x64: launch_inst<128, 64, KS, STRIDE, SRC, STORE>(d, s); break;
+    case T64x64: launch_inst<64, 64, KS, STRIDE, SRC, STORE>(d, s); break;
   }
 }
 
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
-  switch (pick(d)) {
-    case V_3x3_S1_64: launch_inst<128, 64, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s); break;
-    case V_3x3_S1_128: launch_inst<128, 128, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s); break;
-    case V_3x3_S2_128: launch_inst<128, 128, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s); break;
-    case V_1x1_S1_128: launch_inst<128, 128, 1, 1, SRC_PLAIN, STORE_NHWC>(d, s); break;
-    case V_1x1_S2_128: launch_inst<128, 128, 1, 2, SRC_PLAIN, STORE_NHWC>(d, s); break;
-    case V_UPADD_64: launch_inst<128, 64, 3, 1, SRC_UPADD, STORE_NHWC>(d, s); break;
-    case V_CAT4_64: launch_inst<128, 64, 3, 1, SRC_CAT4, STORE_NHWC>(d, s); break;
-    case V_SHUFFLE_128: launch_inst<128, 128, 1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s); break;
-    default: fail(OCR_ERR_INVALID, "%s: no conv_igemm variant for ks=%d stride=%d Cout=%d mode=%d", d.name, d.ks, d.stride, d.Cout, d.src_mode);
-  }
+  if (d.store_mode == STORE_SHUFFLE2) return launch_tiles<1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s);
+  if (d.src_mode == SRC_CAT4) return launch_tiles<3, 1, SRC_CAT4, STORE_NHWC>(d, s);
+  if (d.ks == 3 && d.stride == 1) return launch_tiles<3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.ks == 3 && d.stride == 2) return launch_tiles<3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.ks == 1 && d.stride == 1) return launch_tiles<1, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.ks == 1 && d.stride == 2) return launch_tiles<1, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+  fail(OCR_ERR_INVALID, "%s: no conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
 }
 
 }  // namespace ocr

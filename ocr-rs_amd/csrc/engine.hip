@@ -5,6 +5,7 @@
 // to per-channel scale/bias); activations live in NHWC f32 workspaces in HBM.
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -62,6 +63,7 @@ ConvW Detector::make_conv(const WeightBlob& wb, const std::string& wname, const 
       for (int k = 0; k < ks * ks; ++k) t[((size_t)o * ks * ks + k) * cin + c] = w[((size_t)o * cin + c) * ks * ks + k];
   ConvW cw;
   cw.w = arena_.upload(t);
+  cw.w_bytes = t.size() * sizeof(float);
   cw.cin = cin;
   cw.cout = cout;
   cw.ks = ks;
@@ -126,6 +128,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
         b4[k * 64 + co] = bias[co] * s[co] + b[co];
       }
     tr1_.w = arena_.upload(t);
+    tr1_.w_bytes = t.size() * sizeof(float);
     tr1_.scale = arena_.upload(s4);
     tr1_.bias = arena_.upload(b4);
     tr1_.cin = 64;
@@ -190,6 +193,11 @@ void Detector::ensure_workspace(int n, int h, int w) {
   };
   const size_t N = (size_t)n;
   s_ = alloc(N * (h / 4) * (w / 4) * 64);
+  size_t pcat_elems = 0;
+  for (int l = 0; l < 4; ++l) pcat_elems += N * (h >> (2 + l)) * (w >> (2 + l)) * 64;
+  pcat_ = alloc(pcat_elems);  // p2..p5 in ONE allocation: bin_conv1 gathers all four through one buffer descriptor
+  pcat_bytes_ = pcat_elems * sizeof(float);
+  size_t pofs = 0;
   for (int l = 0; l < 4; ++l) {
     const size_t px = N * (h >> (2 + l)) * (w >> (2 + l));
     const size_t c = (size_t)64 << l;
@@ -197,8 +205,10 @@ void Detector::ensure_workspace(int n, int h, int w) {
     a_[l] = alloc(px * c);
     x_[l] = alloc(px * c);
     d_[l] = l > 0 ? alloc(px * c) : nullptr;
-    i_[l] = alloc(px * 256);
-    p_[l] = alloc(px * 64);
+    i_[l] = l > 0 ? alloc(px * 256) : nullptr;   // raw lateral in3..in5 (in2 is only ever used inside its sum)
+    if (l < 3) sum_[l] = alloc(px * 256);        // up2(in_{k+1}) + in_k
+    p_[l] = pcat_ + pofs;
+    pofs += px * 64;
   }
   b1_ = alloc(N * (h / 4) * (w / 4) * 64);
   tr1buf_ = alloc(N * (h / 2) * (w / 2) * 64);
@@ -243,18 +253,46 @@ void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t
   if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32)
     fail(OCR_ERR_INVALID, "det_forward: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
   OCR_HIP(hipSetDevice(device_));
+  // The conv kernel addresses each tensor with 32-bit byte offsets below 2^31: the largest
+  // workspace tensor holds N*(H/4)*(W/4)*256 floats = N*H*W*64 bytes.  Larger batches run in chunks.
+  const long long per_frame = (long long)h * w * 64;
+  const int max_n = (int)std::min<long long>(n, ((1ll << 31) - 1) / per_frame);
+  if (max_n < 1) fail(OCR_ERR_INVALID, "det_forward: a %dx%d frame exceeds the 2^31-byte tensor limit", h, w);
+  for (int b = 0; b < n; b += max_n) {
+    const int nb = std::min(max_n, n - b);
+    const size_t off = (size_t)b * h * w;
+    forward_chunk(x + off, nb, h, w, prob + off, bitmap ? bitmap + off : nullptr, thresh, prof);
+  }
+}
+
+void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+                             std::vector<ProfileEntry>* prof) {
   ensure_workspace(n, h, w);
   Recorder rec{prof, stream_, {}};
 
+  struct Extra {
+    const float* residual = nullptr;
+    const float* up_residual = nullptr;
+    float* out2 = nullptr;
+    bool cat4 = false;
+    int store = STORE_NHWC;
+  };
   auto conv = [&](const char* name, const ConvW& cw, const float* src, int hin, int win, int stride, float* out,
-                  const float* residual, bool relu, int src_mode = SRC_PLAIN, const float* s1 = nullptr,
-                  const float* s2 = nullptr, const float* s3 = nullptr, int store = STORE_NHWC) {
+                  bool relu, const Extra& ex = Extra()) {
     ConvDesc d{};
     d.src[0] = src;
-    d.src[1] = s1;
-    d.src[2] = s2;
-    d.src[3] = s3;
-    d.src_mode = src_mode;
+    d.src_mode = ex.cat4 ? SRC_CAT4 : SRC_PLAIN;
+    if (ex.cat4) {
+      d.src[0] = p_[3];
+      d.src[1] = p_[2];
+      d.src[2] = p_[1];
+      d.src[3] = p_[0];
+      d.src_base = pcat_;
+      d.src_bytes = pcat_bytes_;
+    } else {
+      d.src_bytes = (size_t)n * hin * win * cw.cin * sizeof(float);
+    }
+    d.wgt_bytes = cw.w_bytes;
     d.N = n;
     d.Hin = hin;
     d.Win = win;
@@ -268,9 +306,11 @@ void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t
     d.wgt = cw.w;
     d.scale = cw.scale;
     d.bias = cw.bias;
-    d.residual = residual;
+    d.residual = ex.residual;
+    d.up_residual = ex.up_residual;
+    d.out2 = ex.out2;
     d.relu = relu ? 1 : 0;
-    d.store_mode = store;
+    d.store_mode = ex.store;
     d.out = out;
     d.name = name;
     rec.begin();
@@ -278,10 +318,10 @@ void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t
     const double M = (double)n * d.Ho * d.Wo;
     const double K = (double)cw.ks * cw.ks * cw.cin;
     double in_bytes = (double)n * hin * win * cw.cin * 4.0;
-    if (src_mode == SRC_UPADD) in_bytes *= 1.25;
-    if (src_mode == SRC_CAT4) in_bytes = (double)n * hin * win * 64 * 4.0 * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
-    const double bytes = in_bytes + M * cw.cout * 4.0 * (residual ? 2.0 : 1.0) + K * cw.cout * 4.0;
-    rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, bytes);
+    if (ex.cat4) in_bytes = (double)n * hin * win * 64 * 4.0 * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
+    double out_bytes = M * cw.cout * 4.0 * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
+                                            (ex.up_residual ? 0.25 : 0.0));
+    rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, in_bytes + out_bytes + K * cw.cout * 4.0);
   };
 
   const int h4 = h / 4, w4 = w / 4;
@@ -296,28 +336,44 @@ void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t
     const int hin = l == 0 ? h4 : (h >> (1 + l)), win = l == 0 ? w4 : (w >> (1 + l));
     const int ho = h >> (2 + l), wo = w >> (2 + l);
     const int stride = l == 0 ? 1 : 2;
-    conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], nullptr, true);
-    const float* shortcut = cur;
+    conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
+    Extra sc;
+    sc.residual = cur;
     if (l > 0) {
-      conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], nullptr, false);
-      shortcut = d_[l];
+      conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
+      sc.residual = d_[l];
     }
-    conv("layer.conv2", layer_[l][0][1], t_[l], ho, wo, 1, a_[l], shortcut, true);
-    conv("layer.conv1", layer_[l][1][0], a_[l], ho, wo, 1, t_[l], nullptr, true);
-    conv("layer.conv2", layer_[l][1][1], t_[l], ho, wo, 1, x_[l], a_[l], true);
+    conv("layer.conv2", layer_[l][0][1], t_[l], ho, wo, 1, a_[l], true, sc);
+    conv("layer.conv1", layer_[l][1][0], a_[l], ho, wo, 1, t_[l], true);
+    Extra sc2;
+    sc2.residual = a_[l];
+    conv("layer.conv2", layer_[l][1][1], t_[l], ho, wo, 1, x_[l], true, sc2);
     cur = x_[l];
   }
-  // FPN laterals in2..in5, model.rs:115-123
-  for (int l = 0; l < 4; ++l) conv("in", in_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, i_[l], nullptr, false);
+  // FPN laterals in5..in2 (model.rs:115-123), coarse to fine; each also emits the top-down sum
+  // up2(in_{k+1}) + in_k that the out_k conv consumes (model.rs:126-137)
+  conv("in5", in_[3], x_[3], h >> 5, w >> 5, 1, i_[3], false);
+  for (int l = 2; l >= 0; --l) {
+    Extra td;
+    td.up_residual = i_[l + 1];
+    td.out2 = sum_[l];
+    conv("in+topdown", in_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, l > 0 ? i_[l] : nullptr, false, td);
+  }
   // p_k = out_k(up2(in_{k+1}) + in_k), p5 = out5(in5), model.rs:126-138
-  for (int l = 0; l < 3; ++l)
-    conv("out", out_[l], i_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], nullptr, false, SRC_UPADD, i_[l + 1]);
-  conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], nullptr, false);
+  for (int l = 0; l < 3; ++l) conv("out", out_[l], sum_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], false);
+  conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
-  conv("bin_conv1", bin1_, p_[3], h4, w4, 1, b1_, nullptr, true, SRC_CAT4, p_[2], p_[1], p_[0]);
+  {
+    Extra c4;
+    c4.cat4 = true;
+    conv("bin_conv1", bin1_, p_[3], h4, w4, 1, b1_, true, c4);
+  }
   // bin_conv_tr1 + bias + bin_bn2 + relu, model.rs:146-148
-  conv("bin_conv_tr1", tr1_, b1_, h4, w4, 1, tr1buf_, nullptr, true, SRC_PLAIN, nullptr, nullptr, nullptr,
-       STORE_SHUFFLE2);
+  {
+    Extra sh;
+    sh.store = STORE_SHUFFLE2;
+    conv("bin_conv_tr1", tr1_, b1_, h4, w4, 1, tr1buf_, true, sh);
+  }
   // bin_conv_tr2 + bias + sigmoid (+ binarize), model.rs:149-150
   rec.begin();
   launch_convt2_sigmoid(tr1buf_, tr2_w_, tr2_bias_, prob, bitmap, thresh, n, h / 2, w / 2, stream_);
@@ -332,7 +388,8 @@ const float* Detector::stage(int id, size_t* elems) const {
   auto px = [&](int shift) { return N * (ws_h_ >> shift) * (ws_w_ >> shift); };
   if (id == 0) { *elems = px(2) * 64; return s_; }
   if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return x_[id - 1]; }
-  if (id >= 5 && id <= 8) { *elems = px(id - 3) * 256; return i_[id - 5]; }
+  if (id == 5) { *elems = px(2) * 256; return sum_[0]; }  // in2 only exists inside its top-down sum
+  if (id >= 6 && id <= 8) { *elems = px(id - 3) * 256; return i_[id - 5]; }
   if (id >= 9 && id <= 12) { *elems = px(id - 7) * 64; return p_[id - 9]; }
   if (id == 13) { *elems = px(2) * 64; return b1_; }
   if (id == 14) { *elems = px(1) * 64; return tr1buf_; }

@@ -27,6 +27,7 @@ class DeviceArena {  // bump allocator over one hipMalloc (weights)
 
 struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
+  size_t w_bytes = 0;
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
   int cin = 0, cout = 0, ks = 0;
@@ -71,7 +72,10 @@ class Detector {
   int ws_n_ = 0, ws_h_ = 0, ws_w_ = 0;
   std::vector<void*> ws_allocs_;
   float *s_ = nullptr, *t_[4] = {}, *a_[4] = {}, *d_[4] = {}, *x_[4] = {};
-  float *i_[4] = {}, *p_[4] = {}, *b1_ = nullptr, *tr1buf_ = nullptr;
+  float *i_[4] = {}, *sum_[3] = {}, *p_[4] = {}, *pcat_ = nullptr, *b1_ = nullptr, *tr1buf_ = nullptr;
+  size_t pcat_bytes_ = 0;
+  void forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+                     std::vector<ProfileEntry>* prof);
   void* scratch_[2] = {nullptr, nullptr};
   size_t scratch_bytes_[2] = {0, 0};
   float *stage_in_ = nullptr, *stage_out_ = nullptr;
