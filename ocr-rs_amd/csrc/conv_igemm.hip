@@ -206,20 +206,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   }
   compute((nsteps - 1) & 1);
 
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-  // Per store instruction a wave writes 2 rows x 128 contiguous bytes.
-  const int colq = lane & 31;
-  const int rowq = (lane >> 5) * 4;
-  const bool full_tile = m0 + BM <= p.M;
+  // ---- epilogue A (plain NHWC store, the MFMA-bound convs): straight from the accumulators.
+  // C/D map of a 32x32 MFMA tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); one store
+  // instruction writes 2 rows x 128 contiguous bytes.  Residual rows are all requested before use.
+  if (STORE == STORE_NHWC && !p.out2) {
+    const int colq = lane & 31;
+    const int rowq = (lane >> 5) * 4;
+    const bool full_tile = m0 + BM <= p.M;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * WN + j * 32 + colq;
-    const float sc = p.scale ? p.scale[col] : 1.f;
-    const float bi = p.bias ? p.bias[col] : 0.f;
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * WN + j * 32 + colq;
+      const float sc = p.scale ? p.scale[col] : 1.f;
+      const float bi = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int mbase = m0 + wm * WM + i * 32 + rowq;
-      if constexpr (STORE == STORE_NHWC) {
+      for (int i = 0; i < MT; ++i) {
+        const int mbase = m0 + wm * WM + i * 32 + rowq;
         float res[16];
         if (p.residual) {
 #pragma unroll
@@ -231,45 +232,104 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) res[e] = 0.f;
         }
-        float up[16];
-        if (p.out2) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = min(mbase + (e & 3) + 8 * (e >> 2), p.M - 1);
-            const int n = m / HoWo;
-            const int rem = m - n * HoWo;
-            const int oh = rem / p.Wo;
-            const int ow = rem - oh * p.Wo;
-            up[e] = p.up_residual[(((size_t)n * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1)) * p.Cout + col];
-          }
-        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = mbase + (e & 3) + 8 * (e >> 2);
           float v = acc[i][j][e] * sc + bi + res[e];
           if (p.relu) v = fmaxf(v, 0.f);
-          if (full_tile || m < p.M) {
-            if (p.out) p.out[(size_t)m * p.Cout + col] = v;
-            if (p.out2) p.out2[(size_t)m * p.Cout + col] = up[e] + v;  // upsample(x_in{k+1}) + x_in{k}
-          }
-        }
-      } else {
-        // conv_transpose2d k=2 s=2: column = (a*2+b)*64 + co -> out[n][2i+a][2j+b][co]
-        const int t = col >> 6, co = col & 63;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + (e & 3) + 8 * (e >> 2);
-          float v = acc[i][j][e] * sc + bi;
-          if (p.relu) v = fmaxf(v, 0.f);
-          const int mm = min(m, p.M - 1);
-          const int n = mm / HoWo;
-          const int rem = mm - n * HoWo;
-          const int oh = rem / p.Wo;
-          const int ow = rem - oh * p.Wo;
-          const size_t o = (((size_t)n * (2 * p.Ho) + 2 * oh + (t >> 1)) * (2 * p.Wo) + 2 * ow + (t & 1)) * 64 + co;
-          if (full_tile || m < p.M) p.out[o] = v;
+          if (full_tile || m < p.M) p.out[(size_t)m * p.Cout + col] = v;
         }
       }
+    }
+    return;
+  }
+
+  // ---- epilogue B (HBM-bound launches: lateral + top-down sum, transposed conv).  The accumulator
+  // tile goes through LDS (the operand stages are free now) so that global traffic is row-major
+  // float4: a wave touches 512 contiguous bytes of one pixel row per instruction.  Per-row index
+  // arithmetic (the only integer divisions) is done once per block by the first BM threads.
+  static_assert(BM * BN <= 2 * STAGE, "accumulator tile must fit in the operand stages");
+  constexpr int CPR = BN / 4;          // float4 chunks per tile row
+  constexpr int RPP = 256 / CPR;       // rows per pass
+  constexpr int PASSES = BM / RPP;
+  const int c4 = (tid % CPR) * 4;      // this thread's 4 columns (fixed)
+  const int rr0 = tid / CPR;           // its row in pass 0
+  const int col = n0 + c4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // residual rows are requested before the LDS round trip so their latency hides behind it
+  f32x4 res[PASSES];
+  if constexpr (STORE == STORE_NHWC) {
+    if (p.residual) {
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const int m = min(m0 + rr0 + k * RPP, p.M - 1);
+        res[k] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + col);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) res[k] = zero4;
+    }
+  }
+  __shared__ int row_aux[BM];   // per tile row: offset of its up_residual pixel / shuffled output pixel
+  __syncthreads();              // every wave is done reading the last operand stage
+  {
+    const int colq = lane & 31;
+    const int rowq = (lane >> 5) * 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          lds[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq) * BN + wn * WN + j * 32 + colq] = acc[i][j][e];
+  }
+  if (tid < BM && (STORE == STORE_SHUFFLE2 || p.out2)) {
+    const int m = min(m0 + tid, p.M - 1);
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
+    const int oh = rem / p.Wo;
+    const int ow = rem - oh * p.Wo;
+    if constexpr (STORE == STORE_SHUFFLE2) row_aux[tid] = ((n * (2 * p.Ho) + 2 * oh) * (2 * p.Wo) + 2 * ow) * 64;
+    else row_aux[tid] = ((n * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1)) * p.Cout;
+  }
+  __syncthreads();
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = zero4;
+  if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+  if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + col);
+  if constexpr (STORE == STORE_NHWC) {
+    f32x4 up[PASSES];
+    if (p.out2) {
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) up[k] = *reinterpret_cast<const f32x4*>(p.up_residual + row_aux[rr0 + k * RPP] + col);
+    }
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int rr = rr0 + k * RPP;
+      const int m = m0 + rr;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[rr * BN + c4]) * sc + bi + res[k];
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if (m < p.M) {
+        const size_t o = (size_t)m * p.Cout + col;
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
+        if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + o) = up[k] + v;  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
+      }
+    }
+  } else {
+    // conv_transpose2d k=2 s=2: column = (a*2+b)*64 + co -> out[n][2i+a][2j+b][co]
+    const int t = col >> 6, co = col & 63;
+    const int toff = ((t >> 1) * (2 * p.Wo) + (t & 1)) * 64 + co;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int rr = rr0 + k * RPP;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[rr * BN + c4]) * sc + bi;
+      if (p.relu) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+      }
+      if (m0 + rr < p.M) *reinterpret_cast<f32x4*>(p.out + (size_t)row_aux[rr] + toff) = v;
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
