@@ -53,6 +53,21 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel: str, n: int, s: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md);
+    None when no extract for this workload is committed.  Not measured live: PMC needs rocprofv3."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        if t.get("batch") == n and t.get("size") == s:
+            e = t["kernels"].get(kernel)
+            return None if e is None else {"hbm_bytes_per_launch": e["bytes_per_launch"], "source": t["source"]}
+    except Exception:
+        pass
+    return None
+
+
 def host_cores() -> int:
     """CPU share of this container: cgroup quota if any (a 1-GPU box gets 16), else affinity."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -94,13 +109,21 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # one rank per GPU; OCR_BENCH_BACKEND=gloo (+ fewer GPUs than ranks) only exists to rehearse the
+    # multi-rank control flow on a 1-GPU box
+    backend = os.environ.get("OCR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     n, s = a.batch, a.size
     det_w = W.make_det_weights(0)
@@ -130,7 +153,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=x.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -150,7 +173,8 @@ def main():
         name, (ms, fl, by, cnt) = dom
         achieved = fl / (ms * 1e-3) / 1e12
         roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": pmc_traffic(name, n, s),
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
                 "avg_launch_gflop": round(fl / cnt / 1e9, 3),
                 "all_kernels": {k: {"ms_per_step": round(v[0] / reps, 4),
@@ -162,6 +186,8 @@ def main():
     gathered = None
     if dist is not None:
         counts = bitmap.view(n, -1).sum(dim=1, dtype=torch.int32)
+        if backend != "nccl":
+            counts = counts.cpu()
         out = [torch.empty_like(counts) for _ in range(world)]
         dist.all_gather(out, counts)
         gathered = int(torch.stack(out).numel())

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int AI = BM / 32, BI = BN / 32;
   constexpr int STAGE = (BM + BN) * BK;   // floats per LDS stage
-  constexpr int NS = SRC == SRC_CAT4 ? 4 : 1;
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -116,35 +115,60 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((n0 + r + 32 * i) * (KS * KS) * p.Cin + gq * 4) * 4);
 
-  // K is walked as segments (tap, source) of seg_steps K-steps; only the SGPR offset changes
-  // inside a segment, the per-lane offsets are recomputed when a segment starts.
-  const int seg_steps = SRC == SRC_CAT4 ? 2 : p.Cin / BK;
-  const int nsteps = KS * KS * NS * seg_steps;
-  unsigned avoff[AI];
+  // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
+  // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
+  // coming back to each pixel's lines once per tap with a reuse distance far beyond L2 (the
+  // 256-channel out2 conv fetched 8.8x its input that way).  All tap offsets are precomputed
+  // per row; only SGPR offsets change in the loop.
+  // CAT4: segments (tap, source) of 2 K-steps; per-lane offsets recomputed per segment.
+  constexpr int NTAP = KS * KS;
+  const int csteps = p.Cin / BK;
+  unsigned avoff[SRC == SRC_CAT4 ? 1 : NTAP][AI];
+  if constexpr (SRC != SRC_CAT4) {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int ih = ih0[i] + kh, iw = iw0[i] + kw;
+        const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        avoff[t][i] = ok ? (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * 4) : OOB;
+      }
+    }
+  }
+  auto issue_plain = [&](float* st, const unsigned (&av)[AI], int tap, int c) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, av[i], c * (BK * 4), 0, 0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * BK), 16, bvoff[i],
+                                               (tap * p.Cin + c * BK) * 4, 0, 0);
+  };
+
+  // ---- CAT4 machinery
+  const int seg_steps = 2;
+  unsigned cvoff[AI];
   int seg_koff = 0;  // K offset (floats) of the current segment inside a weight row
   auto prep_segment = [&](int seg) {
-    const int tap = seg / NS, s = seg - tap * NS;
+    const int tap = seg >> 2, s = seg & 3;
     const int kh = tap / KS, kw = tap - kh * KS;
     seg_koff = tap * p.Cin + s * 64;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int ih = ih0[i] + kh, iw = iw0[i] + kw;
       const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      unsigned off;
-      if constexpr (SRC == SRC_CAT4) {  // channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
-        const int sh = 3 - s;
-        off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + gq * 4) * 4);
-      } else {
-        off = (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * 4);
-      }
-      avoff[i] = ok ? off : OOB;
+      // channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
+      const int sh = 3 - s;
+      const unsigned off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + gq * 4) * 4);
+      cvoff[i] = ok ? off : OOB;
     }
   };
-  auto issue = [&](int stage, int cs) {
+  auto issue_cat = [&](int stage, int cs) {
     float* st = lds + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, avoff[i], cs * (BK * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, cvoff[i], cs * (BK * 4), 0, 0);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * BK), 16, bvoff[i],
@@ -189,22 +213,43 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     }
   };
 
-  int seg = 0, cs = 0;
-  prep_segment(0);
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int j = 1; j < nsteps; ++j) {
-    if (++cs == seg_steps) {
-      cs = 0;
-      prep_segment(++seg);
+  if constexpr (SRC != SRC_CAT4) {
+    int par = 0;  // LDS stage holding the K-step about to be multiplied
+    issue_plain(lds, avoff[0], 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < csteps; ++c) {
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        float* nxt = lds + (par ^ 1) * STAGE;
+        // DMA of the next K-step flies while this one is multiplied
+        if (t + 1 < NTAP) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c);
+        else if (c + 1 < csteps) issue_plain(nxt, avoff[0], 0, c + 1);
+        compute(par);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
+        __syncthreads();                                   // ... and so has everyone's; the old stage is free
+        par ^= 1;
+      }
     }
-    issue(j & 1, cs);        // DMA of K-step j flies while step j-1 is multiplied
-    compute((j - 1) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
-    __syncthreads();                                   // ... and so has everyone's; stage j-1 is free
+  } else {
+    const int nsteps = NTAP * 4 * seg_steps;
+    int seg = 0, cs = 0;
+    prep_segment(0);
+    issue_cat(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int j = 1; j < nsteps; ++j) {
+      if (++cs == seg_steps) {
+        cs = 0;
+        prep_segment(++seg);
+      }
+      issue_cat(j & 1, cs);
+      compute((j - 1) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    compute((nsteps - 1) & 1);
   }
-  compute((nsteps - 1) & 1);
 
   // ---- epilogue A (plain NHWC store, the MFMA-bound convs): straight from the accumulators.
   // C/D map of a 32x32 MFMA tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); one store
@@ -239,6 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
           if (p.relu) v = fmaxf(v, 0.f);
           if (full_tile || m < p.M) p.out[(size_t)m * p.Cout + col] = v;
         }
+        __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile at a time: keeps the residual staging at 16 registers
       }
     }
     return;
@@ -256,20 +302,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int rr0 = tid / CPR;           // its row in pass 0
   const int col = n0 + c4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  // residual rows are requested before the LDS round trip so their latency hides behind it
-  f32x4 res[PASSES];
-  if constexpr (STORE == STORE_NHWC) {
-    if (p.residual) {
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k) {
-        const int m = min(m0 + rr0 + k * RPP, p.M - 1);
-        res[k] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + col);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k) res[k] = zero4;
-    }
-  }
   __shared__ int row_aux[BM];   // per tile row: offset of its up_residual pixel / shuffled output pixel
   __syncthreads();              // every wave is done reading the last operand stage
   {
@@ -297,24 +329,31 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
   if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + col);
   if constexpr (STORE == STORE_NHWC) {
-    f32x4 up[PASSES];
-    if (p.out2) {
+    constexpr int G = PASSES < 4 ? PASSES : 4;  // rows in flight per thread: bounds the staging registers
 #pragma unroll
-      for (int k = 0; k < PASSES; ++k) up[k] = *reinterpret_cast<const f32x4*>(p.up_residual + row_aux[rr0 + k * RPP] + col);
-    }
+    for (int k0 = 0; k0 < PASSES; k0 += G) {
+      f32x4 up[G], res[G];
 #pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-      const int rr = rr0 + k * RPP;
-      const int m = m0 + rr;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[rr * BN + c4]) * sc + bi + res[k];
-      if (p.relu) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      for (int k = 0; k < G; ++k) {
+        const int rr = rr0 + (k0 + k) * RPP;
+        const int m = min(m0 + rr, p.M - 1);
+        up[k] = p.out2 ? *reinterpret_cast<const f32x4*>(p.up_residual + row_aux[rr] + col) : zero4;
+        res[k] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + col) : zero4;
       }
-      if (m < p.M) {
-        const size_t o = (size_t)m * p.Cout + col;
-        if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
-        if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + o) = up[k] + v;  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int rr = rr0 + (k0 + k) * RPP;
+        const int m = m0 + rr;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[rr * BN + c4]) * sc + bi + res[k];
+        if (p.relu) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        if (m < p.M) {
+          const size_t o = (size_t)m * p.Cout + col;
+          if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
+          if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + o) = up[k] + v;  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
+        }
       }
     }
   } else {

@@ -11,14 +11,18 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TPH = 4, TPW = 8;                 // pooled output tile per workgroup
-constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1;  // conv rows/cols feeding it (3x3 s2 window)
-constexpr int IR = 2 * (CR - 1) + 7, IC = 2 * (CC - 1) + 7;  // input rows/cols feeding those (7x7 s2)
+constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1;  // conv rows/cols feeding it (3x3 s2 window): 9 x 17
+constexpr int CG = (CC + 3) / 4;                // conv columns are produced 4 at a time: 5 groups (20 >= 17)
+constexpr int IR = 2 * (CR - 1) + 7;            // input rows feeding the conv tile (7x7 s2): 23
+constexpr int ICP = 8 * CG + 8;                 // padded input row: group g reads floats [8g, 8g+16)
 
-// grid (Wp/TPW, Hp/TPH, N), 256 threads: lane = output channel, wave = conv pixel slot.
+// grid (Wp/TPW, Hp/TPH, N), 256 threads: lane = output channel; a wave walks (conv row, column
+// group) items.  Per item and kernel row the 13 input values of 4 neighbouring conv pixels are
+// fetched with 4 broadcast ds_read_b128 and reused for 28 FMAs.
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
                                                    float* __restrict__ out, int H, int W) {
-  __shared__ float in_s[IR][IC + 1];
+  __shared__ __attribute__((aligned(16))) float in_s[IR][ICP];
   __shared__ float conv_s[CR * CC][64];
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
@@ -27,10 +31,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;
   const int ir0 = 2 * cr0 - 3, ic0 = 2 * cc0 - 3;
   const float* xin = x + (size_t)n * H * W;
-  for (int i = tid; i < IR * IC; i += 256) {
-    const int rr = i / IC, cc = i - rr * IC;
+  for (int i = tid; i < IR * ICP; i += 256) {
+    const int rr = i / ICP, cc = i - rr * ICP;
     const int ih = ir0 + rr, iw = ic0 + cc;
-    float v = 0.f;  // zero padding of conv1
+    float v = 0.f;  // zero padding of conv1 (and the unused tail of the padded row)
     if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[(size_t)ih * W + iw];
     in_s[rr][cc] = v;
   }
@@ -40,21 +44,32 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   for (int t = 0; t < 49; ++t) wreg[t] = w49x64[t * 64 + c];
   const float sc = scale[c], bi = bias[c];
   __syncthreads();
-  for (int pix = wv; pix < CR * CC; pix += 4) {
-    const int pr = pix / CC, pc = pix - pr * CC;
-    const int cr = cr0 + pr, cc = cc0 + pc;
-    // conv positions outside the conv grid are max-pool padding: they never win
-    // against the always-valid window centre because ReLU output is >= 0.
-    float v = 0.f;
-    if ((unsigned)cr < (unsigned)Hc && (unsigned)cc < (unsigned)Wc) {
-      float acc = 0.f;
+  for (int item = wv; item < CR * CG; item += 4) {
+    const int pr = item / CG, g = item - pr * CG;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kh = 0; kh < 7; ++kh)
+    for (int kh = 0; kh < 7; ++kh) {
+      float in[16];
 #pragma unroll
-        for (int kw = 0; kw < 7; ++kw) acc = fmaf(in_s[2 * pr + kh][2 * pc + kw], wreg[kh * 7 + kw], acc);
-      v = fmaxf(acc * sc + bi, 0.f);
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(&in[4 * q]) = *reinterpret_cast<const f32x4*>(&in_s[2 * pr + kh][8 * g + 4 * q]);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) acc[px] = fmaf(in[2 * px + kw], wreg[kh * 7 + kw], acc[px]);
     }
-    conv_s[pix][c] = v;
+    const int cr = cr0 + pr;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const int pc = 4 * g + px;
+      if (pc < CC) {
+        const int cc = cc0 + pc;
+        // conv positions outside the conv grid are max-pool padding: they never win against the
+        // always-valid window centre because ReLU output is >= 0.
+        const bool valid = (unsigned)cr < (unsigned)Hc && (unsigned)cc < (unsigned)Wc;
+        conv_s[pr * CC + pc][c] = valid ? fmaxf(acc[px] * sc + bi, 0.f) : 0.f;
+      }
+    }
   }
   __syncthreads();
   for (int o = tid; o < TPH * TPW * 64; o += 256) {
