@@ -123,56 +123,37 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   // CAT4: segments (tap, source) of 2 K-steps; per-lane offsets recomputed per segment.
   constexpr int NTAP = KS * KS;
   const int csteps = p.Cin / BK;
-  unsigned avoff[SRC == SRC_CAT4 ? 1 : NTAP][AI];
-  if constexpr (SRC != SRC_CAT4) {
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t) {
-      const int kh = t / KS, kw = t - kh * KS;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const int ih = ih0[i] + kh, iw = iw0[i] + kw;
-        const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-        avoff[t][i] = ok ? (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * 4) : OOB;
-      }
+  unsigned avoff[NTAP][AI];
+  // offsets of all taps for source s (PLAIN: the one input tensor; CAT4: p5,p4,p3,p2 = s 0..3,
+  // nearest-upsampled by 8,4,2,1, 64 channels each)
+  auto tap_offset = [&](int s, int t, int i) -> unsigned {
+    const int kh = t / KS, kw = t - kh * KS;
+    const int ih = ih0[i] + kh, iw = iw0[i] + kw;
+    const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+    unsigned off;
+    if constexpr (SRC == SRC_CAT4) {
+      const int sh = 3 - s;
+      off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + gq * 4) * 4);
+    } else {
+      off = (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * 4);
     }
-  }
-  auto issue_plain = [&](float* st, const unsigned (&av)[AI], int tap, int c) {
+    return ok ? off : OOB;
+  };
+  auto prep_source = [&](int s) {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+      for (int i = 0; i < AI; ++i) avoff[t][i] = tap_offset(s, t, i);
+  };
+  prep_source(0);
+  auto issue_plain = [&](float* st, const unsigned (&av)[AI], int tap, int c, int kbase) {
 #pragma unroll
     for (int i = 0; i < AI; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, av[i], c * (BK * 4), 0, 0);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * BK), 16, bvoff[i],
-                                               (tap * p.Cin + c * BK) * 4, 0, 0);
-  };
-
-  // ---- CAT4 machinery
-  const int seg_steps = 2;
-  unsigned cvoff[AI];
-  int seg_koff = 0;  // K offset (floats) of the current segment inside a weight row
-  auto prep_segment = [&](int seg) {
-    const int tap = seg >> 2, s = seg & 3;
-    const int kh = tap / KS, kw = tap - kh * KS;
-    seg_koff = tap * p.Cin + s * 64;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int ih = ih0[i] + kh, iw = iw0[i] + kw;
-      const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      // channels [0,64) p5 (x8), [64,128) p4 (x4), [128,192) p3 (x2), [192,256) p2
-      const int sh = 3 - s;
-      const unsigned off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + gq * 4) * 4);
-      cvoff[i] = ok ? off : OOB;
-    }
-  };
-  auto issue_cat = [&](int stage, int cs) {
-    float* st = lds + stage * STAGE;
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, cvoff[i], cs * (BK * 4), 0, 0);
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * BK), 16, bvoff[i],
-                                               (seg_koff + cs * BK) * 4, 0, 0);
+                                               (tap * p.Cin + kbase + c * BK) * 4, 0, 0);
   };
 
   f32x16 acc[MT][NT];
@@ -213,42 +194,38 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     }
   };
 
-  if constexpr (SRC != SRC_CAT4) {
-    int par = 0;  // LDS stage holding the K-step about to be multiplied
-    issue_plain(lds, avoff[0], 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < csteps; ++c) {
+  // One pass = all channel chunks of one source (PLAIN: the only one; CAT4: four passes of 2 chunks).
+  constexpr int NSRC = SRC == SRC_CAT4 ? 4 : 1;
+  const int pass_chunks = SRC == SRC_CAT4 ? 2 : csteps;
+  int par = 0;  // LDS stage holding the K-step about to be multiplied
+  issue_plain(lds, avoff[0], 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < NSRC; ++s) {
+    // first K-step of the NEXT source needs that source's tap-0 offsets while this source's
+    // table is still live: computed up front (AI registers)
+    unsigned next0[AI];
+    if constexpr (SRC == SRC_CAT4) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) next0[i] = tap_offset(min(s + 1, NSRC - 1), 0, i);
+    }
+    for (int c = 0; c < pass_chunks; ++c) {
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
         float* nxt = lds + (par ^ 1) * STAGE;
         // DMA of the next K-step flies while this one is multiplied
-        if (t + 1 < NTAP) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c);
-        else if (c + 1 < csteps) issue_plain(nxt, avoff[0], 0, c + 1);
+        if (t + 1 < NTAP) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c, s * 64);
+        else if (c + 1 < pass_chunks) issue_plain(nxt, avoff[0], 0, c + 1, s * 64);
+        else if (SRC == SRC_CAT4 && s + 1 < NSRC) issue_plain(nxt, next0, 0, 0, (s + 1) * 64);
         compute(par);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
         __syncthreads();                                   // ... and so has everyone's; the old stage is free
         par ^= 1;
       }
     }
-  } else {
-    const int nsteps = NTAP * 4 * seg_steps;
-    int seg = 0, cs = 0;
-    prep_segment(0);
-    issue_cat(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int j = 1; j < nsteps; ++j) {
-      if (++cs == seg_steps) {
-        cs = 0;
-        prep_segment(++seg);
-      }
-      issue_cat(j & 1, cs);
-      compute((j - 1) & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    if constexpr (SRC == SRC_CAT4) {
+      if (s + 1 < NSRC) prep_source(s + 1);
     }
-    compute((nsteps - 1) & 1);
   }
 
   // ---- epilogue A (plain NHWC store, the MFMA-bound convs): straight from the accumulators.
