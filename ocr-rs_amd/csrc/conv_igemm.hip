@@ -22,6 +22,8 @@
 //
 // Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 32 with BM,BN in {64,128};
 // each wave owns (BM/2) x (BN/2) as 32x32 MFMA tiles.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ocr {
@@ -49,7 +51,15 @@ struct ConvArgs {
   int relu;
   int nblk_n;   // Cout / BN
   int nblk;     // total blocks
+  unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
 };
+
+// x / d for 0 <= x < 2^31 with host-computed (magic, shift): 5 instructions instead of ~25
+__device__ __forceinline__ int fast_div(int x, unsigned magic, unsigned shift) {
+  if (shift == 0xFFFFFFFFu) return x;  // d == 1 (wave-uniform)
+  const unsigned t = __umulhi((unsigned)x, magic);
+  return (int)((t + (((unsigned)x - t) >> 1)) >> shift);
+}
 
 // Consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its
 // own L2).  Remap so that every XCD walks a contiguous run of tiles: neighbouring
@@ -97,9 +107,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + r + 32 * i;
     if (m < p.M) {
-      const int n = m / HoWo;
+      const int n = fast_div(m, p.mg_howo, p.sh_howo);
       const int rem = m - n * HoWo;
-      const int oh = rem / p.Wo;
+      const int oh = fast_div(rem, p.mg_wo, p.sh_wo);
       const int ow = rem - oh * p.Wo;
       ih0[i] = oh * STRIDE - p.pad;
       iw0[i] = ow * STRIDE - p.pad;
@@ -351,6 +361,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// libdivide-style unsigned division by an invariant d >= 1
+static void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;
+  *magic = L == 0 ? 0u : (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+  *shift = L == 0 ? 0xFFFFFFFFu : L - 1;  // d == 1: identity
+}
+
 template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
 void launch_inst(const ConvDesc& d, hipStream_t s) {
   ConvArgs a{};
@@ -378,7 +396,10 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.nblk_n = d.Cout / BN;
   const int nblk_m = (a.M + BM - 1) / BM;
   a.nblk = nblk_m * a.nblk_n;
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), 0, s, a);
+  make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
+  make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
+  static const int extra_lds = getenv("OCR_CONV_EXTRA_LDS") ? atoi(getenv("OCR_CONV_EXTRA_LDS")) : 0;  // tuning knob: caps residency
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), extra_lds, s, a);
   OCR_HIP(hipGetLastError());
 }
 
