@@ -68,6 +68,21 @@ def pmc_traffic(kernel: str, n: int, s: int):
     return None
 
 
+def text_like_maps(n: int, s: int, seed: int) -> np.ndarray:
+    """Probability maps with text-like blobs (the reference's gt_shrinked fixtures, cropped to s x s and
+    jittered): random-weight network outputs are noise, which is not what post-processing sees in use."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    names = ["gt_shrinked_img55.png", "gt_shrinked_img224.png", "gt_shrinked_img494.png", "gt_shrinked_img545.png"]
+    out = []
+    for i in range(n):
+        g = np.array(Image.open(os.path.join(ROOT, "tests", "golden", names[i % 4])).convert("L"))
+        o = (800 - s) // 2
+        g = g[o:o + s, o:o + s] if s <= 800 else np.pad(g, ((0, s - 800), (0, s - 800)))
+        out.append(np.where(g > 127, 0.8 + 0.2 * rng.rand(s, s), 0.1 * rng.rand(s, s)).astype(np.float32))
+    return np.ascontiguousarray(np.stack(out)[:, None])
+
+
 def host_cores() -> int:
     """CPU share of this container: cgroup quota if any (a 1-GPU box gets 16), else affinity."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -182,15 +197,30 @@ def main():
                                     "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
 
-    # ---- the exchange step of the sharded path: gather per-image results over RCCL (outside the timed region)
+    # ---- the exchange step of the sharded path (outside the timed region): every rank post-processes
+    # text-like maps of its shard (get_boxes_and_box_scores) and the variable-length polygon blocks
+    # are all-gathered - RCCL over xGMI when the backend is nccl (ocr-rs_amd/parallel.py)
     gathered = None
-    if dist is not None:
-        counts = bitmap.view(n, -1).sum(dim=1, dtype=torch.int32)
-        if backend != "nccl":
-            counts = counts.cpu()
-        out = [torch.empty_like(counts) for _ in range(world)]
-        dist.all_gather(out, counts)
-        gathered = int(torch.stack(out).numel())
+    post = {}
+    try:
+        maps = text_like_maps(min(n, 8), s, seed=rank)
+        pm = torch.from_numpy(maps).to(x.device)
+        torch.cuda.synchronize()
+        params = capi.default_params(skip_degenerate=True)
+        adj = np.ones((maps.shape[0], 2))
+        polys, scores = det.postprocess(pm, maps.shape[0], s, s, adj, capi.MEM_DEVICE, params)
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            det.postprocess(pm, maps.shape[0], s, s, adj, capi.MEM_DEVICE, params)
+        post = {"postprocess_images_per_s": round(maps.shape[0] * reps / (time.perf_counter() - t1), 1),
+                "postprocess_polygons_per_image": round(sum(len(p) for p in polys) / maps.shape[0], 2)}
+        if dist is not None:
+            from ocr_rs_amd import parallel as P
+            all_p, all_s = P.all_gather_results(polys, scores, x.device if backend == "nccl" else torch.device("cpu"))
+            gathered = {"images": len(all_p), "polygons": sum(len(p) for p in all_p)}
+    except Exception as e:  # side numbers never hide the headline
+        post = {"postprocess_error": str(e)}
 
     extras = {}
     if rank == 0 and not a.no_extras:
@@ -228,7 +258,8 @@ def main():
             "roofline": roof,
         }
         if gathered is not None:
-            line["rccl_all_gather_results"] = gathered
+            line["all_gather_results"] = gathered
+        line.update(post)
         line.update(extras)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(det_w, s, a.cpu_seconds)

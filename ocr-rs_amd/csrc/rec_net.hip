@@ -1,4 +1,4 @@
-// Recognition network, one fused launch: one workgroup per 28x28 crop.
+// Recognition network, one fused launch: one 1024-thread workgroup per 28x28 crop.
 //   /root/reference/src/char_recognition/model.rs:27-39
 //     view[-1,1,28,28] -> conv5x5(1->32)+b -> maxpool2 -> conv5x5(32->64)+b -> maxpool2
 //     -> view[-1,1024] -> fc1(1024->512)+b -> ReLU -> (dropout: identity in eval) -> fc2(512->62)+b
@@ -18,13 +18,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void rec_forward_kernel(RecWeights w, const float* __restrict__ crops,
-                                                          float* __restrict__ logits_out,
-                                                          int32_t* __restrict__ labels, double* __restrict__ probs) {
+constexpr int REC_THREADS = 1024;  // 16 waves per crop: at 256 crops every CU holds one crop
+
+__global__ __launch_bounds__(REC_THREADS) void rec_forward_kernel(RecWeights w, const float* __restrict__ crops,
+                                                                  float* __restrict__ logits_out,
+                                                                  int32_t* __restrict__ labels, double* __restrict__ probs) {
   __shared__ __attribute__((aligned(16))) float img[28 * 28];
   __shared__ __attribute__((aligned(16))) float w1[32 * 25];
   __shared__ __attribute__((aligned(16))) float p1[32][12][12];   // after conv1 + pool
-  __shared__ __attribute__((aligned(16))) float c2[64][8][8];     // conv2 output (pre-pool)
   __shared__ __attribute__((aligned(16))) float feat[1024];       // [c][h][w] flatten (view[-1,1024])
   __shared__ __attribute__((aligned(16))) float hid[512];
   __shared__ float lg[64];
@@ -32,13 +33,21 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecWeights w, const fl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int crop = blockIdx.x;
   const float* src = crops + (size_t)crop * 784;
-  for (int i = tid; i < 784; i += 256) img[i] = src[i];
-  for (int i = tid; i < 800; i += 256) w1[i] = w.c1w[i];
+  if (tid < 784) img[tid] = src[tid];
+  if (tid < 800) w1[tid] = w.c1w[tid];
+  // conv2 weights of this thread's output channel, first input channel: requested now,
+  // consumed after conv1 (their L2 latency hides behind it)
+  const int co2 = tid >> 4;                   // conv2: thread = (output channel, pooled position)
+  const int pp = tid & 15, py = pp >> 2, px = pp & 3;
+  const float* wc = w.c2w + (size_t)co2 * 800;
+  float wcur[25];
+#pragma unroll
+  for (int k = 0; k < 25; ++k) wcur[k] = wc[k];
   __syncthreads();
 
   // conv1 (valid 5x5) fused with 2x2 max pool: 32 x 12 x 12 pooled outputs
-  for (int o = tid; o < 32 * 144; o += 256) {
-    const int co = o / 144, rem = o - co * 144, py = rem / 12, px = rem - py * 12;
+  for (int o = tid; o < 32 * 144; o += REC_THREADS) {
+    const int co = o / 144, rem = o - co * 144, qy = rem / 12, qx = rem - qy * 12;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int kh = 0; kh < 5; ++kh)
@@ -49,70 +58,67 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecWeights w, const fl
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx)
-            acc[dy][dx] = fmaf(img[(2 * py + dy + kh) * 28 + 2 * px + dx + kw], wv, acc[dy][dx]);
+            acc[dy][dx] = fmaf(img[(2 * qy + dy + kh) * 28 + 2 * qx + dx + kw], wv, acc[dy][dx]);
       }
     const float b = w.c1b[co];
-    p1[co][py][px] = fmaxf(fmaxf(acc[0][0] + b, acc[0][1] + b), fmaxf(acc[1][0] + b, acc[1][1] + b));
+    p1[co][qy][qx] = fmaxf(fmaxf(acc[0][0] + b, acc[0][1] + b), fmaxf(acc[1][0] + b, acc[1][1] + b));
   }
   __syncthreads();
 
-  // conv2 (valid 5x5, 32->64): thread = (co, 4x4 block of the 8x8 output)
+  // conv2 (valid 5x5, 32->64) fused with its 2x2 max pool: the thread owns the 2x2 conv outputs
+  // under one pooled pixel; per input channel it reads a 6x6 patch and does 100 FMAs while the
+  // next channel's 25 weights are in flight.
   {
-    const int co = tid >> 2, blk = tid & 3;
-    const int oy0 = (blk >> 1) * 4, ox0 = (blk & 1) * 4;
-    float acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    const float* wc = w.c2w + (size_t)co * 800;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int ci = 0; ci < 32; ++ci) {
+      float wnext[25];
+      const float* wn = wc + (ci + 1 < 32 ? ci + 1 : ci) * 25;
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh) {
-        float wv[5];
+      for (int k = 0; k < 25; ++k) wnext[k] = wn[k];
+      float patch[6][6];
 #pragma unroll
-        for (int kw = 0; kw < 5; ++kw) wv[kw] = wc[ci * 25 + kh * 5 + kw];
+      for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          float row[8];
+        for (int b = 0; b < 6; ++b) patch[a][b] = p1[ci][2 * py + a][2 * px + b];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) row[k] = p1[ci][oy0 + a + kh][ox0 + k];
+      for (int kh = 0; kh < 5; ++kh)
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+        for (int kw = 0; kw < 5; ++kw) {
+          const float wv = wcur[kh * 5 + kw];
 #pragma unroll
-            for (int kw = 0; kw < 5; ++kw) acc[a][b] = fmaf(row[b + kw], wv[kw], acc[a][b]);
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = fmaf(patch[dy + kh][dx + kw], wv, acc[dy][dx]);
         }
-      }
+#pragma unroll
+      for (int k = 0; k < 25; ++k) wcur[k] = wnext[k];
     }
-    const float bb = w.c2b[co];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) c2[co][oy0 + a][ox0 + b] = acc[a][b] + bb;
-  }
-  __syncthreads();
-  for (int o = tid; o < 1024; o += 256) {
-    const int co = o >> 4, py = (o >> 2) & 3, px = o & 3;
-    feat[o] = fmaxf(fmaxf(c2[co][2 * py][2 * px], c2[co][2 * py][2 * px + 1]),
-                    fmaxf(c2[co][2 * py + 1][2 * px], c2[co][2 * py + 1][2 * px + 1]));
+    const float bb = w.c2b[co2];
+    feat[co2 * 16 + pp] = fmaxf(fmaxf(acc[0][0] + bb, acc[0][1] + bb), fmaxf(acc[1][0] + bb, acc[1][1] + bb));
   }
   __syncthreads();
 
-  // fc1 + ReLU: one wave per output, K split over the lanes (coalesced weight rows)
-  for (int o = wave; o < 512; o += 4) {
-    const float* wr = w.f1w + (size_t)o * 1024;
-    float s = 0.f;
+  // fc1 + ReLU: one wave per output row (coalesced 4 KB weight rows), four rows in flight
+  f32x4 fv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(wr + k * 256 + lane * 4);
-      const f32x4 f = *reinterpret_cast<const f32x4*>(feat + k * 256 + lane * 4);
-      s += a[0] * f[0] + a[1] * f[1] + a[2] * f[2] + a[3] * f[3];
+  for (int k = 0; k < 4; ++k) fv[k] = *reinterpret_cast<const f32x4*>(feat + k * 256 + lane * 4);
+  for (int o0 = wave * 4; o0 < 512; o0 += 64) {
+    f32x4 a[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[u][k] = *reinterpret_cast<const f32x4*>(w.f1w + (size_t)(o0 + u) * 1024 + k * 256 + lane * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += a[u][k][0] * fv[k][0] + a[u][k][1] * fv[k][1] + a[u][k][2] * fv[k][2] + a[u][k][3] * fv[k][3];
+      s = wave_sum(s);
+      if (lane == 0) hid[o0 + u] = fmaxf(s + w.f1b[o0 + u], 0.f);
     }
-    s = wave_sum(s);
-    if (lane == 0) hid[o] = fmaxf(s + w.f1b[o], 0.f);
   }
   __syncthreads();
-  for (int o = wave; o < 62; o += 4) {
+  for (int o = wave; o < 62; o += 16) {
     const float* wr = w.f2w + (size_t)o * 512;
     float s = 0.f;
 #pragma unroll
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecWeights w, const fl
 void launch_rec_forward(const RecWeights& w, const float* crops, int n, float* logits, int32_t* labels,
                         double* probs, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(rec_forward_kernel, dim3(n), dim3(256), 0, s, w, crops, logits, labels, probs);
+  hipLaunchKernelGGL(rec_forward_kernel, dim3(n), dim3(REC_THREADS), 0, s, w, crops, logits, labels, probs);
   OCR_HIP(hipGetLastError());
 }
 
