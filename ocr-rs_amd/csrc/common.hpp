@@ -75,6 +75,9 @@ void launch_stem(const float* x, const float* w49x64, const float* scale, const 
 // tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);
+// fused head: convT1 + bias + BN + ReLU + convT2 + bias + sigmoid (+ binarize), tail_fused.hip
+void launch_tail_fused(const float* y, const float* wt1, const float* s4, const float* b4, const float* w2t, float bias2,
+                       float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s);
 void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n, hipStream_t s);
 
 // recognition net, fused

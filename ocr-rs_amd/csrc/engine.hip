@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace ocr {
@@ -141,7 +142,13 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     for (int ci = 0; ci < 64; ++ci)
       for (int k = 0; k < 4; ++k) t[k * 64 + ci] = w[ci * 4 + k];
     tr2_w_ = arena_.upload(t);
+    std::vector<float> tt(64 * 4);
+    for (int ci = 0; ci < 64; ++ci)
+      for (int k = 0; k < 4; ++k) tt[ci * 4 + k] = w[ci * 4 + k];
+    tr2_wt_ = arena_.upload(tt);
     tr2_bias_ = wb.get("bin_conv_tr2.bias", {1}).data[0];
+    const char* e = getenv("OCR_TAIL_UNFUSED");
+    fused_tail_ = !(e && e[0] == '1');
   }
 }
 
@@ -368,17 +375,26 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     c4.cat4 = true;
     conv("bin_conv1", bin1_, p_[3], h4, w4, 1, b1_, true, c4);
   }
-  // bin_conv_tr1 + bias + bin_bn2 + relu, model.rs:146-148
-  {
-    Extra sh;
-    sh.store = STORE_SHUFFLE2;
-    conv("bin_conv_tr1", tr1_, b1_, h4, w4, 1, tr1buf_, true, sh);
+  if (fused_tail_) {
+    // bin_conv_tr1 + bias + bin_bn2 + relu + bin_conv_tr2 + bias + sigmoid (+ binarize) in one kernel:
+    // the 64-channel H/2 x W/2 intermediate never reaches HBM.  model.rs:146-150
+    rec.begin();
+    launch_tail_fused(b1_, tr1_.w, tr1_.scale, tr1_.bias, tr2_wt_, tr2_bias_, prob, bitmap, thresh, n, h4, w4, stream_);
+    rec.end("tail_convt1_bn_relu_convt2_sigmoid", 2.0 * n * h4 * w4 * 64.0 * 256 + 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
+            (double)n * h4 * w4 * 64 * 4 + (double)n * h * w * 4);
+  } else {
+    // bin_conv_tr1 + bias + bin_bn2 + relu, model.rs:146-148
+    {
+      Extra sh;
+      sh.store = STORE_SHUFFLE2;
+      conv("bin_conv_tr1", tr1_, b1_, h4, w4, 1, tr1buf_, true, sh);
+    }
+    // bin_conv_tr2 + bias + sigmoid (+ binarize), model.rs:149-150
+    rec.begin();
+    launch_convt2_sigmoid(tr1buf_, tr2_w_, tr2_bias_, prob, bitmap, thresh, n, h / 2, w / 2, stream_);
+    rec.end("convt2x2_sigmoid", 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
+            (double)n * (h / 2) * (w / 2) * 64 * 4 + (double)n * h * w * 4);
   }
-  // bin_conv_tr2 + bias + sigmoid (+ binarize), model.rs:149-150
-  rec.begin();
-  launch_convt2_sigmoid(tr1buf_, tr2_w_, tr2_bias_, prob, bitmap, thresh, n, h / 2, w / 2, stream_);
-  rec.end("convt2x2_sigmoid", 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
-          (double)n * (h / 2) * (w / 2) * 64 * 4 + (double)n * h * w * 4);
   rec.finish();
 }
 

@@ -67,6 +67,8 @@ class Detector {
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;
+  float* tr2_wt_ = nullptr;   // [64 co][4 u] for the fused head
+  bool fused_tail_ = true;    // OCR_TAIL_UNFUSED=1 keeps the two-kernel head (A/B and debugging)
   float tr2_bias_ = 0.f;
 
   int ws_n_ = 0, ws_h_ = 0, ws_w_ = 0;

@@ -1,0 +1,203 @@
+// Fused probability head: bin_conv_tr1 (convT 2x2 s2, 64->64, +bias) + bin_bn2 + ReLU
+//                       + bin_conv_tr2 (convT 2x2 s2, 64->1, +bias) + sigmoid (+ binarize)
+//   /root/reference/src/text_detection/model.rs:146-150, metrics.rs:129-131
+// Both transposed convs have kernel = stride = 2, so one input pixel (i,j) of bin_conv1's output
+// owns a 4x4 block of the probability map: no halo, no overlap.  Unfused, the 64-channel
+// intermediate at H/2 x W/2 (839 MB per 32 frames) is written and read back; here it lives in
+// the accumulators.
+//
+// Per workgroup: 128 pixels.  For each of the 4 taps t=(a,b) of bin_conv_tr1 a wave computes the
+// TRANSPOSED product  Z_t^T[co][px] = W_t[co][ci] * Y^T[ci][px]  with v_mfma_f32_32x32x2_f32
+// (weights as the row operand, pixels as the column operand): channels land on registers, pixels
+// on lanes.  The second transposed conv contracts over channels, i.e. over REGISTERS of a lane:
+// 4 x 32 FMAs per lane and tap plus one cross-half add - no LDS round trip, no transpose.
+// Operands move by LDS-DMA exactly as in conv_igemm.hip (same swizzled 128-byte rows).
+#include "common.hpp"
+
+namespace ocr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct TailArgs {
+  const float* y;      // bin_conv1 output, NHWC [M][64]
+  const float* wt1;    // [4 taps][64 co][64 ci]
+  const float* s4;     // [256] folded bin_bn2 scale, index t*64+co
+  const float* b4;     // [256] folded bias (conv bias and BN)
+  const float* w2t;    // [64 co][4 u] bin_conv_tr2 weights, u = c'*2+d'
+  float* prob;
+  uint8_t* bitmap;
+  unsigned y_bytes;
+  float bias2, thresh;
+  int M, h4, w4;       // pixels, grid of y
+  unsigned mg_hw, sh_hw, mg_w, sh_w;
+};
+
+__device__ __forceinline__ int fdiv(int x, unsigned magic, unsigned shift) {
+  if (shift == 0xFFFFFFFFu) return x;
+  const unsigned t = __umulhi((unsigned)x, magic);
+  return (int)((t + (((unsigned)x - t) >> 1)) >> shift);
+}
+
+constexpr int TP = 128;                  // pixels per workgroup
+[[maybe_unused]] constexpr int A_FLOATS = 2 * TP * 32;    // two 32-channel chunks of the pixel rows
+[[maybe_unused]] constexpr int W_FLOATS = 2 * 64 * 32;    // one tap: two chunks of 64 output-channel rows
+
+__global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) float lds[A_FLOATS + 2 * W_FLOATS];
+  __shared__ __attribute__((aligned(16))) float tab_s[256], tab_b[256], tab_w2[256];
+  float* As = lds;
+  float* Ws = lds + A_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * TP;
+  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.y), 0, p.y_bytes, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt1), 0, 4 * 64 * 64 * 4, 0x00020000);
+  tab_s[tid] = p.s4[tid];
+  tab_b[tid] = p.b4[tid];
+  tab_w2[tid] = p.w2t[tid];
+
+  // DMA: lane fills slot q of rows r + 32 i with global chunk q ^ f(r) (see conv_igemm.hip)
+  const int r = tid >> 3, q = tid & 7;
+  const int gq = q ^ ((r >> 1) & 7);
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int i = 0; i < TP / 32; ++i) {
+      const int m = m0 + r + 32 * i;
+      const unsigned off = m < p.M ? (unsigned)((m * 64 + kc * 32 + gq * 4) * 4) : 0x80000000u;  // rows past M read as zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lds_void*)(As + kc * TP * 32 + (32 * i + 8 * wave) * 32), 16, off, 0, 0, 0);
+    }
+  auto issue_w = [&](int t, int buf) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(Ws + buf * W_FLOATS + kc * 64 * 32 + (32 * i + 8 * wave) * 32), 16,
+                                                 (unsigned)(((r + 32 * i) * 64 + kc * 32 + gq * 4) * 4), t * 64 * 64 * 4, 0, 0);
+  };
+  issue_w(0, 0);
+
+  const int frow = lane & 31, half = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  int xoff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xoff[g] = ((2 * g + half) ^ fsw) * 4;
+
+  float o[4][4];  // [tap][u] of this lane's pixel
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t + 1 < 4) issue_w(t + 1, (t + 1) & 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+    const float* wb = Ws + (t & 1) * W_FLOATS;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 px = *reinterpret_cast<const f32x4*>(As + kc * TP * 32 + (32 * wave + frow) * 32 + xoff[g]);
+        f32x4 wf[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wf[ct] = *reinterpret_cast<const f32x4*>(wb + kc * 64 * 32 + (32 * ct + frow) * 32 + xoff[g]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][e], px[e], acc[ct], 0, 0, 0);  // rows = co, cols = pixels
+      }
+    // acc[ct][e] = Z_t^T[co][pixel = lane&31] with co = 32 ct + (e&3) + 8 (e>>2) + 4 half
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const float z = fmaxf(acc[ct][e] * tab_s[t * 64 + co] + tab_b[t * 64 + co], 0.f);  // + bias, bin_bn2, ReLU
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(&tab_w2[co * 4]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2[u], part[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s = part[u] + __shfl_xor(part[u], 32, 64) + p.bias2;  // the other half holds the other 32 channels
+      o[t][u] = 1.0f / (1.0f + expf(-s));
+    }
+    if (t + 1 < 4) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  // pixel (n,i,j) owns prob[n][4i .. 4i+3][4j .. 4j+3]: row 2a+c', column 2b+d' = o[a*2+b][c'*2+d'].
+  // Lanes 0-31 write rows 0,1, lanes 32-63 rows 2,3 (both halves hold the sums): float4 per row,
+  // 512 contiguous bytes per 32 lanes.
+  const int m = m0 + 32 * wave + frow;
+  if (m < p.M) {
+    const int hw = p.h4 * p.w4;
+    const int n = fdiv(m, p.mg_hw, p.sh_hw);
+    const int rem = m - n * hw;
+    const int i = fdiv(rem, p.mg_w, p.sh_w);
+    const int j = rem - i * p.w4;
+    const int W = 4 * p.w4;
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const int rr = 2 * half + rs;  // output row inside the 4x4 block: a = rr>>1 = half, c' = rs
+      f32x4 v;
+      v[0] = half ? o[2][2 * rs] : o[0][2 * rs];
+      v[1] = half ? o[2][2 * rs + 1] : o[0][2 * rs + 1];
+      v[2] = half ? o[3][2 * rs] : o[1][2 * rs];
+      v[3] = half ? o[3][2 * rs + 1] : o[1][2 * rs + 1];
+      const size_t off = ((size_t)n * (4 * p.h4) + 4 * i + rr) * W + 4 * j;
+      *reinterpret_cast<f32x4*>(p.prob + off) = v;
+      if (p.bitmap) {
+        const unsigned bits = (v[0] > p.thresh ? 1u : 0u) | (v[1] > p.thresh ? 0x100u : 0u) | (v[2] > p.thresh ? 0x10000u : 0u) |
+                              (v[3] > p.thresh ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(p.bitmap + off) = bits;
+      }
+    }
+  }
+#endif
+}
+
+void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;
+  *magic = L == 0 ? 0u : (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+  *shift = L == 0 ? 0xFFFFFFFFu : L - 1;
+}
+
+}  // namespace
+
+void launch_tail_fused(const float* y, const float* wt1, const float* s4, const float* b4, const float* w2t, float bias2,
+                       float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s) {
+  const long long M = (long long)N * h4 * w4;
+  if (M * 64 * 4 >= (1ll << 31)) fail(OCR_ERR_INVALID, "tail: input exceeds 2^31 bytes; split the batch");
+  if (w4 < 1 || h4 < 1) fail(OCR_ERR_INVALID, "tail: bad grid");
+  TailArgs a{};
+  a.y = y;
+  a.wt1 = wt1;
+  a.s4 = s4;
+  a.b4 = b4;
+  a.w2t = w2t;
+  a.prob = prob;
+  a.bitmap = bitmap;
+  a.y_bytes = (unsigned)(M * 64 * 4);
+  a.bias2 = bias2;
+  a.thresh = thresh;
+  a.M = (int)M;
+  a.h4 = h4;
+  a.w4 = w4;
+  make_magic((unsigned)(h4 * w4), &a.mg_hw, &a.sh_hw);
+  make_magic((unsigned)w4, &a.mg_w, &a.sh_w);
+  hipLaunchKernelGGL(tail_fused_kernel, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
+  OCR_HIP(hipGetLastError());
+}
+
+}  // namespace ocr

@@ -94,6 +94,21 @@ def test_det_other_weights_seed():
     d.close()
 
 
+def test_det_two_kernel_head_matches_fused_head(det_w, monkeypatch):
+    """OCR_TAIL_UNFUSED=1 keeps bin_conv_tr1 / bin_conv_tr2 as two launches; both heads must agree."""
+    x = W.synth_image_batch(12, 2, 64, 96)
+    monkeypatch.setenv("OCR_TAIL_UNFUSED", "1")
+    d2 = capi.Detector(W.pack_blob(det_w), 0)
+    monkeypatch.delenv("OCR_TAIL_UNFUSED")
+    d1 = capi.Detector(W.pack_blob(det_w), 0)
+    a, b = d1.forward_host(x), d2.forward_host(x)
+    ref = T.det_forward(det_w, x)
+    assert np.abs(a - ref).max() < TOL and np.abs(b - ref).max() < TOL
+    assert np.abs(a - b).max() < 1e-5
+    d1.close()
+    d2.close()
+
+
 def test_det_preprocessed_img55_plumbing(det, det_w, golden_dir):
     """BASELINE config 0: the reference's own 800x800 fixture through detect -> polygons."""
     img = np.array(Image.open(os.path.join(golden_dir, "preprocessed_img55.png")).convert("L"))
