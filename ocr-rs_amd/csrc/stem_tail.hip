@@ -12,19 +12,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TPH = 4, TPW = 8;                 // pooled output tile per workgroup
 constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1;  // conv rows/cols feeding it (3x3 s2 window): 9 x 17
-constexpr int CG = (CC + 3) / 4;                // conv columns are produced 4 at a time: 5 groups (20 >= 17)
+constexpr int NPIX = CR * CC;                   // 153 conv pixels per workgroup
+constexpr int MTILES = (NPIX + 31) / 32;        // as 5 MFMA row tiles of 32 pixels
 constexpr int IR = 2 * (CR - 1) + 7;            // input rows feeding the conv tile (7x7 s2): 23
-constexpr int ICP = 8 * CG + 8;                 // padded input row: group g reads floats [8g, 8g+16)
+constexpr int ICP = 2 * (CC - 1) + 7 + 1;       // input columns (39), padded to 40
+constexpr int KSTEPS = 25;                      // K = 49 taps padded to 50 = 25 MFMA steps of 2
 
-// grid (Wp/TPW, Hp/TPH, N), 256 threads: lane = output channel; a wave walks (conv row, column
-// group) items.  Per item and kernel row the 13 input values of 4 neighbouring conv pixels are
-// fetched with 4 broadcast ds_read_b128 and reused for 28 FMAs.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// conv1 as a GEMM on the matrix cores: rows = conv pixels of the tile, columns = 64 channels,
+// K = 49 taps.  The A operand is read straight from the LDS input tile - lane l supplies pixel
+// (l & 31) and tap 2s + (l >> 5), one ds_read_b32 per MFMA whose address is a per-lane base plus
+// a compile-time tap offset - and the 49x64 weights sit in registers (50 per lane).
+// grid (Wp/TPW, Hp/TPH, N), 256 threads; the 10 (pixel tile, channel half) units are dealt to the
+// 4 waves round-robin.  BN + ReLU on the accumulators, conv tile to LDS, then the 3x3 s2 max pool.
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
                                                    float* __restrict__ out, int H, int W) {
-  __shared__ __attribute__((aligned(16))) float in_s[IR][ICP];
-  __shared__ float conv_s[CR * CC][64];
-  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float in_s[IR * ICP];
+  __shared__ float conv_s[NPIX][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.z;
   const int ph0 = blockIdx.y * TPH, pw0 = blockIdx.x * TPW;
   const int Hc = H >> 1, Wc = W >> 1, Hp = H >> 2, Wp = W >> 2;
@@ -34,40 +42,50 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   for (int i = tid; i < IR * ICP; i += 256) {
     const int rr = i / ICP, cc = i - rr * ICP;
     const int ih = ir0 + rr, iw = ic0 + cc;
-    float v = 0.f;  // zero padding of conv1 (and the unused tail of the padded row)
+    float v = 0.f;  // zero padding of conv1 (and the pad column)
     if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[(size_t)ih * W + iw];
-    in_s[rr][cc] = v;
+    in_s[i] = v;
   }
-  const int c = tid & 63, wv = tid >> 6;
-  float wreg[49];
+  const int half = lane >> 5, l31 = lane & 31;
+  // B operand: weight of tap 2s + half for channel 32 ct + (lane & 31); the padded tap 49 is zero
+  float wreg[2][KSTEPS];
 #pragma unroll
-  for (int t = 0; t < 49; ++t) wreg[t] = w49x64[t * 64 + c];
-  const float sc = scale[c], bi = bias[c];
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int k = 2 * s + half;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) wreg[ct][s] = k < 49 ? w49x64[k * 64 + 32 * ct + l31] : 0.f;
+  }
   __syncthreads();
-  for (int item = wv; item < CR * CG; item += 4) {
-    const int pr = item / CG, g = item - pr * CG;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (int unit = wv; unit < 2 * MTILES; unit += 4) {
+    const int mt = unit >> 1, ct = unit & 1;
+    const int pix = min(32 * mt + l31, NPIX - 1);  // rows past the tile repeat its last pixel (never stored)
+    const int pr = pix / CC, pc = pix - pr * CC;
+    const int base = 2 * pr * ICP + 2 * pc;        // top-left input sample of this pixel's 7x7 window
+    f32x16 acc;
 #pragma unroll
-    for (int kh = 0; kh < 7; ++kh) {
-      float in[16];
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4*>(&in[4 * q]) = *reinterpret_cast<const f32x4*>(&in_s[2 * pr + kh][8 * g + 4 * q]);
-#pragma unroll
-      for (int kw = 0; kw < 7; ++kw)
-#pragma unroll
-        for (int px = 0; px < 4; ++px) acc[px] = fmaf(in[2 * px + kw], wreg[kh * 7 + kw], acc[px]);
+    for (int s = 0; s < KSTEPS; ++s) {
+      // tap of this lane: k = 2s + half; (kh, kw) = (k / 7, k % 7); tap 49 re-reads tap 48 (weight 0)
+      const int k0 = 2 * s, k1 = 2 * s + 1 < 49 ? 2 * s + 1 : 48;
+      const int off0 = (k0 / 7) * ICP + k0 % 7, off1 = (k1 / 7) * ICP + k1 % 7;
+      const float a = in_s[base + (half ? off1 : off0)];
+      acc = ct ? __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][s], acc, 0, 0, 0)
+               : __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][s], acc, 0, 0, 0);
     }
-    const int cr = cr0 + pr;
+    // C/D map: column (channel) = lane & 31, row (pixel) = (e&3) + 8 (e>>2) + 4 (lane>>5)
+    const int ch = 32 * ct + l31;
+    const float sc = scale[ch], bi = bias[ch];
 #pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      const int pc = 4 * g + px;
-      if (pc < CC) {
-        const int cc = cc0 + pc;
+    for (int e = 0; e < 16; ++e) {
+      const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (p < NPIX) {
+        const int qr = p / CC, qc = p - qr * CC;
         // conv positions outside the conv grid are max-pool padding: they never win against the
         // always-valid window centre because ReLU output is >= 0.
-        const bool valid = (unsigned)cr < (unsigned)Hc && (unsigned)cc < (unsigned)Wc;
-        conv_s[pr * CC + pc][c] = valid ? fmaxf(acc[px] * sc + bi, 0.f) : 0.f;
+        const bool valid = (unsigned)(cr0 + qr) < (unsigned)Hc && (unsigned)(cc0 + qc) < (unsigned)Wc;
+        conv_s[p][ch] = valid ? fmaxf(acc[e] * sc + bi, 0.f) : 0.f;
       }
     }
   }
