@@ -1,0 +1,100 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties
+(the oracle is only affordable on a few frames at these sizes)."""
+import numpy as np
+import pytest
+
+import ocr_rs_amd  # noqa: F401
+from ocr_rs_amd import capi
+from ocr_rs_amd import weights as W
+from oracle import postproc_oracle as O
+from oracle import torch_ref as T
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def det_w():
+    return W.make_det_weights(0)
+
+
+@pytest.fixture(scope="module")
+def det(det_w):
+    d = capi.Detector(W.pack_blob(det_w), 0)
+    yield d
+    d.close()
+
+
+def test_config1_batch32_640_spot_frames_and_batch_independence(det, det_w):
+    """configs[1]: 32 x 1x640x640.  (a) three frames against the oracle; (b) a frame's map does not
+    depend on what else is in the batch: every output element accumulates K in the same order whatever
+    tile shape the batch size selects, so single-frame and batched results are bit-identical."""
+    x = W.synth_image_batch(1, 32, 640, 640)
+    prob = det.forward_host(x)
+    assert prob.shape == (32, 1, 640, 640) and np.isfinite(prob).all()
+    for i in (0, 13, 31):
+        ref = T.det_forward(det_w, x[i:i + 1])
+        assert np.abs(prob[i:i + 1] - ref).max() < TOL
+    single = det.forward_host(x[7:8])
+    assert np.array_equal(single[0], prob[7])
+    pair = det.forward_host(x[[20, 3]])
+    assert np.array_equal(pair[0], prob[20]) and np.array_equal(pair[1], prob[3])
+    # permutation equivariance over the batch axis
+    perm = np.random.RandomState(0).permutation(32)
+    assert np.array_equal(det.forward_host(x[perm]), prob[perm])
+
+
+def test_batch_larger_than_addressing_chunk(det, det_w):
+    """640x640 frames: one chunk holds at most 81 frames (2^31-byte tensors); 84 frames run as 81 + 3."""
+    x = W.synth_image_batch(5, 84, 640, 640)
+    prob = det.forward_host(x)
+    for i in (0, 80, 81, 83):
+        assert np.array_equal(det.forward_host(x[i:i + 1])[0], prob[i])
+    assert np.abs(prob[83:84] - T.det_forward(det_w, x[83:84])).max() < TOL
+
+
+def test_config0_800x800_default_dimensions(det, det_w):
+    """The reference's default frame (text_detection/mod.rs:20-21), batch 2 (its chunk size)."""
+    x = W.synth_image_batch(9, 2, 800, 800)
+    prob = det.forward_host(x)
+    assert np.abs(prob - T.det_forward(det_w, x)).max() < TOL
+
+
+def test_postprocess_batch32_idempotent_and_order_free(det):
+    """32 text-like 640x640 maps: results of a frame do not depend on its position in the batch, running
+    twice gives identical blocks, and a sample of frames matches the oracle exactly."""
+    import bench
+    maps = bench.text_like_maps(32, 640, seed=3)
+    adj = np.tile(np.array([[1.25, 0.8]]), (32, 1))
+    p = capi.default_params(skip_degenerate=True)
+    polys, scores = det.postprocess(maps, 32, 640, 640, adj, capi.MEM_HOST, p)
+    polys2, scores2 = det.postprocess(maps, 32, 640, 640, adj, capi.MEM_HOST, p)
+    assert polys == polys2 and scores == scores2
+    perm = np.random.RandomState(1).permutation(32)
+    pp, ps = det.postprocess(np.ascontiguousarray(maps[perm]), 32, 640, 640, adj, capi.MEM_HOST, p)
+    assert pp == [polys[i] for i in perm] and ps == [scores[i] for i in perm]
+    assert sum(len(q) for q in polys) >= 64
+    for i in (0, 5, 18):
+        op, os_ = O.get_boxes_and_box_scores(maps[i:i + 1], adj[i:i + 1], skip_degenerate=True)
+        assert polys[i] == op[0]
+        assert np.allclose(scores[i], os_[0], rtol=0, atol=1e-12)
+
+
+def test_config2_recognition_4096_crops():
+    rw = W.make_rec_weights(0)
+    rec = capi.Recognizer(W.pack_blob(rw), 0)
+    crops = W.synth_crops(6, 4096)
+    logits = rec.forward_host(crops)
+    labels, probs = rec.classify_host(crops)
+    sub = np.arange(0, 4096, 37)
+    ref = T.rec_forward(rw, crops[sub])
+    assert np.abs(logits[sub] - ref).max() < TOL
+    rl, rp = T.rec_classify(ref)
+    srt = np.sort(ref, axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 1e-3
+    assert (labels[sub][decided] == rl[decided]).all()
+    # size-independent: a crop's result does not depend on the batch around it
+    l2, p2 = rec.classify_host(crops[100:101])
+    assert l2[0] == labels[100] and p2[0] == probs[100]
+    assert np.array_equal(np.argmax(logits, axis=1).astype(np.int32), labels)
+    rec.close()
