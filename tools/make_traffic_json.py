@@ -18,7 +18,8 @@ def pretty(name: str) -> str:
     # "void ocr::igemm::conv_igemm_f32<128, 64, 3, 1, 0, 0>(...)" -> bench.py's kernel label
     if "conv_igemm_f32<" not in name:
         return "stem_conv7x7_bn_relu_maxpool" if "stem_kernel" in name else \
-               "convt2x2_sigmoid" if "convt2_sigmoid" in name else name.split("(")[0]
+               "convt2x2_sigmoid" if "convt2_sigmoid" in name else \
+               "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
     tile = f"{a[0]}x{a[1]}"
     return f"conv_igemm_f32<{tile},k{a[2]},s{a[3]},{'CAT4' if a[4] == '2' else 'PLAIN'}{',SHUFFLE2' if a[5] == '1' else ''}>"
@@ -35,7 +36,7 @@ def load(d, counter):
 
 fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
-half = len(fetch) - 31                     # two forwards per run: keep the last (warm) one = 31 launches
+half = len(fetch) // 2                     # two identical forwards per run: keep the second (warm) one
 agg = collections.OrderedDict()
 for (nf, f), (nw, w) in zip(fetch[half:], write[half:]):
     assert nf == nw, (nf, nw)
