@@ -80,6 +80,18 @@ int ocr_det_forward_profile(ocr_det_t* det, const float* x_dev, int n, int h, in
                             double* bytes, int* n_entries);
 
 /* ---------------------------------------------------------------------------
+ * Pre-processing (the step in front of the detector).  Replaces the arithmetic of
+ *   preprocess_image(file, (W, H)) -> (GrayImage, adjust_x, adjust_y)   image_ops.rs:188-220
+ * after decoding: rgba is h x w x 4 u8.  Aspect-preserving Triangle resize (image 0.23.11
+ * sampling: vertical then horizontal pass, u8-truncating), to_luma, zero padding to
+ * target_w x target_h.  gray (u8) and/or gray_f32 (the raw 0..255 values as f32, i.e. the
+ * N=1 input frame of ocr_det_forward) receive target_h x target_w values; adj_xy[2] =
+ * resized / original (x, y).  `det` supplies the GPU and stream.  Blocking.
+ * ------------------------------------------------------------------------- */
+int ocr_preprocess_image(ocr_det_t* det, const uint8_t* rgba, int w, int h, int target_w, int target_h,
+                         uint8_t* gray, float* gray_f32, double* adj_xy, int mem_kind);
+
+/* ---------------------------------------------------------------------------
  * Detection post-processing.  Replaces
  *   get_boxes_and_box_scores(pred, adjust_values) -> Result<PolygonScores>
  *                                                  text_detection/metrics.rs:37-56

@@ -22,7 +22,7 @@ EXPORTS = [
     "ocr_last_error", "ocr_version", "ocr_device_count",
     "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
-    "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
+    "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify", "ocr_rec_alphabet",
 ]
@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         L.ocr_det_forward_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                               C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ocr_preprocess_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.ocr_postproc_default_params.argtypes = [C.POINTER(PostprocParams)]
         L.ocr_postproc_default_params.restype = None
         L.ocr_det_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -189,6 +191,17 @@ class Detector:
         out = np.empty(n.value, np.float32)
         check(lib().ocr_test_det_stage(self._h, stage_id, _ptr(out), n.value, C.byref(n)))
         return np.ascontiguousarray(out.reshape(shape_nhwc).transpose(0, 3, 1, 2))
+
+    def preprocess_image(self, rgba: np.ndarray, target_w: int, target_h: int, want_f32: bool = False):
+        """image_ops::preprocess_image after decoding: rgba h x w x 4 u8 -> (gray HxW u8[, f32 frame], adj_x, adj_y)."""
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        h, w = rgba.shape[:2]
+        gray = np.empty((target_h, target_w), np.uint8)
+        f32 = np.empty((1, 1, target_h, target_w), np.float32) if want_f32 else None
+        adj = (C.c_double * 2)()
+        check(lib().ocr_preprocess_image(self._h, _ptr(rgba), w, h, target_w, target_h, _ptr(gray),
+                                         _ptr(f32) if want_f32 else None, adj, MEM_HOST))
+        return (gray, f32, adj[0], adj[1]) if want_f32 else (gray, adj[0], adj[1])
 
     def debug_conv_bench(self, n, h, w, cin, cout, ks=3, stride=1, src_mode=0, iters=5) -> float:
         """Test hook: average milliseconds of one conv_igemm launch of this shape."""

@@ -239,6 +239,37 @@ int ocr_det_forward_profile(ocr_det_t* det, const float* x, int n, int h, int w,
   });
 }
 
+int ocr_preprocess_image(ocr_det_t* det, const uint8_t* rgba, int w, int h, int target_w, int target_h, uint8_t* gray,
+                         float* gray_f32, double* adj_xy, int mem_kind) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !rgba || (!gray && !gray_f32)) fail(OCR_ERR_INVALID, "preprocess_image: null argument");
+    if (w < 1 || h < 1 || target_w < 1 || target_h < 1) fail(OCR_ERR_INVALID, "preprocess_image: bad dimensions");
+    if (mem_kind != OCR_MEM_HOST && mem_kind != OCR_MEM_DEVICE) fail(OCR_ERR_INVALID, "mem_kind %d", mem_kind);
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const size_t px_in = (size_t)w * h * 4, px_out = (size_t)target_w * target_h;
+    const size_t need = preprocess_scratch_bytes(w, h, target_w, target_h);
+    if (mem_kind == OCR_MEM_DEVICE) {
+      // gray may be null when only the f32 frame is wanted: stage it in scratch
+      char* sc = static_cast<char*>(det->impl.scratch(1, need + align256(px_out)));
+      uint8_t* g = gray ? gray : reinterpret_cast<uint8_t*>(sc + align256(need));
+      launch_preprocess(rgba, w, h, target_w, target_h, g, gray_f32, sc, need, adj_xy, s);
+      OCR_HIP(hipStreamSynchronize(s));
+    } else {
+      const size_t o_in = align256(need), o_g = o_in + align256(px_in), o_f = o_g + align256(px_out);
+      char* sc = static_cast<char*>(det->impl.scratch(1, o_f + align256(px_out * 4)));
+      OCR_HIP(hipMemcpyAsync(sc + o_in, rgba, px_in, hipMemcpyHostToDevice, s));
+      launch_preprocess(reinterpret_cast<const unsigned char*>(sc + o_in), w, h, target_w, target_h,
+                        reinterpret_cast<unsigned char*>(sc + o_g), gray_f32 ? reinterpret_cast<float*>(sc + o_f) : nullptr, sc, need,
+                        adj_xy, s);
+      if (gray) OCR_HIP(hipMemcpyAsync(gray, sc + o_g, px_out, hipMemcpyDeviceToHost, s));
+      if (gray_f32) OCR_HIP(hipMemcpyAsync(gray_f32, sc + o_f, px_out * 4, hipMemcpyDeviceToHost, s));
+      OCR_HIP(hipStreamSynchronize(s));
+    }
+  });
+}
+
 void ocr_postproc_default_params(ocr_postproc_params_t* p) {
   if (!p) return;
   p->thresh = 0.6;        // metrics.rs:38

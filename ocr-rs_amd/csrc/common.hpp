@@ -80,6 +80,12 @@ void launch_tail_fused(const float* y, const float* wt1, const float* s4, const 
                        float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s);
 void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n, hipStream_t s);
 
+// preprocess_image (image_ops.rs:188-220): Triangle resize + luma + zero pad, preprocess.hip
+void resize_dimensions(int width, int height, int nwidth, int nheight, int* ow, int* oh);
+size_t preprocess_scratch_bytes(int w, int h, int W, int H);
+void launch_preprocess(const unsigned char* rgba_dev, int w, int h, int W, int H, unsigned char* gray_dev, float* gray_f32_dev,
+                       void* scratch, size_t scratch_bytes, double* adj_xy, hipStream_t s);
+
 // recognition net, fused
 struct RecWeights {
   const float *c1w, *c1b, *c2w, *c2b, *f1w, *f1b, *f2w, *f2b;

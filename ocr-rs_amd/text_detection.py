@@ -64,6 +64,12 @@ def resnet18(weights_blob: bytes, device: int = 0) -> FuncT:
     return FuncT(weights_blob, device)
 
 
+def preprocess_image(net: FuncT, rgba: np.ndarray, target_dim=(DEFAULT_WIDTH, DEFAULT_HEIGHT)):
+    """image_ops::preprocess_image (image_ops.rs:188-220) on an already decoded RGBA image:
+    returns (GrayImage as H x W u8, adjust_x, adjust_y)."""
+    return net.handle.preprocess_image(rgba, target_dim[0], target_dim[1])
+
+
 def get_boxes_and_box_scores(net: FuncT, pred, adjust_values, skip_degenerate: bool = False) -> PolygonScores:
     """metrics.rs:37-56.  `net` supplies the GPU/stream the HIP post-processing kernels run on.
     Raises OcrError(code 6) where the reference would abort on `expand_polygon(..).unwrap()`."""
