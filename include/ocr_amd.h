@@ -134,6 +134,16 @@ int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, 
                         ocr_polygons_t** out);
 void ocr_polygons_free(ocr_polygons_t* p);
 
+/* Detect -> recognise link (BUILD-DEFINED: the reference never implemented its "Character
+ * Segmentation" step, README.md:20-26, so there is no reference rule to match).  For every polygon
+ * of `polys` (as returned by ocr_det_postprocess for the same batch) the axis-aligned bounding box,
+ * mapped back to frame coordinates with adj_xy, is resampled bilinearly to 28 x 28 and divided by
+ * 255 (load_image_as_tensor's scaling, image_ops.rs:80-83): crops is n_polygons x 784 f32, ready
+ * for ocr_rec_forward / ocr_rec_classify.  frames: N x 1 x H x W f32 (the detector's input).
+ * frames and crops share mem_kind; polys and adj_xy are host memory.  Rule: oracle/crop_oracle.py. */
+int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, int mem_kind,
+                      const ocr_polygons_t* polys, const double* adj_xy, float* crops);
+
 /* ---------------------------------------------------------------------------
  * Recogniser.  Replaces
  *   let net = Net::new(&weights.root()); weights.load(file)   char_recognition/mod.rs:44-46

@@ -23,6 +23,7 @@ EXPORTS = [
     "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
+    "ocr_extract_crops",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify", "ocr_rec_alphabet",
 ]
@@ -79,6 +80,8 @@ def lib() -> C.CDLL:
                                           C.POINTER(C.POINTER(Polygons))]
         L.ocr_polygons_free.argtypes = [C.POINTER(Polygons)]
         L.ocr_polygons_free.restype = None
+        L.ocr_extract_crops.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Polygons),
+                                        C.POINTER(C.c_double), C.c_void_p]
         L.ocr_rec_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_rec_destroy.argtypes = [C.c_void_p]
         L.ocr_rec_destroy.restype = None
@@ -183,6 +186,26 @@ class Detector:
         cnt = C.c_int(0)
         check(lib().ocr_det_forward_profile(self._h, x_ptr, n, h, w, prob_ptr, cap, names, ms, fl, by, C.byref(cnt)))
         return [(names[i].decode(), float(ms[i]), float(fl[i]), float(by[i])) for i in range(cnt.value)]
+
+    def postprocess_and_crops(self, prob: np.ndarray, frames: np.ndarray, adjust_values: np.ndarray,
+                              params: Optional[PostprocParams] = None):
+        """get_boxes_and_box_scores followed by the detect -> recognise crop step (host arrays):
+        returns (polygons, scores, crops[P x 784])."""
+        prob = np.ascontiguousarray(prob, dtype=np.float32)
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        n, _, h, w = prob.shape
+        adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+        adj_p = adj.ctypes.data_as(C.POINTER(C.c_double))
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_postprocess(self._h, _ptr(prob), n, h, w, MEM_HOST, adj_p,
+                                        C.byref(params) if params is not None else None, C.byref(out)))
+        try:
+            crops = np.zeros((out.contents.n_polygons, 784), np.float32)
+            check(lib().ocr_extract_crops(self._h, _ptr(frames), n, h, w, MEM_HOST, out, adj_p, _ptr(crops)))
+            polys, scores = polygons_to_python(out)
+            return polys, scores, crops
+        finally:
+            lib().ocr_polygons_free(out)
 
     def debug_stage(self, stage_id: int, shape_nhwc) -> np.ndarray:
         """Test hook: NHWC intermediate of the last forward, returned as NCHW."""

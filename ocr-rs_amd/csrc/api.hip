@@ -270,6 +270,52 @@ int ocr_preprocess_image(ocr_det_t* det, const uint8_t* rgba, int w, int h, int 
   });
 }
 
+int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, int mem_kind, const ocr_polygons_t* polys,
+                      const double* adj_xy, float* crops) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !frames || !polys || !adj_xy || (!crops && polys->n_polygons > 0)) fail(OCR_ERR_INVALID, "extract_crops: null argument");
+    if (polys->n_images != n) fail(OCR_ERR_INVALID, "extract_crops: polygon block holds %d images, frames %d", polys->n_images, n);
+    if (mem_kind != OCR_MEM_HOST && mem_kind != OCR_MEM_DEVICE) fail(OCR_ERR_INVALID, "mem_kind %d", mem_kind);
+    const int np = polys->n_polygons;
+    if (np == 0) return;
+    std::vector<CropBox> boxes;
+    boxes.reserve(np);
+    for (int b = 0; b < n; ++b) {
+      const double ax = adj_xy[2 * b], ay = adj_xy[2 * b + 1];
+      for (int k = polys->img_offsets[b]; k < polys->img_offsets[b + 1]; ++k) {
+        double mnx = 1e300, mxx = -1e300, mny = 1e300, mxy = -1e300;
+        for (int v = polys->poly_offsets[k]; v < polys->poly_offsets[k + 1]; ++v) {
+          const double x = polys->xy[2 * v] * ax, y = polys->xy[2 * v + 1] * ay;  // back to frame coordinates
+          mnx = std::min(mnx, x); mxx = std::max(mxx, x);
+          mny = std::min(mny, y); mxy = std::max(mxy, y);
+        }
+        const double x0 = std::min(std::max(mnx, 0.0), w - 1.0), x1 = std::min(std::max(mxx + 1.0, x0 + 1.0), (double)w);
+        const double y0 = std::min(std::max(mny, 0.0), h - 1.0), y1 = std::min(std::max(mxy + 1.0, y0 + 1.0), (double)h);
+        boxes.push_back({b, (float)x0, (float)y0, (float)x1, (float)y1});
+      }
+    }
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const size_t fr_bytes = (size_t)n * h * w * 4, bx_bytes = boxes.size() * sizeof(CropBox), cr_bytes = (size_t)np * 784 * 4;
+    if (mem_kind == OCR_MEM_DEVICE) {
+      char* sc = static_cast<char*>(det->impl.scratch(1, align256(bx_bytes)));
+      OCR_HIP(hipMemcpyAsync(sc, boxes.data(), bx_bytes, hipMemcpyHostToDevice, s));
+      launch_crops(frames, h, w, reinterpret_cast<const CropBox*>(sc), np, crops, s);
+      OCR_HIP(hipStreamSynchronize(s));
+    } else {
+      const size_t o_fr = align256(bx_bytes), o_cr = o_fr + align256(fr_bytes);
+      char* sc = static_cast<char*>(det->impl.scratch(0, o_cr + align256(cr_bytes)));
+      OCR_HIP(hipMemcpyAsync(sc, boxes.data(), bx_bytes, hipMemcpyHostToDevice, s));
+      OCR_HIP(hipMemcpyAsync(sc + o_fr, frames, fr_bytes, hipMemcpyHostToDevice, s));
+      launch_crops(reinterpret_cast<const float*>(sc + o_fr), h, w, reinterpret_cast<const CropBox*>(sc), np,
+                   reinterpret_cast<float*>(sc + o_cr), s);
+      OCR_HIP(hipMemcpyAsync(crops, sc + o_cr, cr_bytes, hipMemcpyDeviceToHost, s));
+      OCR_HIP(hipStreamSynchronize(s));
+    }
+  });
+}
+
 void ocr_postproc_default_params(ocr_postproc_params_t* p) {
   if (!p) return;
   p->thresh = 0.6;        // metrics.rs:38

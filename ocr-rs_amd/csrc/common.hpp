@@ -86,6 +86,13 @@ size_t preprocess_scratch_bytes(int w, int h, int W, int H);
 void launch_preprocess(const unsigned char* rgba_dev, int w, int h, int W, int H, unsigned char* gray_dev, float* gray_f32_dev,
                        void* scratch, size_t scratch_bytes, double* adj_xy, hipStream_t s);
 
+// crop extraction detect -> recognise (build-defined rule, oracle/crop_oracle.py), crops.hip
+struct CropBox {
+  int frame;
+  float x0, y0, x1, y1;
+};
+void launch_crops(const float* frames_dev, int H, int W, const CropBox* boxes_dev, int n_boxes, float* crops_dev, hipStream_t s);
+
 // recognition net, fused
 struct RecWeights {
   const float *c1w, *c1b, *c2w, *c2b, *f1w, *f1b, *f2w, *f2b;
