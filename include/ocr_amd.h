@@ -145,6 +145,23 @@ int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, 
                       const ocr_polygons_t* polys, const double* adj_xy, float* crops);
 
 /* ---------------------------------------------------------------------------
+ * Detection quality metrics (host code; consumers of the polygon lists).  Replaces
+ *   evaluate_image(gt, ignore_flags, pred) -> Result<MetricsItem>      metrics.rs:255-380
+ *   combine_results(results) -> Result<(precision, recall, hmean)>     metrics.rs:229-253
+ * (validate_measure :191-219 = drop predictions with score < 0.6, then evaluate_image per image;
+ *  gather_measure :221-227 = combine_results over the concatenated items: see the host mirrors.)
+ * Polygons are CSR: offsets[n+1] into x,y pairs, u32 as in MultiPolygon<u32>.
+ * ------------------------------------------------------------------------- */
+typedef struct ocr_metrics_item {   /* MetricsItem, metrics.rs:22-30 */
+  double precision, recall, hmean;
+  int32_t gt_care, det_care, det_matched;
+} ocr_metrics_item_t;
+
+int ocr_evaluate_image(const uint32_t* gt_xy, const int32_t* gt_offsets, int n_gt, const uint8_t* ignore_flags,
+                       const uint32_t* pred_xy, const int32_t* pred_offsets, int n_pred, ocr_metrics_item_t* out);
+int ocr_combine_results(const ocr_metrics_item_t* items, int n, double* precision, double* recall, double* hmean);
+
+/* ---------------------------------------------------------------------------
  * Recogniser.  Replaces
  *   let net = Net::new(&weights.root()); weights.load(file)   char_recognition/mod.rs:44-46
  *   net.forward_t(&image_tensor, false)                       char_recognition/mod.rs:53-54

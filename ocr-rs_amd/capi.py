@@ -23,7 +23,7 @@ EXPORTS = [
     "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
-    "ocr_extract_crops",
+    "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify", "ocr_rec_alphabet",
 ]
@@ -38,6 +38,11 @@ class OcrError(RuntimeError):
 class PostprocParams(C.Structure):
     _fields_ = [("thresh", C.c_double), ("box_thresh", C.c_double), ("min_size", C.c_double),
                 ("unclip_ratio", C.c_double), ("skip_degenerate", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MetricsItem(C.Structure):
+    _fields_ = [("precision", C.c_double), ("recall", C.c_double), ("hmean", C.c_double),
+                ("gt_care", C.c_int32), ("det_care", C.c_int32), ("det_matched", C.c_int32)]
 
 
 class Polygons(C.Structure):
@@ -80,6 +85,10 @@ def lib() -> C.CDLL:
                                           C.POINTER(C.POINTER(Polygons))]
         L.ocr_polygons_free.argtypes = [C.POINTER(Polygons)]
         L.ocr_polygons_free.restype = None
+        L.ocr_evaluate_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.POINTER(MetricsItem)]
+        L.ocr_combine_results.argtypes = [C.POINTER(MetricsItem), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double)]
         L.ocr_extract_crops.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Polygons),
                                         C.POINTER(C.c_double), C.c_void_p]
         L.ocr_rec_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]

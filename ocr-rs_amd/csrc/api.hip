@@ -316,6 +316,39 @@ int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, 
   });
 }
 
+static std::vector<std::vector<ocr::geom::Pt>> csr_polys(const uint32_t* xy, const int32_t* offsets, int n) {
+  std::vector<std::vector<ocr::geom::Pt>> out(n);
+  for (int k = 0; k < n; ++k)
+    for (int v = offsets[k]; v < offsets[k + 1]; ++v) out[k].push_back({(int)xy[2 * v], (int)xy[2 * v + 1]});
+  return out;
+}
+
+int ocr_evaluate_image(const uint32_t* gt_xy, const int32_t* gt_offsets, int n_gt, const uint8_t* ignore_flags,
+                       const uint32_t* pred_xy, const int32_t* pred_offsets, int n_pred, ocr_metrics_item_t* out) {
+  return guard([&] {
+    if (!out || n_gt < 0 || n_pred < 0 || (n_gt > 0 && (!gt_xy || !gt_offsets || !ignore_flags)) || (n_pred > 0 && (!pred_xy || !pred_offsets)))
+      ocr::fail(OCR_ERR_INVALID, "evaluate_image: null argument");
+    std::vector<bool> ign(n_gt);
+    for (int i = 0; i < n_gt; ++i) ign[i] = ignore_flags[i] != 0;
+    const ocr::geom::MetricsItem m = ocr::geom::evaluate_image(csr_polys(gt_xy, gt_offsets, n_gt), ign, csr_polys(pred_xy, pred_offsets, n_pred));
+    out->precision = m.precision;
+    out->recall = m.recall;
+    out->hmean = m.hmean;
+    out->gt_care = m.gt_care;
+    out->det_care = m.det_care;
+    out->det_matched = m.det_matched;
+  });
+}
+
+int ocr_combine_results(const ocr_metrics_item_t* items, int n, double* precision, double* recall, double* hmean) {
+  return guard([&] {
+    if ((n > 0 && !items) || !precision || !recall || !hmean) ocr::fail(OCR_ERR_INVALID, "combine_results: null argument");
+    std::vector<ocr::geom::MetricsItem> v(n);
+    for (int i = 0; i < n; ++i) v[i] = {items[i].precision, items[i].recall, items[i].hmean, items[i].gt_care, items[i].det_care, items[i].det_matched};
+    ocr::geom::combine_results(v.data(), n, precision, recall, hmean);
+  });
+}
+
 void ocr_postproc_default_params(ocr_postproc_params_t* p) {
   if (!p) return;
   p->thresh = 0.6;        // metrics.rs:38

@@ -28,6 +28,18 @@ void raw_offset_ring(const std::vector<Pt>& poly, double delta, std::vector<Pt>&
 void positive_union_outer(const std::vector<Pt>& ring, std::vector<Pt>& out);
 bool expand_polygon(const std::vector<Pt>& pts, double factor, std::vector<Pt>& out);
 
+// eval metrics (eval_metrics.cpp): metrics.rs:229-394
+struct MetricsItem {  // metrics.rs:22-30
+  double precision, recall, hmean;
+  int gt_care, det_care, det_matched;
+};
+double polygon_area(const std::vector<Pt>& p);
+double intersection_area(const std::vector<Pt>& a, const std::vector<Pt>& b);
+double union_area(const std::vector<Pt>& a, const std::vector<Pt>& b);
+MetricsItem evaluate_image(const std::vector<std::vector<Pt>>& gt, const std::vector<bool>& ignore,
+                           const std::vector<std::vector<Pt>>& pred);
+void combine_results(const MetricsItem* r, int n, double* precision, double* recall, double* hmean);
+
 // contours -> Douglas-Peucker polygons with >= 4 points (metrics.rs:78-98)
 void contour_candidates(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& cands);
 // score threshold, unclip, min-size filter, round(p/adj) as u32 (metrics.rs:100-123).
