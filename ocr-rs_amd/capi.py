@@ -17,10 +17,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCR_AMD_LIB") or os.path.join(_HERE, "lib", "libocr_amd.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
+PRECISION_F32, PRECISION_BF16 = 0, 1
 
 EXPORTS = [
     "ocr_last_error", "ocr_version", "ocr_device_count",
-    "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_forward",
+    "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
@@ -69,6 +70,7 @@ def lib() -> C.CDLL:
         L.ocr_det_destroy.argtypes = [C.c_void_p]
         L.ocr_det_destroy.restype = None
         L.ocr_det_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.ocr_det_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.ocr_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ocr_det_forward_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_float]
@@ -108,6 +110,8 @@ def lib() -> C.CDLL:
         L.ocr_test_box_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_void_p]
         L.ocr_test_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.POINTER(C.c_float)]
+        L.ocr_test_conv_run.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] +
+                                        [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2)
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
@@ -169,6 +173,10 @@ class Detector:
 
     def set_stream(self, raw_stream: Optional[int]) -> None:
         check(lib().ocr_det_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def set_precision(self, precision: int) -> None:
+        """PRECISION_F32 (default, the parity configuration) or PRECISION_BF16 (trunk + FPN in bf16)."""
+        check(lib().ocr_det_set_precision(self._h, precision))
 
     def synchronize(self) -> None:
         check(lib().ocr_det_synchronize(self._h))
@@ -240,6 +248,26 @@ class Detector:
         ms = C.c_float(0.0)
         check(lib().ocr_test_conv_bench(self._h, n, h, w, cin, cout, ks, stride, src_mode, iters, C.byref(ms)))
         return ms.value
+
+    def debug_conv_run(self, x_nhwc, wgt_ohwi, stride=1, scale=None, bias=None, residual=None, up_residual=None,
+                       relu=False, cat4_shape=None, in_bf16=False, out_bf16=False, want_out=True, want_out2=False):
+        """One conv_igemm launch on caller data (test hook).  x_nhwc: N x H x W x Cin f32, or with
+        cat4_shape=(n, h, w) the flat concatenation p5|p4|p3|p2.  Returns (out, out2) as N x Ho x Wo x Cout f32."""
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        x, wg = f(x_nhwc), f(wgt_ohwi)
+        cout, kk, cin = wg.shape
+        ks = int(round(kk ** 0.5))
+        n, h, w = cat4_shape if cat4_shape else x.shape[:3]
+        pad = (ks - 1) // 2
+        ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+        out = np.empty((n, ho, wo, cout), np.float32) if want_out else None
+        out2 = np.empty((n, ho, wo, cout), np.float32) if want_out2 else None
+        sc, bi, rs, ur = f(scale), f(bias), f(residual), f(up_residual)
+        p = lambda a: None if a is None else _ptr(a)
+        check(lib().ocr_test_conv_run(self._h, int(in_bf16), int(out_bf16), _ptr(x), n, h, w, cin, _ptr(wg), cout, ks,
+                                      stride, p(sc), p(bi), p(rs), p(ur), int(relu), int(bool(cat4_shape)),
+                                      p(out), p(out2)))
+        return out, out2
 
     def debug_box_scores(self, pred_hw: np.ndarray, polys):
         """Test hook: raw (sum, count) of the GPU box-score kernel for given polygons."""

@@ -192,6 +192,13 @@ int ocr_det_set_stream(ocr_det_t* det, void* s) {
   });
 }
 
+int ocr_det_set_precision(ocr_det_t* det, int precision) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
+    det->impl.set_precision(precision);
+  });
+}
+
 int ocr_det_forward(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, int mem_kind) {
   return guard([&] {
     if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
@@ -517,6 +524,100 @@ int ocr_test_box_scores(ocr_det_t* det, const float* prob_host, int h, int w, co
     OCR_HIP(hipStreamSynchronize(s));
   });
 }
+// one conv_igemm launch on caller data (kernel-level parity hook).  All host arrays are f32; with in_bf16 /
+// out_bf16 they are rounded to bf16 (nearest even) on the way in and widened on the way out, so the caller
+// compares against a reference computed from the SAME rounded operands.  in: NHWC; cat4: the four pyramid
+// levels p5 (h/8), p4 (h/4), p3 (h/2), p2 (h) back to back, 64 channels each.  wgt: [cout][ks*ks][cin].
+int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in, int n, int h, int w, int cin,
+                      const float* wgt, int cout, int ks, int stride, const float* scale, const float* bias,
+                      const float* residual, const float* up_residual, int relu, int cat4, float* out, float* out2) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !in || !wgt) fail(OCR_ERR_INVALID, "null argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const int pad = (ks - 1) / 2;
+    const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
+    size_t lvl[4] = {0, 0, 0, 0};
+    size_t in_e = (size_t)n * h * w * cin;
+    if (cat4) {
+      if (cin != 256 || (h % 8) || (w % 8)) fail(OCR_ERR_INVALID, "cat4 needs cin 256 and h, w multiples of 8");
+      in_e = 0;
+      for (int l = 0; l < 4; ++l) {
+        lvl[l] = in_e;
+        in_e += (size_t)n * (h >> (3 - l)) * (w >> (3 - l)) * 64;
+      }
+    }
+    const size_t w_e = (size_t)cout * ks * ks * cin, out_e = (size_t)n * ho * wo * cout;
+    const size_t up_e = (size_t)n * (ho / 2) * (wo / 2) * cout;
+    auto bf16_bits = [](float f) {
+      uint32_t u;
+      std::memcpy(&u, &f, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    std::vector<void*> allocs;
+    auto up = [&](const float* src, size_t elems, bool bf) -> void* {
+      if (!src) return nullptr;
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, elems * (bf ? 2 : 4)));
+      allocs.push_back(d);
+      if (bf) {
+        std::vector<uint16_t> t(elems);
+        for (size_t i = 0; i < elems; ++i) t[i] = bf16_bits(src[i]);
+        OCR_HIP(hipMemcpy(d, t.data(), elems * 2, hipMemcpyHostToDevice));
+      } else {
+        OCR_HIP(hipMemcpy(d, src, elems * 4, hipMemcpyHostToDevice));
+      }
+      return d;
+    };
+    auto down = [&](float* dst, const void* dev, size_t elems, bool bf) {
+      if (!dst) return;
+      if (bf) {
+        std::vector<uint16_t> t(elems);
+        OCR_HIP(hipMemcpy(t.data(), dev, elems * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < elems; ++i) {
+          const uint32_t u = (uint32_t)t[i] << 16;
+          std::memcpy(&dst[i], &u, 4);
+        }
+      } else {
+        OCR_HIP(hipMemcpy(dst, dev, elems * 4, hipMemcpyDeviceToHost));
+      }
+    };
+    const size_t ies = in_bf16 ? 2 : 4, oes = out_bf16 ? 2 : 4;
+    char* d_in = static_cast<char*>(up(in, in_e, in_bf16));
+    ConvDesc d{};
+    d.in_bf16 = in_bf16 ? 1 : 0;
+    d.out_bf16 = out_bf16 ? 1 : 0;
+    d.src_mode = cat4 ? SRC_CAT4 : SRC_PLAIN;
+    d.src[0] = d_in;
+    if (cat4) {
+      for (int l = 0; l < 4; ++l) d.src[l] = d_in + lvl[l] * ies;
+      d.src_base = d_in;
+    }
+    d.src_bytes = in_e * ies;
+    d.wgt = up(wgt, w_e, in_bf16);
+    d.wgt_bytes = w_e * ies;
+    d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    d.ks = ks; d.stride = stride; d.pad = pad;
+    d.scale = static_cast<const float*>(up(scale, cout, false));
+    d.bias = static_cast<const float*>(up(bias, cout, false));
+    d.residual = up(residual, out_e, out_bf16);
+    d.up_residual = up(up_residual, up_e, out_bf16);
+    d.relu = relu; d.store_mode = STORE_NHWC; d.name = "test_conv";
+    void* d_out = nullptr;
+    void* d_out2 = nullptr;
+    if (out) { OCR_HIP(hipMalloc(&d_out, out_e * oes)); allocs.push_back(d_out); }
+    if (out2) { OCR_HIP(hipMalloc(&d_out2, out_e * oes)); allocs.push_back(d_out2); }
+    d.out = d_out;
+    d.out2 = d_out2;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    launch_conv_igemm(d, s);
+    OCR_HIP(hipStreamSynchronize(s));
+    down(out, d_out, out_e, out_bf16);
+    down(out2, d_out2, out_e, out_bf16);
+  });
+}
 // micro-benchmark of one conv_igemm launch shape on constant data (kernel tuning aid)
 int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, int ks, int stride, int src_mode,
                         int iters, float* ms_out) {
@@ -537,9 +638,10 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
     ConvDesc d{};
     d.src[0] = in;
     d.src_mode = SRC_PLAIN;
-    (void)src_mode;
-    d.src_bytes = in_e * 4;
-    d.wgt_bytes = w_e * 4; d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    const int bf = src_mode == 16 ? 1 : 0;  // src_mode 16: bf16 operands and output (the buffers are just reinterpreted)
+    d.in_bf16 = d.out_bf16 = bf;
+    d.src_bytes = in_e * (bf ? 2 : 4);
+    d.wgt_bytes = w_e * (bf ? 2 : 4); d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
     d.ks = ks; d.stride = stride; d.pad = pad; d.wgt = wt; d.relu = 1; d.store_mode = STORE_NHWC; d.out = out;
     d.name = "bench";
     hipEvent_t e0, e1;

@@ -44,25 +44,26 @@ enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1 };
 // One convolution as an implicit GEMM: M = N*Ho*Wo pixels, N = Cout, K = ks*ks*Cin.
 // Activations are NHWC f32, weights [Cout][ks*ks][Cin] f32.
 struct ConvDesc {
-  const float* src[4];    // PLAIN: src[0]; CAT4: p5,p4,p3,p2 (all inside ONE allocation starting at src_base)
-  const float* src_base;  // CAT4: start of the allocation holding the four sources (else unused)
+  int in_bf16, out_bf16;  // element types: operands (src, wgt) and results (out, out2, residual, up_residual); 0 = f32
+  const void* src[4];     // PLAIN: src[0]; CAT4: p5,p4,p3,p2 (all inside ONE allocation starting at src_base)
+  const void* src_base;   // CAT4: start of the allocation holding the four sources (else unused)
   size_t src_bytes;       // bytes addressable from src[0] (PLAIN) / src_base (CAT4); must be < 2^31
   size_t wgt_bytes;
   int src_mode;
   int N, Hin, Win, Cin;   // logical input grid of this conv
   int Ho, Wo, Cout;
   int ks, stride, pad;
-  const float* wgt;
-  const float* scale;     // per output column, may be null (then scale 1 / bias 0)
+  const void* wgt;
+  const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32
   const float* bias;
-  const float* residual;  // NHWC, shape of the output, may be null
+  const void* residual;   // NHWC, shape of the output, may be null
   // second output: out2 = value + nearest_upsample_x2(up_residual) (FPN top-down sum,
   // model.rs:126-137); up_residual is [N][Ho/2][Wo/2][Cout].  out may be null when out2 is set.
-  const float* up_residual;
-  float* out2;
+  const void* up_residual;
+  void* out2;
   int relu;
   int store_mode;
-  float* out;
+  void* out;
   const char* name;
 };
 
@@ -71,7 +72,7 @@ const char* conv_igemm_kernel_name(const ConvDesc& d);
 
 // stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
 void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,
-                 float* out, int N, int H, int W, hipStream_t s);
+                 void* out, int out_bf16, int N, int H, int W, hipStream_t s);
 // tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);

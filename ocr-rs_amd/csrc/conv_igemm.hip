@@ -20,8 +20,14 @@
 // undone by the fragment read, which makes every 16-lane ds_read_b128 group conflict-free.
 // Two stages, one barrier per K-step: the DMA of step k+1 flies during the MFMAs of step k.
 //
-// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 32 with BM,BN in {64,128};
-// each wave owns (BM/2) x (BN/2) as 32x32 MFMA tiles.
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 128 bytes of K with BM,BN in
+// {64,128}; each wave owns (BM/2) x (BN/2) as 32x32 MFMA tiles.
+//
+// Element types.  TI (operands) is f32 or bf16, TO (output, residuals) f32 or bf16; accumulation,
+// scale/bias and the epilogue arithmetic are always f32.  A 128-byte LDS row holds 32 f32 or 64 bf16
+// of K, so the DMA / swizzle / fragment-read machinery is byte-identical for both; bf16 feeds
+// v_mfma_f32_32x32x16_bf16 (one 16-byte fragment = one MFMA instead of four).  The default (and the
+// benchmarked BASELINE config 1) is f32 throughout; bf16 is the opt-in precision of config 5.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -31,17 +37,41 @@ namespace igemm {  // named (not anonymous): the kernel stubs are referenced fro
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+// 4 consecutive elements of an f32 / bf16 tensor as f32x4 (16- / 8-byte access)
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ f32x4 load4(const void* base, size_t idx) { return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx); }
+  static __device__ __forceinline__ void store4(void* base, size_t idx, f32x4 v) { *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v; }
+  static __device__ __forceinline__ float load1(const void* base, size_t idx) { return static_cast<const float*>(base)[idx]; }
+  static __device__ __forceinline__ void store1(void* base, size_t idx, float v) { static_cast<float*>(base)[idx] = v; }
+};
+template <> struct Elem<__bf16> {
+  static __device__ __forceinline__ f32x4 load4(const void* base, size_t idx) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(base) + idx);
+    f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return v;
+  }
+  static __device__ __forceinline__ void store4(void* base, size_t idx, f32x4 v) {
+    bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};  // round to nearest even
+    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(base) + idx) = h;
+  }
+  static __device__ __forceinline__ float load1(const void* base, size_t idx) { return (float)static_cast<const __bf16*>(base)[idx]; }
+  static __device__ __forceinline__ void store1(void* base, size_t idx, float v) { static_cast<__bf16*>(base)[idx] = (__bf16)v; }
+};
+
 struct ConvArgs {
-  const float* src;       // PLAIN: the input tensor; CAT4: allocation holding p5,p4,p3,p2
-  const float* wgt;
+  const void* src;        // PLAIN: the input tensor; CAT4: allocation holding p5,p4,p3,p2   (TI)
+  const void* wgt;        //                                                                  (TI)
   const float* scale;
   const float* bias;
-  const float* residual;
-  const float* up_residual;
-  float* out;
-  float* out2;
+  const void* residual;   //                                                                  (TO)
+  const void* up_residual;
+  void* out;
+  void* out2;
   unsigned src_bytes, wgt_bytes;
   int src_off[4];         // CAT4: element offset of p5,p4,p3,p2 inside src
   int N, Hin, Win, Cin;
@@ -70,18 +100,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
-constexpr int BK = 32;                    // floats per LDS row (one 128-byte line)
+constexpr int ROWB = 128;                 // bytes of K per LDS row (one cache line): 32 f32 or 64 bf16
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;     // voffset beyond any tensor (< 2^31 bytes): reads as zero
 
-template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
-__global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
+template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
+__global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources, LDS address space):
                                      // the host pass only needs the launch stub
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int AI = BM / 32, BI = BN / 32;
-  constexpr int STAGE = (BM + BN) * BK;   // floats per LDS stage
-  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+  constexpr int EB = sizeof(TI);              // bytes per operand element
+  constexpr int BK = ROWB / EB;               // K elements per LDS row / K-step
+  constexpr bool BF16 = EB == 2;
+  constexpr int STAGE = (BM + BN) * ROWB;     // bytes per LDS stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,8 +127,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
-  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
-  const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
+  const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
   // ---- DMA coordinates: this lane fills LDS slot q of rows r + 32 i with global chunk q ^ f(r)
   const int r = tid >> 3;
@@ -114,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       ih0[i] = oh * STRIDE - p.pad;
       iw0[i] = ow * STRIDE - p.pad;
       if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; the pixel offset depends on the source
-      else abase[i] = (((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin + gq * 4) * 4;  // bytes
+      else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin * EB + gq * 16;  // bytes
     } else {
       ih0[i] = -(1 << 20);  // every tap out of range -> zeros
       iw0[i] = 0;
@@ -123,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   }
   unsigned bvoff[BI];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((n0 + r + 32 * i) * (KS * KS) * p.Cin + gq * 4) * 4);
+  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)((n0 + r + 32 * i) * (KS * KS) * p.Cin * EB + gq * 16);
 
   // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
   // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
@@ -143,9 +176,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     unsigned off;
     if constexpr (SRC == SRC_CAT4) {
       const int sh = 3 - s;
-      off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64 + gq * 4) * 4);
+      off = (unsigned)((p.src_off[s] + ((abase[i] * (p.Hin >> sh) + (ih >> sh)) * (p.Win >> sh) + (iw >> sh)) * 64) * EB + gq * 16);
     } else {
-      off = (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * 4);
+      off = (unsigned)(abase[i] + (kh * p.Win + kw) * p.Cin * EB);
     }
     return ok ? off : OOB;
   };
@@ -156,14 +189,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       for (int i = 0; i < AI; ++i) avoff[t][i] = tap_offset(s, t, i);
   };
   prep_source(0);
-  auto issue_plain = [&](float* st, const unsigned (&av)[AI], int tap, int c, int kbase) {
+  auto issue_plain = [&](unsigned char* st, const unsigned (&av)[AI], int tap, int c, int kbase) {
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * BK), 16, av[i], c * (BK * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * ROWB), 16, av[i], c * ROWB, 0, 0);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * BK), 16, bvoff[i],
-                                               (tap * p.Cin + kbase + c * BK) * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * ROWB), 16, bvoff[i],
+                                               (tap * p.Cin + kbase) * EB + c * ROWB, 0, 0);
   };
 
   f32x16 acc[MT][NT];
@@ -174,39 +207,50 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // MFMA operand fetch: lane l supplies row (l & 31); lanes 0-31 hold k = 8g+j, lanes 32-63
-  // hold k = 8g+4+j for the j-th MFMA of K-group g (same map for A and B): chunk c = 2g + (l>>5),
-  // stored in slot c ^ f(row).
+  // MFMA operand fetch: lane l supplies row (l & 31) and the 16-byte chunk c = 2g + (l>>5) of K-group
+  // g, stored in slot c ^ f(row) (same map for A and B).
+  //   f32 : the chunk is 4 k; the j-th of four v_mfma_f32_32x32x2_f32 takes k = 8g+j (lanes 0-31) and
+  //         8g+4+j (lanes 32-63);
+  //   bf16: the chunk is 8 k = exactly one operand of v_mfma_f32_32x32x16_bf16 (k = 16g + 8 (l>>5) + j).
   const int frow = lane & 31;
   const int fsw = (frow >> 1) & 7;
-  int xoff[BK / 8];
+  int xoff[4];
 #pragma unroll
-  for (int g = 0; g < BK / 8; ++g) xoff[g] = ((2 * g + (lane >> 5)) ^ fsw) * 4;
-  const int a_row = (wm * WM + frow) * BK;
-  const int b_row = (BM + wn * WN + frow) * BK;
+  for (int g = 0; g < 4; ++g) xoff[g] = ((2 * g + (lane >> 5)) ^ fsw) * 16;
+  const int a_row = (wm * WM + frow) * ROWB;
+  const int b_row = (BM + wn * WN + frow) * ROWB;
 
   auto compute = [&](int stage) {
-    const float* st = lds + stage * STAGE;
+    const unsigned char* st = lds + stage * STAGE;
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
+    for (int g = 0; g < 4; ++g) {
       f32x4 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_row + i * 32 * BK + xoff[g]);
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_row + i * 32 * ROWB + xoff[g]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + b_row + j * 32 * BK + xoff[g]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + b_row + j * 32 * ROWB + xoff[g]);
+      if constexpr (BF16) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+                                                                 acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
   // One pass = all channel chunks of one source (PLAIN: the only one; CAT4: four passes of 2 chunks).
   constexpr int NSRC = SRC == SRC_CAT4 ? 4 : 1;
-  const int pass_chunks = SRC == SRC_CAT4 ? 2 : csteps;
+  const int pass_chunks = SRC == SRC_CAT4 ? 64 / BK : csteps;
   int par = 0;  // LDS stage holding the K-step about to be multiplied
   issue_plain(lds, avoff[0], 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     for (int c = 0; c < pass_chunks; ++c) {
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
-        float* nxt = lds + (par ^ 1) * STAGE;
+        unsigned char* nxt = lds + (par ^ 1) * STAGE;
         // DMA of the next K-step flies while this one is multiplied
         if (t + 1 < NTAP) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c, s * 64);
         else if (c + 1 < pass_chunks) issue_plain(nxt, avoff[0], 0, c + 1, s * 64);
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   // ---- epilogue A (plain NHWC store, the MFMA-bound convs): straight from the accumulators.
   // C/D map of a 32x32 MFMA tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); one store
   // instruction writes 2 rows x 128 contiguous bytes.  Residual rows are all requested before use.
-  if (STORE == STORE_NHWC && !p.out2) {
+  if (STORE == STORE_NHWC && sizeof(TO) == 4 && !p.out2) {
     const int colq = lane & 31;
     const int rowq = (lane >> 5) * 4;
     const bool full_tile = m0 + BM <= p.M;
@@ -258,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int m = min(mbase + (e & 3) + 8 * (e >> 2), p.M - 1);
-            res[e] = p.residual[(size_t)m * p.Cout + col];
+            res[e] = Elem<TO>::load1(p.residual, (size_t)m * p.Cout + col);
           }
         } else {
 #pragma unroll
@@ -269,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
           const int m = mbase + (e & 3) + 8 * (e >> 2);
           float v = acc[i][j][e] * sc + bi + res[e];
           if (p.relu) v = fmaxf(v, 0.f);
-          if (full_tile || m < p.M) p.out[(size_t)m * p.Cout + col] = v;
+          if (full_tile || m < p.M) Elem<TO>::store1(p.out, (size_t)m * p.Cout + col, v);
         }
         __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile at a time: keeps the residual staging at 16 registers
       }
@@ -277,11 +321,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     return;
   }
 
-  // ---- epilogue B (HBM-bound launches: lateral + top-down sum, transposed conv).  The accumulator
+  // ---- epilogue B (HBM-bound launches: lateral + top-down sum, transposed conv; every bf16 output).  The accumulator
   // tile goes through LDS (the operand stages are free now) so that global traffic is row-major
   // float4: a wave touches 512 contiguous bytes of one pixel row per instruction.  Per-row index
   // arithmetic (the only integer divisions) is done once per block by the first BM threads.
-  static_assert(BM * BN <= 2 * STAGE, "accumulator tile must fit in the operand stages");
+  static_assert(BM * BN * 4 <= 2 * STAGE, "accumulator tile must fit in the operand stages");
+  float* tile = reinterpret_cast<float*>(lds);
   constexpr int CPR = BN / 4;          // float4 chunks per tile row
   constexpr int RPP = 256 / CPR;       // rows per pass
   constexpr int PASSES = BM / RPP;
@@ -300,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          lds[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq) * BN + wn * WN + j * 32 + colq] = acc[i][j][e];
+          tile[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq) * BN + wn * WN + j * 32 + colq] = acc[i][j][e];
   }
   if (tid < BM && (STORE == STORE_SHUFFLE2 || p.out2)) {
     const int m = min(m0 + tid, p.M - 1);
@@ -324,22 +369,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       for (int k = 0; k < G; ++k) {
         const int rr = rr0 + (k0 + k) * RPP;
         const int m = min(m0 + rr, p.M - 1);
-        up[k] = p.out2 ? *reinterpret_cast<const f32x4*>(p.up_residual + row_aux[rr] + col) : zero4;
-        res[k] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + col) : zero4;
+        up[k] = p.out2 ? Elem<TO>::load4(p.up_residual, (size_t)row_aux[rr] + col) : zero4;
+        res[k] = p.residual ? Elem<TO>::load4(p.residual, (size_t)m * p.Cout + col) : zero4;
       }
 #pragma unroll
       for (int k = 0; k < G; ++k) {
         const int rr = rr0 + (k0 + k) * RPP;
         const int m = m0 + rr;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[rr * BN + c4]) * sc + bi + res[k];
+        f32x4 v = *reinterpret_cast<const f32x4*>(&tile[rr * BN + c4]) * sc + bi + res[k];
         if (p.relu) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
         }
         if (m < p.M) {
           const size_t o = (size_t)m * p.Cout + col;
-          if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
-          if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + o) = up[k] + v;  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
+          if (p.out) Elem<TO>::store4(p.out, o, v);
+          if (p.out2) Elem<TO>::store4(p.out2, o, up[k] + v);  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
         }
       }
     }
@@ -350,12 +395,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
       const int rr = rr0 + k * RPP;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[rr * BN + c4]) * sc + bi;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&tile[rr * BN + c4]) * sc + bi;
       if (p.relu) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
       }
-      if (m0 + rr < p.M) *reinterpret_cast<f32x4*>(p.out + (size_t)row_aux[rr] + toff) = v;
+      if (m0 + rr < p.M) Elem<TO>::store4(p.out, (size_t)row_aux[rr] + toff, v);
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -369,13 +414,15 @@ static void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
   *shift = L == 0 ? 0xFFFFFFFFu : L - 1;  // d == 1: identity
 }
 
-template <int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
+template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
 void launch_inst(const ConvDesc& d, hipStream_t s) {
   ConvArgs a{};
   a.src = d.src_mode == SRC_CAT4 ? d.src_base : d.src[0];
   a.src_bytes = (unsigned)d.src_bytes;
   a.wgt_bytes = (unsigned)d.wgt_bytes;
-  for (int i = 0; i < 4; ++i) a.src_off[i] = d.src_mode == SRC_CAT4 ? (int)(d.src[i] - d.src_base) : 0;
+  // element offsets of the CAT4 sources inside their shared allocation
+  for (int i = 0; i < 4; ++i)
+    a.src_off[i] = d.src_mode == SRC_CAT4 ? (int)((static_cast<const char*>(d.src[i]) - static_cast<const char*>(d.src_base)) / (long)sizeof(TI)) : 0;
   a.wgt = d.wgt;
   a.scale = d.scale;
   a.bias = d.bias;
@@ -399,7 +446,7 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
   static const int extra_lds = getenv("OCR_CONV_EXTRA_LDS") ? atoi(getenv("OCR_CONV_EXTRA_LDS")) : 0;  // tuning knob: caps residency
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), extra_lds, s, a);
+  hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), extra_lds, s, a);
   OCR_HIP(hipGetLastError());
 }
 
@@ -409,7 +456,9 @@ using namespace igemm;
 // Host-side shape checks: the kernel assumes exactly these, and an out-of-bounds
 // access on the GPU can take the whole node down.
 static void check(const ConvDesc& d) {
-  if (d.Cin % BK != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, BK);
+  const int eb = d.in_bf16 ? 2 : 4;
+  const int bk = 128 / eb;
+  if (d.Cin % bk != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, bk);
   if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
   if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
   if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);
@@ -418,24 +467,27 @@ static void check(const ConvDesc& d) {
     fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
   if ((long long)d.N * d.Ho * d.Wo >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: M overflows int", d.name);
   // the kernel addresses its operands with 32-bit BYTE offsets below the out-of-range marker 2^31
-  const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)d.N * d.Hin * d.Win * d.Cin * 4;
+  const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)d.N * d.Hin * d.Win * d.Cin * eb;
   if (in_bytes >= (1ll << 31) || (long long)d.src_bytes >= (1ll << 31) || (long long)d.src_bytes < in_bytes)
     fail(OCR_ERR_INVALID, "%s: input of %lld bytes (addressable %zu) must be < 2^31 bytes; split the batch", d.name, in_bytes, d.src_bytes);
-  if ((long long)d.wgt_bytes != (long long)d.Cout * d.ks * d.ks * d.Cin * 4) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if ((long long)d.wgt_bytes != (long long)d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
   if (d.src_mode != SRC_PLAIN && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: source mode %d", d.name, d.src_mode);
   if (d.src_mode == SRC_CAT4) {
     if (d.Cin != 256 || ((d.Hin | d.Win) & 7) || d.ks != 3 || d.stride != 1 || d.Cout != 64)
       fail(OCR_ERR_INVALID, "%s: CAT4 needs a 3x3 s1 256->64 conv on a grid divisible by 8", d.name);
     for (int i = 0; i < 4; ++i) {
-      const long long need = (long long)d.N * (d.Hin >> (3 - i)) * (d.Win >> (3 - i)) * 64 * 4;
-      if (!d.src[i] || d.src[i] < d.src_base || (d.src[i] - d.src_base) * 4ll + need > (long long)d.src_bytes)
+      const long long need = (long long)d.N * (d.Hin >> (3 - i)) * (d.Win >> (3 - i)) * 64 * eb;
+      const long long off = static_cast<const char*>(d.src[i]) - static_cast<const char*>(d.src_base);
+      if (!d.src[i] || off < 0 || off % eb || off + need > (long long)d.src_bytes)
         fail(OCR_ERR_INVALID, "%s: CAT4 source %d lies outside the shared allocation", d.name, i);
     }
   }
-  if (d.store_mode == STORE_SHUFFLE2 && (d.Cout != 256 || d.ks != 1 || d.residual || d.out2))
-    fail(OCR_ERR_INVALID, "%s: SHUFFLE2 store needs a plain 1x1 conv with Cout 4*64", d.name);
+  if (d.store_mode == STORE_SHUFFLE2 && (d.Cout != 256 || d.ks != 1 || d.residual || d.out2 || d.in_bf16 || d.out_bf16))
+    fail(OCR_ERR_INVALID, "%s: SHUFFLE2 store needs a plain f32 1x1 conv with Cout 4*64", d.name);
   if (d.out2 && (!d.up_residual || ((d.Ho | d.Wo) & 1))) fail(OCR_ERR_INVALID, "%s: out2 needs up_residual and an even grid", d.name);
   if (!d.src[0] || !d.wgt || (!d.out && !d.out2)) fail(OCR_ERR_INVALID, "%s: null operand", d.name);
+  if (!d.in_bf16 && d.out_bf16) fail(OCR_ERR_INVALID, "%s: f32 operands with bf16 output is not instantiated", d.name);
+  if (d.in_bf16 && !d.out_bf16 && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: bf16 -> f32 exists for the CAT4 conv only", d.name);
 }
 
 // Tile choice: the largest tile that still leaves >= 8 tiles per CU (256 CUs), so that the
@@ -454,7 +506,7 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
-  snprintf(buf, sizeof buf, "conv_igemm_f32<%s,k%d,s%d,%s%s>", tile_name(pick_tile(d)), d.ks, d.stride,
+  snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
            d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : "");
   // names must outlive the call: intern them
   static thread_local std::vector<std::string>* pool = new std::vector<std::string>();
@@ -465,23 +517,31 @@ const char* conv_igemm_kernel_name(const ConvDesc& d) {
   return pool->back().c_str();
 }
 
-template <int KS, int STRIDE, int SRC, int STORE>
+template <typename TI, typename TO, int KS, int STRIDE, int SRC, int STORE>
 static void launch_tiles(const ConvDesc& d, hipStream_t s) {
   switch (pick_tile(d)) {
-    case T128x128: launch_inst<128, 128, KS, STRIDE, SRC, STORE>(d, s); break;
-    case T128x64: launch_inst<128, 64, KS, STRIDE, SRC, STORE>(d, s); break;
-    case T64x64: launch_inst<64, 64, KS, STRIDE, SRC, STORE>(d, s); break;
+    case T128x128: launch_inst<TI, TO, 128, 128, KS, STRIDE, SRC, STORE>(d, s); break;
+    case T128x64: launch_inst<TI, TO, 128, 64, KS, STRIDE, SRC, STORE>(d, s); break;
+    case T64x64: launch_inst<TI, TO, 64, 64, KS, STRIDE, SRC, STORE>(d, s); break;
   }
 }
 
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
-  if (d.store_mode == STORE_SHUFFLE2) return launch_tiles<1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s);
-  if (d.src_mode == SRC_CAT4) return launch_tiles<3, 1, SRC_CAT4, STORE_NHWC>(d, s);
-  if (d.ks == 3 && d.stride == 1) return launch_tiles<3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
-  if (d.ks == 3 && d.stride == 2) return launch_tiles<3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
-  if (d.ks == 1 && d.stride == 1) return launch_tiles<1, 1, SRC_PLAIN, STORE_NHWC>(d, s);
-  if (d.ks == 1 && d.stride == 2) return launch_tiles<1, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.in_bf16) {
+    if (d.src_mode == SRC_CAT4) return launch_tiles<__bf16, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
+    if (d.ks == 3 && d.stride == 1) return launch_tiles<__bf16, __bf16, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+    if (d.ks == 3 && d.stride == 2) return launch_tiles<__bf16, __bf16, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+    if (d.ks == 1 && d.stride == 1) return launch_tiles<__bf16, __bf16, 1, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+    if (d.ks == 1 && d.stride == 2) return launch_tiles<__bf16, __bf16, 1, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+    fail(OCR_ERR_INVALID, "%s: no bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
+  }
+  if (d.store_mode == STORE_SHUFFLE2) return launch_tiles<float, float, 1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s);
+  if (d.src_mode == SRC_CAT4) return launch_tiles<float, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
+  if (d.ks == 3 && d.stride == 1) return launch_tiles<float, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.ks == 3 && d.stride == 2) return launch_tiles<float, float, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.ks == 1 && d.stride == 1) return launch_tiles<float, float, 1, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+  if (d.ks == 1 && d.stride == 2) return launch_tiles<float, float, 1, 2, SRC_PLAIN, STORE_NHWC>(d, s);
   fail(OCR_ERR_INVALID, "%s: no conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
 }
 

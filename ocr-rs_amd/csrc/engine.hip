@@ -65,6 +65,7 @@ ConvW Detector::make_conv(const WeightBlob& wb, const std::string& wname, const 
   ConvW cw;
   cw.w = arena_.upload(t);
   cw.w_bytes = t.size() * sizeof(float);
+  cw.host = std::move(t);
   cw.cin = cin;
   cw.cout = cout;
   cw.ks = ks;
@@ -82,7 +83,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
   WeightBlob wb(blob, bytes);
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-  arena_.reserve((size_t)64 << 20);  // 12.2 M parameters = 48.7 MB + padding
+  arena_.reserve((size_t)96 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -150,6 +151,41 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     const char* e = getenv("OCR_TAIL_UNFUSED");
     fused_tail_ = !(e && e[0] == '1');
   }
+  for (int l = 0; l < 4; ++l) {
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 2; ++c) all_convs_.push_back(&layer_[l][b][c]);
+    if (l > 0) all_convs_.push_back(&down_[l]);
+    all_convs_.push_back(&in_[l]);
+    all_convs_.push_back(&out_[l]);
+  }
+  all_convs_.push_back(&bin1_);
+  {
+    const char* e = getenv("OCR_DET_PRECISION");
+    if (e && std::string(e) == "bf16") set_precision(1);
+  }
+}
+
+// f32 -> bf16, round to nearest even (NaN stays NaN)
+static inline uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+void Detector::set_precision(int precision) {
+  if (precision != 0 && precision != 1) fail(OCR_ERR_INVALID, "precision %d (0 = f32, 1 = bf16)", precision);
+  OCR_HIP(hipSetDevice(device_));
+  if (precision == 1) {
+    for (ConvW* cw : all_convs_) {
+      if (cw->w_bf16) continue;
+      std::vector<float> packed((cw->host.size() + 1) / 2);
+      uint16_t* h = reinterpret_cast<uint16_t*>(packed.data());
+      for (size_t i = 0; i < cw->host.size(); ++i) h[i] = f32_to_bf16(cw->host[i]);
+      cw->w_bf16 = arena_.upload(packed);
+    }
+  }
+  bf16_ = precision == 1;
 }
 
 void Detector::free_workspace() {
@@ -189,36 +225,38 @@ void* Detector::scratch(int slot, size_t bytes) {
 }
 
 void Detector::ensure_workspace(int n, int h, int w) {
-  if (n == ws_n_ && h == ws_h_ && w == ws_w_) return;
+  if (n == ws_n_ && h == ws_h_ && w == ws_w_ && ws_bf16_ == bf16_) return;
   OCR_HIP(hipStreamSynchronize(stream_));
   free_workspace();
-  auto alloc = [&](size_t elems) {
+  const size_t es = bf16_ ? 2 : 4;  // bytes per activation element
+  auto alloc = [&](size_t bytes) {
     void* p = nullptr;
-    OCR_HIP(hipMalloc(&p, elems * sizeof(float)));
+    OCR_HIP(hipMalloc(&p, bytes));
     ws_allocs_.push_back(p);
-    return static_cast<float*>(p);
+    return static_cast<char*>(p);
   };
   const size_t N = (size_t)n;
-  s_ = alloc(N * (h / 4) * (w / 4) * 64);
+  s_ = alloc(N * (h / 4) * (w / 4) * 64 * es);
   size_t pcat_elems = 0;
   for (int l = 0; l < 4; ++l) pcat_elems += N * (h >> (2 + l)) * (w >> (2 + l)) * 64;
-  pcat_ = alloc(pcat_elems);  // p2..p5 in ONE allocation: bin_conv1 gathers all four through one buffer descriptor
-  pcat_bytes_ = pcat_elems * sizeof(float);
+  pcat_ = alloc(pcat_elems * es);  // p2..p5 in ONE allocation: bin_conv1 gathers all four through one buffer descriptor
+  pcat_bytes_ = pcat_elems * es;
   size_t pofs = 0;
   for (int l = 0; l < 4; ++l) {
     const size_t px = N * (h >> (2 + l)) * (w >> (2 + l));
     const size_t c = (size_t)64 << l;
-    t_[l] = alloc(px * c);
-    a_[l] = alloc(px * c);
-    x_[l] = alloc(px * c);
-    d_[l] = l > 0 ? alloc(px * c) : nullptr;
-    i_[l] = l > 0 ? alloc(px * 256) : nullptr;   // raw lateral in3..in5 (in2 is only ever used inside its sum)
-    if (l < 3) sum_[l] = alloc(px * 256);        // up2(in_{k+1}) + in_k
-    p_[l] = pcat_ + pofs;
+    t_[l] = alloc(px * c * es);
+    a_[l] = alloc(px * c * es);
+    x_[l] = alloc(px * c * es);
+    d_[l] = l > 0 ? alloc(px * c * es) : nullptr;
+    i_[l] = l > 0 ? alloc(px * 256 * es) : nullptr;   // raw lateral in3..in5 (in2 is only ever used inside its sum)
+    if (l < 3) sum_[l] = alloc(px * 256 * es);        // up2(in_{k+1}) + in_k
+    p_[l] = pcat_ + pofs * es;
     pofs += px * 64;
   }
-  b1_ = alloc(N * (h / 4) * (w / 4) * 64);
-  tr1buf_ = alloc(N * (h / 2) * (w / 2) * 64);
+  b1_ = reinterpret_cast<float*>(alloc(N * (h / 4) * (w / 4) * 64 * 4));
+  tr1buf_ = fused_tail_ ? nullptr : reinterpret_cast<float*>(alloc(N * (h / 2) * (w / 2) * 64 * 4));
+  ws_bf16_ = bf16_;
   ws_n_ = n;
   ws_h_ = h;
   ws_w_ = w;
@@ -278,15 +316,22 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   Recorder rec{prof, stream_, {}};
 
   struct Extra {
-    const float* residual = nullptr;
-    const float* up_residual = nullptr;
-    float* out2 = nullptr;
+    const void* residual = nullptr;
+    const void* up_residual = nullptr;
+    void* out2 = nullptr;
     bool cat4 = false;
     int store = STORE_NHWC;
   };
-  auto conv = [&](const char* name, const ConvW& cw, const float* src, int hin, int win, int stride, float* out,
+  const bool bf = bf16_;
+  const size_t es = bf ? 2 : 4;
+  auto conv = [&](const char* name, const ConvW& cw, const void* src, int hin, int win, int stride, void* out,
                   bool relu, const Extra& ex = Extra()) {
     ConvDesc d{};
+    // the probability head (bin_conv_tr1 as a GEMM) always runs in f32; bin_conv1 reads bf16 and writes f32
+    const bool in_bf = bf && ex.store != STORE_SHUFFLE2;
+    d.in_bf16 = in_bf ? 1 : 0;
+    d.out_bf16 = (in_bf && !ex.cat4) ? 1 : 0;
+    const size_t ies = in_bf ? 2 : 4;
     d.src[0] = src;
     d.src_mode = ex.cat4 ? SRC_CAT4 : SRC_PLAIN;
     if (ex.cat4) {
@@ -297,9 +342,9 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
       d.src_base = pcat_;
       d.src_bytes = pcat_bytes_;
     } else {
-      d.src_bytes = (size_t)n * hin * win * cw.cin * sizeof(float);
+      d.src_bytes = (size_t)n * hin * win * cw.cin * ies;
     }
-    d.wgt_bytes = cw.w_bytes;
+    d.wgt_bytes = in_bf ? cw.w_bytes / 2 : cw.w_bytes;
     d.N = n;
     d.Hin = hin;
     d.Win = win;
@@ -310,7 +355,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.Ho = (hin + 2 * d.pad - cw.ks) / stride + 1;
     d.Wo = (win + 2 * d.pad - cw.ks) / stride + 1;
     d.Cout = cw.cout;
-    d.wgt = cw.w;
+    d.wgt = in_bf ? cw.w_bf16 : static_cast<const void*>(cw.w);
     d.scale = cw.scale;
     d.bias = cw.bias;
     d.residual = ex.residual;
@@ -324,21 +369,22 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     launch_conv_igemm(d, stream_);
     const double M = (double)n * d.Ho * d.Wo;
     const double K = (double)cw.ks * cw.ks * cw.cin;
-    double in_bytes = (double)n * hin * win * cw.cin * 4.0;
-    if (ex.cat4) in_bytes = (double)n * hin * win * 64 * 4.0 * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
-    double out_bytes = M * cw.cout * 4.0 * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
+    double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
+    if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
+    const double oes = d.out_bf16 ? 2.0 : 4.0;
+    double out_bytes = M * cw.cout * oes * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
                                             (ex.up_residual ? 0.25 : 0.0));
-    rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, in_bytes + out_bytes + K * cw.cout * 4.0);
+    rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, in_bytes + out_bytes + K * cw.cout * (double)ies);
   };
 
   const int h4 = h / 4, w4 = w / 4;
   rec.begin();
-  launch_stem(x, stem_w_, stem_scale_, stem_bias_, s_, n, h, w, stream_);
+  launch_stem(x, stem_w_, stem_scale_, stem_bias_, s_, bf ? 1 : 0, n, h, w, stream_);
   rec.end("stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
-          (double)n * h * w * 4 + (double)n * h4 * w4 * 64 * 4);
+          (double)n * h * w * 4 + (double)n * h4 * w4 * 64 * (double)es);
 
   // ResNet-18 trunk, model.rs:113-120 (basic_block :40-55)
-  const float* cur = s_;
+  const void* cur = s_;
   for (int l = 0; l < 4; ++l) {
     const int hin = l == 0 ? h4 : (h >> (1 + l)), win = l == 0 ? w4 : (w >> (1 + l));
     const int ho = h >> (2 + l), wo = w >> (2 + l);
@@ -400,15 +446,17 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
 
 const float* Detector::stage(int id, size_t* elems) const {
   if (ws_n_ == 0) fail(OCR_ERR_INVALID, "no forward has run yet");
+  if (ws_bf16_ && id != 13) fail(OCR_ERR_INVALID, "stage read-back is f32 only (bf16 precision is active)");
+  auto f = [](const char* p) { return reinterpret_cast<const float*>(p); };
   const size_t N = (size_t)ws_n_;
   auto px = [&](int shift) { return N * (ws_h_ >> shift) * (ws_w_ >> shift); };
-  if (id == 0) { *elems = px(2) * 64; return s_; }
-  if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return x_[id - 1]; }
-  if (id == 5) { *elems = px(2) * 256; return sum_[0]; }  // in2 only exists inside its top-down sum
-  if (id >= 6 && id <= 8) { *elems = px(id - 3) * 256; return i_[id - 5]; }
-  if (id >= 9 && id <= 12) { *elems = px(id - 7) * 64; return p_[id - 9]; }
+  if (id == 0) { *elems = px(2) * 64; return f(s_); }
+  if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return f(x_[id - 1]); }
+  if (id == 5) { *elems = px(2) * 256; return f(sum_[0]); }  // in2 only exists inside its top-down sum
+  if (id >= 6 && id <= 8) { *elems = px(id - 3) * 256; return f(i_[id - 5]); }
+  if (id >= 9 && id <= 12) { *elems = px(id - 7) * 64; return f(p_[id - 9]); }
   if (id == 13) { *elems = px(2) * 64; return b1_; }
-  if (id == 14) { *elems = px(1) * 64; return tr1buf_; }
+  if (id == 14 && tr1buf_) { *elems = px(1) * 64; return tr1buf_; }
   fail(OCR_ERR_INVALID, "unknown stage %d", id);
 }
 

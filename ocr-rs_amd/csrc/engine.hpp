@@ -28,6 +28,8 @@ class DeviceArena {  // bump allocator over one hipMalloc (weights)
 struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
   size_t w_bytes = 0;
+  void* w_bf16 = nullptr;  // same layout in bf16 (filled by Detector::set_precision)
+  std::vector<float> host; // the f32 layout, kept for the bf16 conversion
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
   int cin = 0, cout = 0, ks = 0;
@@ -41,6 +43,10 @@ class Detector {
   hipStream_t stream() const { return stream_; }
   int device() const { return device_; }
   void synchronize();
+  // 0: f32 everywhere (default).  1: trunk / FPN activations and conv weights in bf16, f32 accumulate,
+  // f32 folded batch norm, f32 probability head (BASELINE config 5).
+  void set_precision(int precision);
+  int precision() const { return bf16_ ? 1 : 0; }
   // device pointers; enqueues on stream().  prof != null -> per-launch events.
   void forward(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                std::vector<ProfileEntry>* prof);
@@ -71,10 +77,15 @@ class Detector {
   bool fused_tail_ = true;    // OCR_TAIL_UNFUSED=1 keeps the two-kernel head (A/B and debugging)
   float tr2_bias_ = 0.f;
 
+  bool bf16_ = false;
   int ws_n_ = 0, ws_h_ = 0, ws_w_ = 0;
+  bool ws_bf16_ = false;
   std::vector<void*> ws_allocs_;
-  float *s_ = nullptr, *t_[4] = {}, *a_[4] = {}, *d_[4] = {}, *x_[4] = {};
-  float *i_[4] = {}, *sum_[3] = {}, *p_[4] = {}, *pcat_ = nullptr, *b1_ = nullptr, *tr1buf_ = nullptr;
+  // activations are f32 or bf16 depending on the precision (b1_, tr1buf_ are always f32)
+  char *s_ = nullptr, *t_[4] = {}, *a_[4] = {}, *d_[4] = {}, *x_[4] = {};
+  char *i_[4] = {}, *sum_[3] = {}, *p_[4] = {}, *pcat_ = nullptr;
+  float *b1_ = nullptr, *tr1buf_ = nullptr;
+  std::vector<ConvW*> all_convs_;
   size_t pcat_bytes_ = 0;
   void forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                      std::vector<ProfileEntry>* prof);

@@ -26,9 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // a compile-time tap offset - and the 49x64 weights sit in registers (50 per lane).
 // grid (Wp/TPW, Hp/TPH, N), 256 threads; the 10 (pixel tile, channel half) units are dealt to the
 // 4 waves round-robin.  BN + ReLU on the accumulators, conv tile to LDS, then the 3x3 s2 max pool.
+template <typename TO>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
-                                                   float* __restrict__ out, int H, int W) {
+                                                   TO* __restrict__ out, int H, int W) {
   __shared__ __attribute__((aligned(16))) float in_s[IR * ICP];
   __shared__ float conv_s[NPIX][64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, conv_s[(2 * py + dy) * CC + 2 * px + dx][ch]);
-      out[(((size_t)n * Hp + ph) * Wp + pw) * 64 + ch] = m;
+      out[(((size_t)n * Hp + ph) * Wp + pw) * 64 + ch] = (TO)m;
     }
   }
 }
@@ -146,12 +147,13 @@ __global__ __launch_bounds__(256) void binarize_kernel(const float* __restrict__
 
 }  // namespace
 
-void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias, float* out, int N,
+void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias, void* out, int out_bf16, int N,
                  int H, int W, hipStream_t s) {
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
   dim3 grid((Wp + TPW - 1) / TPW, (Hp + TPH - 1) / TPH, N);
-  hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, s, x, w49x64, scale, bias, out, H, W);
+  if (out_bf16) hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(256), 0, s, x, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
+  else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, x, w49x64, scale, bias, static_cast<float*>(out), H, W);
   OCR_HIP(hipGetLastError());
 }
 

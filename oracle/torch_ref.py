@@ -93,6 +93,67 @@ def det_forward(params: Dict[str, np.ndarray], x: np.ndarray, stages: dict | Non
         return torch.sigmoid(y).numpy()
 
 
+def det_forward_bf16(params: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray:
+    """The OCR_PRECISION_BF16 arithmetic of the product, restated (there is no reference behaviour to
+    match: the reference is f32 only; BASELINE config 5 names bf16 as an optional precision):
+    every conv from layer1 to bin_conv1 takes operands rounded to bf16 (activations and weights),
+    accumulates in f32, applies folded batch norm / residual / ReLU in f32 and stores bf16; the FPN
+    top-down sums are stored bf16 too; the stem's conv and everything after bin_conv1 are f32.
+    Differences to the product: accumulation order only (then a bf16 rounding may flip by one ulp)."""
+    p = _t(params)
+
+    def q(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    def conv(t, name, stride=1, pad=0):
+        return F.conv2d(t, q(p[name]), None, stride, pad)
+
+    def block(t, prefix, stride):
+        y = q(F.relu(_bn(conv(t, prefix + ".conv1.weight", stride, 1), p, prefix + ".bn1")))
+        y = _bn(conv(y, prefix + ".conv2.weight", 1, 1), p, prefix + ".bn2")
+        if (prefix + ".downsample.0.weight") in p:
+            d = q(_bn(conv(t, prefix + ".downsample.0.weight", stride, 0), p, prefix + ".downsample.1"))
+        else:
+            d = t
+        return q(F.relu(y + d))
+
+    with torch.no_grad():
+        xs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        s = F.conv2d(xs, p["conv1.weight"], None, 2, 3)
+        s = q(F.max_pool2d(F.relu(_bn(s, p, "bn1")), 3, 2, 1, 1, False))
+        feats = []
+        cur = s
+        for li in range(1, 5):
+            cur = block(cur, f"layer{li}.0", 1 if li == 1 else 2)
+            cur = block(cur, f"layer{li}.1", 1)
+            feats.append(cur)
+        x1, x2, x3, x4 = feats
+
+        def up(t, k):
+            return F.interpolate(t, scale_factor=k, mode="nearest")
+
+        # laterals: the raw in3..in5 are stored bf16; each sum is formed from the f32 conv result plus
+        # the bf16-stored upper lateral and stored bf16 (conv_igemm's out2)
+        i5 = q(conv(x4, "in5.weight"))
+        i4f = conv(x3, "in4.weight")
+        i3f = conv(x2, "in3.weight")
+        i2f = conv(x1, "in2.weight")
+        i4, i3 = q(i4f), q(i3f)
+        s4 = q(i4f + up(i5, 2))
+        s3 = q(i3f + up(i4, 2))
+        s2 = q(i2f + up(i3, 2))
+        p2 = q(conv(s2, "out2.weight", 1, 1))
+        p3 = up(q(conv(s3, "out3.weight", 1, 1)), 2)
+        p4 = up(q(conv(s4, "out4.weight", 1, 1)), 4)
+        p5 = up(q(conv(i5, "out5.weight", 1, 1)), 8)
+        fuse = torch.cat([p5, p4, p3, p2], 1)
+        y = F.relu(_bn(conv(fuse, "bin_conv1.weight", 1, 1), p, "bin_bn1"))   # f32 out
+        y = F.conv_transpose2d(y, p["bin_conv_tr1.weight"], p["bin_conv_tr1.bias"], 2, 0)
+        y = F.relu(_bn(y, p, "bin_bn2"))
+        y = F.conv_transpose2d(y, p["bin_conv_tr2.weight"], p["bin_conv_tr2.bias"], 2, 0)
+        return torch.sigmoid(y).numpy()
+
+
 def rec_forward(params: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray:
     """Net::forward_t(xs, train=false), char_recognition/model.rs:27-39 -> N x 62 logits."""
     p = _t(params)

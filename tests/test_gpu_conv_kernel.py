@@ -1,0 +1,125 @@
+"""Kernel-level parity of conv_igemm (the dominant kernel) through the ocr_test_conv_run hook:
+one launch on caller data against ATen-CPU conv2d on the same operands.
+
+f32: relative 2e-5 of the layer's scale (accumulation order + FMA contraction only).
+bf16 (OCR_PRECISION_BF16): operands are rounded to bf16 on the way in, so the reference is computed from
+the same rounded operands with f32 accumulation; what is left is accumulation order, which can move a
+result across a bf16 rounding boundary: at most one bf16 ulp, at a small fraction of the elements.
+(End-to-end bit-level emulation of the bf16 network is not a usable bar: the stack of roundings is chaotic -
+a 1e-6 relative change of the input frame moves the emulated map by 9e-3, see tests/test_gpu_bf16.py.)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ocr_rs_amd  # noqa: F401
+from ocr_rs_amd import capi
+from ocr_rs_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det():
+    d = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)
+    yield d
+    d.close()
+
+
+def _q(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _ref(x, wg, stride, scale, bias, residual, up_residual, relu):
+    """x: N H W C, wg: O (kh kw) I -> (out, out2) NHWC, f32 accumulate."""
+    cout, kk, cin = wg.shape
+    ks = int(round(kk ** 0.5))
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(wg).reshape(cout, ks, ks, cin).permute(0, 3, 1, 2)
+    y = F.conv2d(xt, wt, None, stride, (ks - 1) // 2)
+    if scale is not None:
+        y = y * torch.from_numpy(scale).view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + torch.from_numpy(bias).view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + torch.from_numpy(residual).permute(0, 3, 1, 2)
+    if relu:
+        y = F.relu(y)
+    y2 = None
+    if up_residual is not None:
+        u = F.interpolate(torch.from_numpy(up_residual).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+        y2 = (y + u).permute(0, 2, 3, 1).contiguous().numpy()
+    return y.permute(0, 2, 3, 1).contiguous().numpy(), y2
+
+
+def _check(got, ref, bf16_out):
+    scale = float(np.abs(ref).max()) + 1e-12
+    if not bf16_out:
+        assert float(np.abs(got - ref).max()) / scale < 2e-5
+        return
+    refq = _q(ref)
+    # one bf16 ulp of the reference value (8 significand bits) + f32 accumulation slack near zero
+    tol = np.abs(refq) * 2.0 ** -7 + 1e-5 * scale
+    diff = np.abs(got - refq)
+    assert (diff <= tol).all(), float((diff - tol).max())
+    assert float((diff > 1e-5 * scale).mean()) < 0.01   # flips are rare
+
+
+CASES = [
+    # n, h, w, cin, cout, ks, stride, bn, residual, up, relu, want_out
+    (1, 10, 14, 64, 64, 3, 1, True, True, False, True, True),       # basic_block conv2 + identity, ragged M
+    (2, 18, 22, 64, 128, 3, 2, True, False, False, True, True),     # strided conv1 of layer2.0, odd output grid
+    (2, 18, 22, 64, 128, 1, 2, True, False, False, False, True),    # downsample 1x1 s2
+    (1, 12, 20, 128, 256, 1, 1, False, False, True, False, True),   # lateral in3 + top-down sum (two outputs)
+    (1, 12, 20, 64, 256, 1, 1, False, False, True, False, False),   # lateral in2: only the sum is stored
+    (1, 9, 7, 256, 64, 3, 1, False, False, False, False, True),     # out2..5
+    (1, 12, 12, 512, 256, 1, 1, False, False, False, False, True),  # in5
+    (4, 256, 256, 64, 64, 3, 1, True, True, False, True, True),     # full-size tile (128x64) and XCD remap
+    (8, 128, 128, 128, 256, 1, 1, False, False, True, False, True), # 128x128 tile with both outputs
+]
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_conv_matches_aten(det, case, bf16):
+    n, h, w, cin, cout, ks, stride, bn, has_res, has_up, relu, want_out = case
+    rng = np.random.default_rng(hash(case[:7]) & 0xFFFF)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wg = (rng.standard_normal((cout, ks * ks, cin), dtype=np.float32) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    pad = (ks - 1) // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+    up = rng.standard_normal((n, ho // 2, wo // 2, cout), dtype=np.float32) if has_up else None
+    if bf16:
+        x, wg = _q(x), _q(wg)
+        res = _q(res) if res is not None else None
+        up = _q(up) if up is not None else None
+    out, out2 = det.debug_conv_run(x, wg, stride, scale, bias, res, up, relu, None, bf16, bf16, want_out, has_up)
+    ref, ref2 = _ref(x, wg, stride, scale, bias, res, up, relu)
+    if want_out:
+        _check(out, ref, bf16)
+    if has_up:
+        _check(out2, ref2, bf16)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_cat4_conv_matches_aten(det, bf16):
+    """bin_conv1 over the virtual concat [up8(p5), up4(p4), up2(p3), p2] (model.rs:139-146): the kernel
+    gathers the four levels itself; bf16 operands still give an f32 result (it feeds the f32 head)."""
+    n, h, w = 2, 16, 24
+    rng = np.random.default_rng(5)
+    lv = [rng.standard_normal((n, h >> s, w >> s, 64), dtype=np.float32) for s in (3, 2, 1, 0)]   # p5, p4, p3, p2
+    wg = (rng.standard_normal((64, 9, 256), dtype=np.float32) / 48.0).astype(np.float32)
+    scale = 0.5 + rng.random(64, dtype=np.float32)
+    bias = rng.standard_normal(64, dtype=np.float32)
+    if bf16:
+        lv, wg = [_q(a) for a in lv], _q(wg)
+    flat = np.concatenate([a.ravel() for a in lv])
+    out, _ = det.debug_conv_run(flat, wg, 1, scale, bias, None, None, True, (n, h, w), bf16, False)
+    ups = [np.repeat(np.repeat(a, 8 >> i, axis=1), 8 >> i, axis=2) for i, a in enumerate(lv)]
+    fuse = np.concatenate(ups, axis=3)
+    ref, _ = _ref(fuse, wg, 1, scale, bias, None, None, True)
+    _check(out, ref, False)
