@@ -39,7 +39,9 @@ struct Error : std::runtime_error {
 // ---- kernel launch descriptors ------------------------------------------------
 
 enum SrcMode { SRC_PLAIN = 0, SRC_CAT4 = 2 };
-enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1 };
+// STORE_PHASE2: the conv is the low-res form of "3x3 conv of a nearest-x2-upsampled tensor": ks = 2, four
+// weight sets [phase = 2a+b][Cout][2x2][Cin], output pixel (2i+a, 2j+b) of a [N][2Ho][2Wo][Cout] tensor.
+enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_PHASE2 = 2 };
 
 // One convolution as an implicit GEMM: M = N*Ho*Wo pixels, N = Cout, K = ks*ks*Cin.
 // Activations are NHWC f32, weights [Cout][ks*ks][Cin] f32.

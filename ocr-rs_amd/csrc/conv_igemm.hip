@@ -81,6 +81,7 @@ struct ConvArgs {
   int relu;
   int nblk_n;   // Cout / BN
   int nblk;     // total blocks
+  int nblk_m;   // tiles along M (PHASE2: per phase; the grid holds 4 phases)
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
 };
 
@@ -100,7 +101,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
-constexpr int ROWB = 128;                 // bytes of K per LDS row (one cache line): 32 f32 or 64 bf16
+[[maybe_unused]] constexpr int ROWB = 128;                 // bytes of K per LDS row (one cache line): 32 f32 or 64 bf16
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;     // voffset beyond any tensor (< 2^31 bytes): reads as zero
 
 template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
@@ -123,7 +124,17 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 
   const int bid = xcd_remap(blockIdx.x, p.nblk);
   const int tile_n = bid % p.nblk_n;
-  const int tile_m = bid / p.nblk_n;
+  int tile_m = bid / p.nblk_n;
+  // PHASE2 (3x3 conv of a nearest-x2-upsampled tensor, computed on the low-res grid): output pixel
+  // (2i+pa, 2j+pb) sees the 2x2 low-res neighbourhood rows i-1+pa.., cols j-1+pb.. with that phase's
+  // pre-summed weights; the four phases are four quarters of the grid.
+  int ph = 0, pa = 0, pb = 0;
+  if constexpr (STORE == STORE_PHASE2) {
+    ph = tile_m / p.nblk_m;
+    tile_m -= ph * p.nblk_m;
+    pa = ph >> 1;
+    pb = ph & 1;
+  }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -144,8 +155,8 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       const int rem = m - n * HoWo;
       const int oh = fast_div(rem, p.mg_wo, p.sh_wo);
       const int ow = rem - oh * p.Wo;
-      ih0[i] = oh * STRIDE - p.pad;
-      iw0[i] = ow * STRIDE - p.pad;
+      ih0[i] = oh * STRIDE - p.pad + pa;
+      iw0[i] = ow * STRIDE - p.pad + pb;
       if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; the pixel offset depends on the source
       else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin * EB + gq * 16;  // bytes
     } else {
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   }
   unsigned bvoff[BI];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)((n0 + r + 32 * i) * (KS * KS) * p.Cin * EB + gq * 16);
+  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)((ph * p.Cout + n0 + r + 32 * i) * (KS * KS) * p.Cin * EB + gq * 16);
 
   // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
   // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
@@ -347,20 +358,21 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         for (int e = 0; e < 16; ++e)
           tile[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq) * BN + wn * WN + j * 32 + colq] = acc[i][j][e];
   }
-  if (tid < BM && (STORE == STORE_SHUFFLE2 || p.out2)) {
+  if (tid < BM && (STORE != STORE_NHWC || p.out2)) {
     const int m = min(m0 + tid, p.M - 1);
     const int n = m / HoWo;
     const int rem = m - n * HoWo;
     const int oh = rem / p.Wo;
     const int ow = rem - oh * p.Wo;
     if constexpr (STORE == STORE_SHUFFLE2) row_aux[tid] = ((n * (2 * p.Ho) + 2 * oh) * (2 * p.Wo) + 2 * ow) * 64;
+    else if constexpr (STORE == STORE_PHASE2) row_aux[tid] = ((n * (2 * p.Ho) + 2 * oh + pa) * (2 * p.Wo) + 2 * ow + pb) * p.Cout;
     else row_aux[tid] = ((n * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1)) * p.Cout;
   }
   __syncthreads();
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = zero4;
   if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
   if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + col);
-  if constexpr (STORE == STORE_NHWC) {
+  if constexpr (STORE != STORE_SHUFFLE2) {
     constexpr int G = PASSES < 4 ? PASSES : 4;  // rows in flight per thread: bounds the staging registers
 #pragma unroll
     for (int k0 = 0; k0 < PASSES; k0 += G) {
@@ -370,7 +382,8 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         const int rr = rr0 + (k0 + k) * RPP;
         const int m = min(m0 + rr, p.M - 1);
         up[k] = p.out2 ? Elem<TO>::load4(p.up_residual, (size_t)row_aux[rr] + col) : zero4;
-        res[k] = p.residual ? Elem<TO>::load4(p.residual, (size_t)m * p.Cout + col) : zero4;
+        const size_t ro = STORE == STORE_PHASE2 ? (size_t)row_aux[rr] + col : (size_t)m * p.Cout + col;
+        res[k] = p.residual ? Elem<TO>::load4(p.residual, ro) : zero4;
       }
 #pragma unroll
       for (int k = 0; k < G; ++k) {
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
           for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
         }
         if (m < p.M) {
-          const size_t o = (size_t)m * p.Cout + col;
+          const size_t o = STORE == STORE_PHASE2 ? (size_t)row_aux[rr] + col : (size_t)m * p.Cout + col;
           if (p.out) Elem<TO>::store4(p.out, o, v);
           if (p.out2) Elem<TO>::store4(p.out2, o, up[k] + v);  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
         }
@@ -441,8 +454,8 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.pad = d.pad;
   a.relu = d.relu;
   a.nblk_n = d.Cout / BN;
-  const int nblk_m = (a.M + BM - 1) / BM;
-  a.nblk = nblk_m * a.nblk_n;
+  a.nblk_m = (a.M + BM - 1) / BM;
+  a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE2 ? 4 : 1);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
   static const int extra_lds = getenv("OCR_CONV_EXTRA_LDS") ? atoi(getenv("OCR_CONV_EXTRA_LDS")) : 0;  // tuning knob: caps residency
@@ -460,17 +473,27 @@ static void check(const ConvDesc& d) {
   const int bk = 128 / eb;
   if (d.Cin % bk != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, bk);
   if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
-  if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
-  if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);
-  if (d.pad != (d.ks - 1) / 2) fail(OCR_ERR_INVALID, "%s: pad %d", d.name, d.pad);
-  if (d.Ho != (d.Hin + 2 * d.pad - d.ks) / d.stride + 1 || d.Wo != (d.Win + 2 * d.pad - d.ks) / d.stride + 1)
-    fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
+  const bool phase2 = d.store_mode == STORE_PHASE2;
+  if (phase2) {
+    // four 2x2 phase convs on the low-res grid: out is [N][2 Ho][2 Wo][Cout], wgt [4][Cout][2x2][Cin]
+    if (d.ks != 2 || d.stride != 1 || d.pad != 1 || d.Ho != d.Hin || d.Wo != d.Win || d.out2 || d.src_mode != SRC_PLAIN || !d.out)
+      fail(OCR_ERR_INVALID, "%s: PHASE2 store needs a 2x2 s1 pad-1 conv on the low-res grid", d.name);
+    if ((long long)d.N * d.Ho * d.Wo * 4 * d.Cout >= (1ll << 31))
+      fail(OCR_ERR_INVALID, "%s: PHASE2 output too large", d.name);
+  } else {
+    if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
+    if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);
+    if (d.pad != (d.ks - 1) / 2) fail(OCR_ERR_INVALID, "%s: pad %d", d.name, d.pad);
+    if (d.Ho != (d.Hin + 2 * d.pad - d.ks) / d.stride + 1 || d.Wo != (d.Win + 2 * d.pad - d.ks) / d.stride + 1)
+      fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
+  }
   if ((long long)d.N * d.Ho * d.Wo >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: M overflows int", d.name);
   // the kernel addresses its operands with 32-bit BYTE offsets below the out-of-range marker 2^31
   const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)d.N * d.Hin * d.Win * d.Cin * eb;
   if (in_bytes >= (1ll << 31) || (long long)d.src_bytes >= (1ll << 31) || (long long)d.src_bytes < in_bytes)
     fail(OCR_ERR_INVALID, "%s: input of %lld bytes (addressable %zu) must be < 2^31 bytes; split the batch", d.name, in_bytes, d.src_bytes);
-  if ((long long)d.wgt_bytes != (long long)d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if ((long long)d.wgt_bytes != (long long)(phase2 ? 4 : 1) * d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if ((long long)d.wgt_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: weights too large", d.name);
   if (d.src_mode != SRC_PLAIN && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: source mode %d", d.name, d.src_mode);
   if (d.src_mode == SRC_CAT4) {
     if (d.Cin != 256 || ((d.Hin | d.Win) & 7) || d.ks != 3 || d.stride != 1 || d.Cout != 64)
@@ -496,7 +519,8 @@ static void check(const ConvDesc& d) {
 enum Tile { T128x128, T128x64, T64x64 };
 static Tile pick_tile(const ConvDesc& d) {
   const long long M = (long long)d.N * d.Ho * d.Wo;
-  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn); };
+  const int reps = d.store_mode == STORE_PHASE2 ? 4 : 1;
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
   if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
   if (blocks(128, 64) >= 2048) return T128x64;
   return T64x64;
@@ -507,7 +531,7 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
   snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
-           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : "");
+           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE2 ? ",PHASE2" : "");
   // names must outlive the call: intern them
   static thread_local std::vector<std::string>* pool = new std::vector<std::string>();
   for (const auto& s : *pool)
@@ -529,6 +553,7 @@ static void launch_tiles(const ConvDesc& d, hipStream_t s) {
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
   if (d.in_bf16) {
+    if (d.store_mode == STORE_PHASE2) return launch_tiles<__bf16, __bf16, 2, 1, SRC_PLAIN, STORE_PHASE2>(d, s);
     if (d.src_mode == SRC_CAT4) return launch_tiles<__bf16, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 1) return launch_tiles<__bf16, __bf16, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 2) return launch_tiles<__bf16, __bf16, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
@@ -537,6 +562,7 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
     fail(OCR_ERR_INVALID, "%s: no bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
   }
   if (d.store_mode == STORE_SHUFFLE2) return launch_tiles<float, float, 1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s);
+  if (d.store_mode == STORE_PHASE2) return launch_tiles<float, float, 2, 1, SRC_PLAIN, STORE_PHASE2>(d, s);
   if (d.src_mode == SRC_CAT4) return launch_tiles<float, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
   if (d.ks == 3 && d.stride == 1) return launch_tiles<float, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
   if (d.ks == 3 && d.stride == 2) return launch_tiles<float, float, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);

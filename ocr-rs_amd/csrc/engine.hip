@@ -78,12 +78,73 @@ ConvW Detector::make_conv(const WeightBlob& wb, const std::string& wname, const 
   return cw;
 }
 
+// out (3x3, 256 -> 64, OHWI) after in (1x1, cin -> 256): T[o][tap][i] = sum_c out[o][tap][c] * in[c][i], in f64
+static std::vector<double> compose_taps(const ConvW& out, const ConvW& in) {
+  const int cin = in.cin, mid = out.cin;
+  std::vector<double> t((size_t)out.cout * 9 * cin, 0.0);
+  for (int o = 0; o < out.cout; ++o)
+    for (int k = 0; k < 9; ++k) {
+      double* row = &t[((size_t)o * 9 + k) * cin];
+      const float* ow = &out.host[((size_t)o * 9 + k) * mid];
+      for (int c = 0; c < mid; ++c) {
+        const double a = ow[c];
+        const float* iw = &in.host[(size_t)c * cin];
+        for (int i = 0; i < cin; ++i) row[i] += a * (double)iw[i];
+      }
+    }
+  return t;
+}
+
+ConvW Detector::finish_composed(std::vector<float>&& t, int cout, int cin, int ks) {
+  ConvW cw;
+  cw.w = arena_.upload(t);
+  cw.w_bytes = t.size() * sizeof(float);
+  cw.host = std::move(t);
+  cw.cin = cin;
+  cw.cout = cout;
+  cw.ks = ks;
+  return cw;
+}
+
+// A_k = out_k o in_k
+ConvW Detector::compose_lateral(const ConvW& out, const ConvW& in) {
+  const std::vector<double> t = compose_taps(out, in);
+  return finish_composed(std::vector<float>(t.begin(), t.end()), out.cout, in.cin, 3);
+}
+
+// B_k: a 3x3 conv of the nearest-x2 upsample of z = in_up(x) seen from the low-res grid.  High-res row
+// 2i+a with tap dy reads high-res row 2i+a+dy-1, i.e. low-res row (2i+a+dy-1) >> 1:
+//   a = 0: dy 0 -> row i-1 (tap 0);  dy 1, 2 -> row i   (tap 1)
+//   a = 1: dy 0, 1 -> row i (tap 0); dy 2    -> row i+1 (tap 1)
+// (same for columns), and zero padding of the high-res tensor is zero padding of the low-res one.
+// Layout [phase = 2a+b][cout][2x2][cin].
+ConvW Detector::compose_upsampled(const ConvW& out, const ConvW& in_up) {
+  const std::vector<double> t = compose_taps(out, in_up);
+  const int cin = in_up.cin, cout = out.cout;
+  std::vector<float> w((size_t)4 * cout * 4 * cin);
+  auto tap_of = [](int phase_bit, int d) { return phase_bit == 0 ? (d == 0 ? 0 : 1) : (d == 2 ? 1 : 0); };
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int o = 0; o < cout; ++o) {
+        std::vector<double> acc((size_t)4 * cin, 0.0);
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx) {
+            const int tp = tap_of(a, dy) * 2 + tap_of(b, dx);
+            const double* src = &t[((size_t)o * 9 + dy * 3 + dx) * cin];
+            for (int i = 0; i < cin; ++i) acc[(size_t)tp * cin + i] += src[i];
+          }
+        float* dst = &w[(((size_t)(a * 2 + b) * cout + o) * 4) * cin];
+        for (size_t i = 0; i < acc.size(); ++i) dst[i] = (float)acc[i];
+      }
+  return finish_composed(std::move(w), cout, cin, 2);
+}
+
 Detector::Detector(const void* blob, size_t bytes, int device) : device_(device) {
   check_device(device);
   WeightBlob wb(blob, bytes);
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-  arena_.reserve((size_t)96 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
+  arena_.reserve((size_t)104 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -114,6 +175,15 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     in_[l] = make_conv(wb, "in" + std::to_string(l + 2) + ".weight", "", 256, 64 << l, 1);
     out_[l] = make_conv(wb, "out" + std::to_string(l + 2) + ".weight", "", 64, 256, 3);
   }
+  {
+    const char* e = getenv("OCR_FPN_UNFUSED");
+    fpn_composed_ = !(e && e[0] == '1');
+  }
+  if (fpn_composed_)
+    for (int l = 0; l < 2; ++l) {
+      fpn_a_[l] = compose_lateral(out_[l], in_[l]);
+      fpn_b_[l] = compose_upsampled(out_[l], in_[l + 1]);
+    }
   bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
   {  // bin_conv_tr1 [Cin=64][Cout=64][2][2] + bias, then bin_bn2:
      // GEMM B rows = (a*2+b)*64 + co over K = ci; (acc + bias)*s + t = acc*s + (bias*s + t)
@@ -159,6 +229,11 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     all_convs_.push_back(&out_[l]);
   }
   all_convs_.push_back(&bin1_);
+  if (fpn_composed_)
+    for (int l = 0; l < 2; ++l) {
+      all_convs_.push_back(&fpn_a_[l]);
+      all_convs_.push_back(&fpn_b_[l]);
+    }
   {
     const char* e = getenv("OCR_DET_PRECISION");
     if (e && std::string(e) == "bf16") set_precision(1);
@@ -249,8 +324,12 @@ void Detector::ensure_workspace(int n, int h, int w) {
     a_[l] = alloc(px * c * es);
     x_[l] = alloc(px * c * es);
     d_[l] = l > 0 ? alloc(px * c * es) : nullptr;
-    i_[l] = l > 0 ? alloc(px * 256 * es) : nullptr;   // raw lateral in3..in5 (in2 is only ever used inside its sum)
-    if (l < 3) sum_[l] = alloc(px * 256 * es);        // up2(in_{k+1}) + in_k
+    // raw lateral in3..in5 (in2 is only ever used inside its sum) and the sums up2(in_{k+1}) + in_k; with
+    // the composed FPN only in5 and the level-4 sum are ever materialised
+    const bool need_i = fpn_composed_ ? l == 3 : l > 0;
+    const bool need_sum = fpn_composed_ ? l == 2 : l < 3;
+    i_[l] = need_i ? alloc(px * 256 * es) : nullptr;
+    if (l < 3) sum_[l] = need_sum ? alloc(px * 256 * es) : nullptr;
     p_[l] = pcat_ + pofs * es;
     pofs += px * 64;
   }
@@ -351,9 +430,9 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.Cin = cw.cin;
     d.ks = cw.ks;
     d.stride = stride;
-    d.pad = (cw.ks - 1) / 2;
-    d.Ho = (hin + 2 * d.pad - cw.ks) / stride + 1;
-    d.Wo = (win + 2 * d.pad - cw.ks) / stride + 1;
+    d.pad = ex.store == STORE_PHASE2 ? 1 : (cw.ks - 1) / 2;
+    d.Ho = ex.store == STORE_PHASE2 ? hin : (hin + 2 * d.pad - cw.ks) / stride + 1;
+    d.Wo = ex.store == STORE_PHASE2 ? win : (win + 2 * d.pad - cw.ks) / stride + 1;
     d.Cout = cw.cout;
     d.wgt = in_bf ? cw.w_bf16 : static_cast<const void*>(cw.w);
     d.scale = cw.scale;
@@ -368,11 +447,12 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     rec.begin();
     launch_conv_igemm(d, stream_);
     const double M = (double)n * d.Ho * d.Wo;
-    const double K = (double)cw.ks * cw.ks * cw.cin;
+    const double reps = ex.store == STORE_PHASE2 ? 4.0 : 1.0;  // four phase convs per low-res pixel
+    const double K = (double)cw.ks * cw.ks * cw.cin * reps;
     double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
     if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
     const double oes = d.out_bf16 ? 2.0 : 4.0;
-    double out_bytes = M * cw.cout * oes * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
+    double out_bytes = M * reps * cw.cout * oes * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
                                             (ex.up_residual ? 0.25 : 0.0));
     rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, in_bytes + out_bytes + K * cw.cout * (double)ies);
   };
@@ -406,15 +486,35 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   // FPN laterals in5..in2 (model.rs:115-123), coarse to fine; each also emits the top-down sum
   // up2(in_{k+1}) + in_k that the out_k conv consumes (model.rs:126-137)
   conv("in5", in_[3], x_[3], h >> 5, w >> 5, 1, i_[3], false);
-  for (int l = 2; l >= 0; --l) {
-    Extra td;
-    td.up_residual = i_[l + 1];
-    td.out2 = sum_[l];
-    conv("in+topdown", in_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, l > 0 ? i_[l] : nullptr, false, td);
+  if (fpn_composed_) {
+    {
+      Extra td;
+      td.up_residual = i_[3];
+      td.out2 = sum_[2];
+      conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
+    }
+    conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
+    conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
+    // p3, p2 = A_k * x_k + B_k *' x_{k+1}: the upsampled term first (phase store), the lateral term on top
+    for (int l = 1; l >= 0; --l) {
+      Extra up;
+      up.store = STORE_PHASE2;
+      conv("fpn.upsampled", fpn_b_[l], x_[l + 1], h >> (3 + l), w >> (3 + l), 1, p_[l], false, up);
+      Extra lat;
+      lat.residual = p_[l];
+      conv("fpn.lateral", fpn_a_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], false, lat);
+    }
+  } else {
+    for (int l = 2; l >= 0; --l) {
+      Extra td;
+      td.up_residual = i_[l + 1];
+      td.out2 = sum_[l];
+      conv("in+topdown", in_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, l > 0 ? i_[l] : nullptr, false, td);
+    }
+    // p_k = out_k(up2(in_{k+1}) + in_k), p5 = out5(in5), model.rs:126-138
+    for (int l = 0; l < 3; ++l) conv("out", out_[l], sum_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], false);
+    conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   }
-  // p_k = out_k(up2(in_{k+1}) + in_k), p5 = out5(in5), model.rs:126-138
-  for (int l = 0; l < 3; ++l) conv("out", out_[l], sum_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], false);
-  conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
   {
     Extra c4;
@@ -452,6 +552,8 @@ const float* Detector::stage(int id, size_t* elems) const {
   auto px = [&](int shift) { return N * (ws_h_ >> shift) * (ws_w_ >> shift); };
   if (id == 0) { *elems = px(2) * 64; return f(s_); }
   if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return f(x_[id - 1]); }
+  if (id >= 5 && id <= 8 && !(id == 5 ? sum_[0] : i_[id - 5]))
+    fail(OCR_ERR_INVALID, "stage %d is not materialised by the composed FPN (OCR_FPN_UNFUSED=1 keeps it)", id);
   if (id == 5) { *elems = px(2) * 256; return f(sum_[0]); }  // in2 only exists inside its top-down sum
   if (id >= 6 && id <= 8) { *elems = px(id - 3) * 256; return f(i_[id - 5]); }
   if (id >= 9 && id <= 12) { *elems = px(id - 7) * 64; return f(p_[id - 9]); }

@@ -70,6 +70,15 @@ class Detector {
   ConvW layer_[4][2][2];  // [layer][block][conv1|conv2]
   ConvW down_[4];         // [layer] (layer 0 unused)
   ConvW in_[4];           // in2..in5
+  // p2 / p3 with the lateral folded into the 3x3 conv (both linear, nothing in between):
+  //   out_k(up2(in_{k+1}(x_{k+1})) + in_k(x_k)) = A_k * x_k + B_k *' x_{k+1}
+  // A_k = out_k o in_k (3x3, C_k -> 64); B_k = out_k o up2 o in_{k+1} as four 2x2 phase convs on the
+  // low-res grid (C_{k+1} -> 64).  [0] = p2, [1] = p3.
+  ConvW fpn_a_[2], fpn_b_[2];
+  ConvW finish_composed(std::vector<float>&& t, int cout, int cin, int ks);
+  ConvW compose_lateral(const ConvW& out, const ConvW& in);
+  ConvW compose_upsampled(const ConvW& out, const ConvW& in_up);
+  bool fpn_composed_ = true;  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;
