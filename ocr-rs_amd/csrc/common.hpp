@@ -39,9 +39,10 @@ struct Error : std::runtime_error {
 // ---- kernel launch descriptors ------------------------------------------------
 
 enum SrcMode { SRC_PLAIN = 0, SRC_CAT4 = 2 };
-// STORE_PHASE2: the conv is the low-res form of "3x3 conv of a nearest-x2-upsampled tensor": ks = 2, four
-// weight sets [phase = 2a+b][Cout][2x2][Cin], output pixel (2i+a, 2j+b) of a [N][2Ho][2Wo][Cout] tensor.
-enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_PHASE2 = 2 };
+// STORE_PHASE: the conv is the low-res form of "3x3 conv of a nearest-x-up upsampled tensor" (up = 2, 4, 8):
+// ks = 2, up*up weight sets [phase = up a + b][Cout][2x2][Cin], output pixel (up i + a, up j + b) of a
+// [N][up Ho][up Wo][Cout] tensor; the 2x2 window starts at row i-1 for a = 0 and at row i otherwise.
+enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_PHASE = 2 };
 
 // One convolution as an implicit GEMM: M = N*Ho*Wo pixels, N = Cout, K = ks*ks*Cin.
 // Activations are NHWC f32, weights [Cout][ks*ks][Cin] f32.
@@ -55,6 +56,7 @@ struct ConvDesc {
   int N, Hin, Win, Cin;   // logical input grid of this conv
   int Ho, Wo, Cout;
   int ks, stride, pad;
+  int up;                 // STORE_PHASE: upsampling factor
   const void* wgt;
   const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32
   const float* bias;

@@ -63,6 +63,22 @@ template <> struct Elem<__bf16> {
   static __device__ __forceinline__ void store1(void* base, size_t idx, float v) { static_cast<__bf16*>(base)[idx] = (__bf16)v; }
 };
 
+// One 16-byte-per-lane LDS-DMA load (buffer_load_dwordx4 ... lds): lane l's 16 bytes land at lds_addr + 16 l.
+// Written as inline asm, not __builtin_amdgcn_raw_ptr_buffer_load_lds: for the builtin the compiler knows the
+// load writes LDS and, unable to prove that the operand stage being filled is not the one being read, puts
+// s_waitcnt vmcnt(0) in front of the next ds_read - every wave then sits out the full DMA latency right after
+// issuing it instead of multiplying the resident stage.  Here the ordering is explicit instead: the K loop
+// waits (vmcnt(0)) and barriers before a stage is read, and the "memory" clobber keeps LDS accesses from
+// being moved across the issue.  m0 carries the LDS address; the compiler sets m0 itself before any use of
+// its own, so it is not preserved.
+template <typename R>
+__device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
 struct ConvArgs {
   const void* src;        // PLAIN: the input tensor; CAT4: allocation holding p5,p4,p3,p2   (TI)
   const void* wgt;        //                                                                  (TI)
@@ -81,7 +97,8 @@ struct ConvArgs {
   int relu;
   int nblk_n;   // Cout / BN
   int nblk;     // total blocks
-  int nblk_m;   // tiles along M (PHASE2: per phase; the grid holds 4 phases)
+  int nblk_m;   // tiles along M (PHASE: per phase; the grid holds up*up phases)
+  int up_shift; // PHASE: log2 of the upsampling factor (1, 2, 3)
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
 };
 
@@ -125,15 +142,16 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   const int bid = xcd_remap(blockIdx.x, p.nblk);
   const int tile_n = bid % p.nblk_n;
   int tile_m = bid / p.nblk_n;
-  // PHASE2 (3x3 conv of a nearest-x2-upsampled tensor, computed on the low-res grid): output pixel
-  // (2i+pa, 2j+pb) sees the 2x2 low-res neighbourhood rows i-1+pa.., cols j-1+pb.. with that phase's
-  // pre-summed weights; the four phases are four quarters of the grid.
+  // PHASE (3x3 conv of a nearest-x-up upsampled tensor, computed on the low-res grid): output pixel
+  // (up i + pa, up j + pb) sees a 2x2 low-res neighbourhood - rows i-1, i for pa = 0, rows i, i+1 otherwise
+  // (same for columns) - with that phase's pre-summed weights; the up*up phases are consecutive slices of
+  // the grid.
   int ph = 0, pa = 0, pb = 0;
-  if constexpr (STORE == STORE_PHASE2) {
+  if constexpr (STORE == STORE_PHASE) {
     ph = tile_m / p.nblk_m;
     tile_m -= ph * p.nblk_m;
-    pa = ph >> 1;
-    pb = ph & 1;
+    pa = ph >> p.up_shift;
+    pb = ph & ((1 << p.up_shift) - 1);
   }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
@@ -155,8 +173,8 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       const int rem = m - n * HoWo;
       const int oh = fast_div(rem, p.mg_wo, p.sh_wo);
       const int ow = rem - oh * p.Wo;
-      ih0[i] = oh * STRIDE - p.pad + pa;
-      iw0[i] = ow * STRIDE - p.pad + pb;
+      ih0[i] = oh * STRIDE - p.pad + (pa > 0);
+      iw0[i] = ow * STRIDE - p.pad + (pb > 0);
       if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; the pixel offset depends on the source
       else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin * EB + gq * 16;  // bytes
     } else {
@@ -200,14 +218,13 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       for (int i = 0; i < AI; ++i) avoff[t][i] = tap_offset(s, t, i);
   };
   prep_source(0);
-  auto issue_plain = [&](unsigned char* st, const unsigned (&av)[AI], int tap, int c, int kbase) {
+  const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds + (unsigned)(8 * wave * ROWB);
+  auto issue_plain = [&](int stage, const unsigned (&av)[AI], int tap, int c, int kbase) {
+    const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE));
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(st + (32 * i + 8 * wave) * ROWB), 16, av[i], c * ROWB, 0, 0);
+    for (int i = 0; i < AI; ++i) dma16(a_rsrc, st + 32 * i * ROWB, av[i], c * ROWB);
 #pragma unroll
-    for (int i = 0; i < BI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(st + (BM + 32 * i + 8 * wave) * ROWB), 16, bvoff[i],
-                                               (tap * p.Cin + kbase) * EB + c * ROWB, 0, 0);
+    for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (BM + 32 * i) * ROWB, bvoff[i], (tap * p.Cin + kbase) * EB + c * ROWB);
   };
 
   f32x16 acc[MT][NT];
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   constexpr int NSRC = SRC == SRC_CAT4 ? 4 : 1;
   const int pass_chunks = SRC == SRC_CAT4 ? 64 / BK : csteps;
   int par = 0;  // LDS stage holding the K-step about to be multiplied
-  issue_plain(lds, avoff[0], 0, 0, 0);
+  issue_plain(0, avoff[0], 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int s = 0; s < NSRC; ++s) {
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     for (int c = 0; c < pass_chunks; ++c) {
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
-        unsigned char* nxt = lds + (par ^ 1) * STAGE;
+        const int nxt = par ^ 1;
         // DMA of the next K-step flies while this one is multiplied
         if (t + 1 < NTAP) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c, s * 64);
         else if (c + 1 < pass_chunks) issue_plain(nxt, avoff[0], 0, c + 1, s * 64);
@@ -365,7 +382,8 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     const int oh = rem / p.Wo;
     const int ow = rem - oh * p.Wo;
     if constexpr (STORE == STORE_SHUFFLE2) row_aux[tid] = ((n * (2 * p.Ho) + 2 * oh) * (2 * p.Wo) + 2 * ow) * 64;
-    else if constexpr (STORE == STORE_PHASE2) row_aux[tid] = ((n * (2 * p.Ho) + 2 * oh + pa) * (2 * p.Wo) + 2 * ow + pb) * p.Cout;
+    else if constexpr (STORE == STORE_PHASE)
+      row_aux[tid] = ((((n * p.Ho + oh) << p.up_shift) + pa) * (p.Wo << p.up_shift) + (ow << p.up_shift) + pb) * p.Cout;
     else row_aux[tid] = ((n * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1)) * p.Cout;
   }
   __syncthreads();
@@ -382,7 +400,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         const int rr = rr0 + (k0 + k) * RPP;
         const int m = min(m0 + rr, p.M - 1);
         up[k] = p.out2 ? Elem<TO>::load4(p.up_residual, (size_t)row_aux[rr] + col) : zero4;
-        const size_t ro = STORE == STORE_PHASE2 ? (size_t)row_aux[rr] + col : (size_t)m * p.Cout + col;
+        const size_t ro = STORE == STORE_PHASE ? (size_t)row_aux[rr] + col : (size_t)m * p.Cout + col;
         res[k] = p.residual ? Elem<TO>::load4(p.residual, ro) : zero4;
       }
 #pragma unroll
@@ -395,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
           for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
         }
         if (m < p.M) {
-          const size_t o = STORE == STORE_PHASE2 ? (size_t)row_aux[rr] + col : (size_t)m * p.Cout + col;
+          const size_t o = STORE == STORE_PHASE ? (size_t)row_aux[rr] + col : (size_t)m * p.Cout + col;
           if (p.out) Elem<TO>::store4(p.out, o, v);
           if (p.out2) Elem<TO>::store4(p.out2, o, up[k] + v);  // upsample(x_in{k+1}) + x_in{k}, model.rs:126-137
         }
@@ -455,7 +473,8 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.relu = d.relu;
   a.nblk_n = d.Cout / BN;
   a.nblk_m = (a.M + BM - 1) / BM;
-  a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE2 ? 4 : 1);
+  a.up_shift = d.up == 8 ? 3 : d.up == 4 ? 2 : 1;
+  a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : 1);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
   static const int extra_lds = getenv("OCR_CONV_EXTRA_LDS") ? atoi(getenv("OCR_CONV_EXTRA_LDS")) : 0;  // tuning knob: caps residency
@@ -473,13 +492,14 @@ static void check(const ConvDesc& d) {
   const int bk = 128 / eb;
   if (d.Cin % bk != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, bk);
   if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
-  const bool phase2 = d.store_mode == STORE_PHASE2;
+  const bool phase2 = d.store_mode == STORE_PHASE;
   if (phase2) {
-    // four 2x2 phase convs on the low-res grid: out is [N][2 Ho][2 Wo][Cout], wgt [4][Cout][2x2][Cin]
+    // up*up 2x2 phase convs on the low-res grid: out is [N][up Ho][up Wo][Cout], wgt [up*up][Cout][2x2][Cin]
+    if (d.up != 2 && d.up != 4 && d.up != 8) fail(OCR_ERR_INVALID, "%s: PHASE store with up = %d", d.name, d.up);
     if (d.ks != 2 || d.stride != 1 || d.pad != 1 || d.Ho != d.Hin || d.Wo != d.Win || d.out2 || d.src_mode != SRC_PLAIN || !d.out)
-      fail(OCR_ERR_INVALID, "%s: PHASE2 store needs a 2x2 s1 pad-1 conv on the low-res grid", d.name);
-    if ((long long)d.N * d.Ho * d.Wo * 4 * d.Cout >= (1ll << 31))
-      fail(OCR_ERR_INVALID, "%s: PHASE2 output too large", d.name);
+      fail(OCR_ERR_INVALID, "%s: PHASE store needs a 2x2 s1 pad-1 conv on the low-res grid", d.name);
+    if ((long long)d.N * d.Ho * d.Wo * d.up * d.up * d.Cout >= (1ll << 31))
+      fail(OCR_ERR_INVALID, "%s: PHASE output too large", d.name);
   } else {
     if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
     if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);
@@ -492,7 +512,7 @@ static void check(const ConvDesc& d) {
   const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)d.N * d.Hin * d.Win * d.Cin * eb;
   if (in_bytes >= (1ll << 31) || (long long)d.src_bytes >= (1ll << 31) || (long long)d.src_bytes < in_bytes)
     fail(OCR_ERR_INVALID, "%s: input of %lld bytes (addressable %zu) must be < 2^31 bytes; split the batch", d.name, in_bytes, d.src_bytes);
-  if ((long long)d.wgt_bytes != (long long)(phase2 ? 4 : 1) * d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if ((long long)d.wgt_bytes != (long long)(phase2 ? d.up * d.up : 1) * d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
   if ((long long)d.wgt_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: weights too large", d.name);
   if (d.src_mode != SRC_PLAIN && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: source mode %d", d.name, d.src_mode);
   if (d.src_mode == SRC_CAT4) {
@@ -510,7 +530,8 @@ static void check(const ConvDesc& d) {
   if (d.out2 && (!d.up_residual || ((d.Ho | d.Wo) & 1))) fail(OCR_ERR_INVALID, "%s: out2 needs up_residual and an even grid", d.name);
   if (!d.src[0] || !d.wgt || (!d.out && !d.out2)) fail(OCR_ERR_INVALID, "%s: null operand", d.name);
   if (!d.in_bf16 && d.out_bf16) fail(OCR_ERR_INVALID, "%s: f32 operands with bf16 output is not instantiated", d.name);
-  if (d.in_bf16 && !d.out_bf16 && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: bf16 -> f32 exists for the CAT4 conv only", d.name);
+  if (d.in_bf16 && !d.out_bf16 && d.src_mode != SRC_CAT4 && !(phase2 || (d.ks == 3 && d.stride == 1)))
+    fail(OCR_ERR_INVALID, "%s: bf16 -> f32 exists for the CAT4, 3x3 s1 and PHASE convs only", d.name);
 }
 
 // Tile choice: the largest tile that still leaves >= 8 tiles per CU (256 CUs), so that the
@@ -519,7 +540,7 @@ static void check(const ConvDesc& d) {
 enum Tile { T128x128, T128x64, T64x64 };
 static Tile pick_tile(const ConvDesc& d) {
   const long long M = (long long)d.N * d.Ho * d.Wo;
-  const int reps = d.store_mode == STORE_PHASE2 ? 4 : 1;
+  const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : 1;
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
   if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
   if (blocks(128, 64) >= 2048) return T128x64;
@@ -531,7 +552,7 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
   snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
-           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE2 ? ",PHASE2" : "");
+           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8") : "");
   // names must outlive the call: intern them
   static thread_local std::vector<std::string>* pool = new std::vector<std::string>();
   for (const auto& s : *pool)
@@ -553,7 +574,9 @@ static void launch_tiles(const ConvDesc& d, hipStream_t s) {
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
   if (d.in_bf16) {
-    if (d.store_mode == STORE_PHASE2) return launch_tiles<__bf16, __bf16, 2, 1, SRC_PLAIN, STORE_PHASE2>(d, s);
+    if (d.store_mode == STORE_PHASE && !d.out_bf16) return launch_tiles<__bf16, float, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
+    if (d.store_mode == STORE_PHASE) return launch_tiles<__bf16, __bf16, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
+    if (d.ks == 3 && d.stride == 1 && !d.out_bf16 && d.src_mode == SRC_PLAIN) return launch_tiles<__bf16, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.src_mode == SRC_CAT4) return launch_tiles<__bf16, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 1) return launch_tiles<__bf16, __bf16, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 2) return launch_tiles<__bf16, __bf16, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
@@ -562,7 +585,7 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
     fail(OCR_ERR_INVALID, "%s: no bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
   }
   if (d.store_mode == STORE_SHUFFLE2) return launch_tiles<float, float, 1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s);
-  if (d.store_mode == STORE_PHASE2) return launch_tiles<float, float, 2, 1, SRC_PLAIN, STORE_PHASE2>(d, s);
+  if (d.store_mode == STORE_PHASE) return launch_tiles<float, float, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
   if (d.src_mode == SRC_CAT4) return launch_tiles<float, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
   if (d.ks == 3 && d.stride == 1) return launch_tiles<float, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
   if (d.ks == 3 && d.stride == 2) return launch_tiles<float, float, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);

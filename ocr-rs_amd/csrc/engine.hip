@@ -74,6 +74,7 @@ ConvW Detector::make_conv(const WeightBlob& wb, const std::string& wname, const 
     fold_bn(wb, bn, cout, s, b);
     cw.scale = arena_.upload(s);
     cw.bias = arena_.upload(b);
+    cw.host_scale = s;
   }
   return cw;
 }
@@ -112,31 +113,38 @@ ConvW Detector::compose_lateral(const ConvW& out, const ConvW& in) {
   return finish_composed(std::vector<float>(t.begin(), t.end()), out.cout, in.cin, 3);
 }
 
-// B_k: a 3x3 conv of the nearest-x2 upsample of z = in_up(x) seen from the low-res grid.  High-res row
-// 2i+a with tap dy reads high-res row 2i+a+dy-1, i.e. low-res row (2i+a+dy-1) >> 1:
-//   a = 0: dy 0 -> row i-1 (tap 0);  dy 1, 2 -> row i   (tap 1)
-//   a = 1: dy 0, 1 -> row i (tap 0); dy 2    -> row i+1 (tap 1)
+// A 3x3 conv (taps [cout][9][cin], f64) of the nearest-x-up upsample of a tensor, seen from the low-res
+// grid.  High-res row up i + a with tap dy reads high-res row up i + a + dy - 1, i.e. low-res row
+//   a = 0        : dy 0 -> i-1 (tap 0);  dy 1, 2 -> i (tap 1)            window starts at i-1
+//   0 < a < up-1 : dy 0, 1, 2 -> i (tap 0); tap 1 is empty                window starts at i
+//   a = up-1     : dy 0, 1 -> i (tap 0);  dy 2 -> i+1 (tap 1)             window starts at i
 // (same for columns), and zero padding of the high-res tensor is zero padding of the low-res one.
-// Layout [phase = 2a+b][cout][2x2][cin].
-ConvW Detector::compose_upsampled(const ConvW& out, const ConvW& in_up) {
-  const std::vector<double> t = compose_taps(out, in_up);
-  const int cin = in_up.cin, cout = out.cout;
-  std::vector<float> w((size_t)4 * cout * 4 * cin);
-  auto tap_of = [](int phase_bit, int d) { return phase_bit == 0 ? (d == 0 ? 0 : 1) : (d == 2 ? 1 : 0); };
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b)
+// Layout [phase = up a + b][cout][2x2][cin].
+ConvW Detector::phase_conv(const std::vector<double>& t, int cout, int cin, int up) {
+  std::vector<float> w((size_t)up * up * cout * 4 * cin);
+  auto tap_of = [up](int a, int d) { return a == 0 ? (d == 0 ? 0 : 1) : (a == up - 1 && d == 2) ? 1 : 0; };
+  std::vector<double> acc((size_t)4 * cin);
+  for (int a = 0; a < up; ++a)
+    for (int b = 0; b < up; ++b)
       for (int o = 0; o < cout; ++o) {
-        std::vector<double> acc((size_t)4 * cin, 0.0);
+        std::fill(acc.begin(), acc.end(), 0.0);
         for (int dy = 0; dy < 3; ++dy)
           for (int dx = 0; dx < 3; ++dx) {
             const int tp = tap_of(a, dy) * 2 + tap_of(b, dx);
             const double* src = &t[((size_t)o * 9 + dy * 3 + dx) * cin];
             for (int i = 0; i < cin; ++i) acc[(size_t)tp * cin + i] += src[i];
           }
-        float* dst = &w[(((size_t)(a * 2 + b) * cout + o) * 4) * cin];
+        float* dst = &w[(((size_t)(a * up + b) * cout + o) * 4) * cin];
         for (size_t i = 0; i < acc.size(); ++i) dst[i] = (float)acc[i];
       }
-  return finish_composed(std::move(w), cout, cin, 2);
+  ConvW cw = finish_composed(std::move(w), cout, cin, 2);
+  cw.up = up;
+  return cw;
+}
+
+// B_k = out_k o up2 o in_{k+1}
+ConvW Detector::compose_upsampled(const ConvW& out, const ConvW& in_up) {
+  return phase_conv(compose_taps(out, in_up), out.cout, in_up.cin, 2);
 }
 
 Detector::Detector(const void* blob, size_t bytes, int device) : device_(device) {
@@ -185,6 +193,21 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       fpn_b_[l] = compose_upsampled(out_[l], in_[l + 1]);
     }
   bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
+  if (fpn_composed_) {
+    // slice s of the 256 input channels (p5, p4, p3, p2 = s 0..3), bin_bn1's scale folded in
+    auto slice = [&](int sidx) {
+      std::vector<double> t((size_t)64 * 9 * 64);
+      for (int o = 0; o < 64; ++o)
+        for (int k = 0; k < 9; ++k)
+          for (int c = 0; c < 64; ++c)
+            t[((size_t)o * 9 + k) * 64 + c] = (double)bin1_.host_scale[o] * (double)bin1_.host[((size_t)o * 9 + k) * 256 + sidx * 64 + c];
+      return t;
+    };
+    for (int l = 0; l < 3; ++l) bin_up_[l] = phase_conv(slice(2 - l), 64, 64, 2 << l);
+    const std::vector<double> t2 = slice(3);
+    bin_p2_ = finish_composed(std::vector<float>(t2.begin(), t2.end()), 64, 64, 3);
+    bin_p2_.bias = bin1_.bias;
+  }
   {  // bin_conv_tr1 [Cin=64][Cout=64][2][2] + bias, then bin_bn2:
      // GEMM B rows = (a*2+b)*64 + co over K = ci; (acc + bias)*s + t = acc*s + (bias*s + t)
     const float* w = wb.get("bin_conv_tr1.weight", {64, 64, 2, 2}).data;
@@ -234,6 +257,10 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       all_convs_.push_back(&fpn_a_[l]);
       all_convs_.push_back(&fpn_b_[l]);
     }
+  if (fpn_composed_) {
+    for (int l = 0; l < 3; ++l) all_convs_.push_back(&bin_up_[l]);
+    all_convs_.push_back(&bin_p2_);
+  }
   {
     const char* e = getenv("OCR_DET_PRECISION");
     if (e && std::string(e) == "bf16") set_precision(1);
@@ -399,6 +426,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     const void* up_residual = nullptr;
     void* out2 = nullptr;
     bool cat4 = false;
+    bool f32_out = false;   // bf16 precision: keep this conv's result (and residual) in f32
     int store = STORE_NHWC;
   };
   const bool bf = bf16_;
@@ -409,7 +437,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     // the probability head (bin_conv_tr1 as a GEMM) always runs in f32; bin_conv1 reads bf16 and writes f32
     const bool in_bf = bf && ex.store != STORE_SHUFFLE2;
     d.in_bf16 = in_bf ? 1 : 0;
-    d.out_bf16 = (in_bf && !ex.cat4) ? 1 : 0;
+    d.out_bf16 = (in_bf && !ex.cat4 && !ex.f32_out) ? 1 : 0;
+    d.up = cw.up;
     const size_t ies = in_bf ? 2 : 4;
     d.src[0] = src;
     d.src_mode = ex.cat4 ? SRC_CAT4 : SRC_PLAIN;
@@ -430,9 +459,9 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.Cin = cw.cin;
     d.ks = cw.ks;
     d.stride = stride;
-    d.pad = ex.store == STORE_PHASE2 ? 1 : (cw.ks - 1) / 2;
-    d.Ho = ex.store == STORE_PHASE2 ? hin : (hin + 2 * d.pad - cw.ks) / stride + 1;
-    d.Wo = ex.store == STORE_PHASE2 ? win : (win + 2 * d.pad - cw.ks) / stride + 1;
+    d.pad = ex.store == STORE_PHASE ? 1 : (cw.ks - 1) / 2;
+    d.Ho = ex.store == STORE_PHASE ? hin : (hin + 2 * d.pad - cw.ks) / stride + 1;
+    d.Wo = ex.store == STORE_PHASE ? win : (win + 2 * d.pad - cw.ks) / stride + 1;
     d.Cout = cw.cout;
     d.wgt = in_bf ? cw.w_bf16 : static_cast<const void*>(cw.w);
     d.scale = cw.scale;
@@ -447,7 +476,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     rec.begin();
     launch_conv_igemm(d, stream_);
     const double M = (double)n * d.Ho * d.Wo;
-    const double reps = ex.store == STORE_PHASE2 ? 4.0 : 1.0;  // four phase convs per low-res pixel
+    const double reps = ex.store == STORE_PHASE ? (double)(cw.up * cw.up) : 1.0;  // phase convs per low-res pixel
     const double K = (double)cw.ks * cw.ks * cw.cin * reps;
     double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
     if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
@@ -498,7 +527,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     // p3, p2 = A_k * x_k + B_k *' x_{k+1}: the upsampled term first (phase store), the lateral term on top
     for (int l = 1; l >= 0; --l) {
       Extra up;
-      up.store = STORE_PHASE2;
+      up.store = STORE_PHASE;
       conv("fpn.upsampled", fpn_b_[l], x_[l + 1], h >> (3 + l), w >> (3 + l), 1, p_[l], false, up);
       Extra lat;
       lat.residual = p_[l];
@@ -516,7 +545,21 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   }
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
-  {
+  if (fpn_composed_) {
+    // the three upsampled quarters of the concat as phase convs on their own grids, coarse to fine, then the
+    // p2 quarter with bias + ReLU; partial sums live in b1 (f32 in either precision)
+    for (int l = 2; l >= 0; --l) {
+      Extra up;
+      up.store = STORE_PHASE;
+      up.f32_out = true;
+      if (l < 2) up.residual = b1_;
+      conv("bin_conv1.upsampled", bin_up_[l], p_[l + 1], h >> (3 + l), w >> (3 + l), 1, b1_, false, up);
+    }
+    Extra last;
+    last.residual = b1_;
+    last.f32_out = true;
+    conv("bin_conv1.p2", bin_p2_, p_[0], h4, w4, 1, b1_, true, last);
+  } else {
     Extra c4;
     c4.cat4 = true;
     conv("bin_conv1", bin1_, p_[3], h4, w4, 1, b1_, true, c4);

@@ -30,6 +30,8 @@ struct ConvW {
   size_t w_bytes = 0;
   void* w_bf16 = nullptr;  // same layout in bf16 (filled by Detector::set_precision)
   std::vector<float> host; // the f32 layout, kept for the bf16 conversion
+  std::vector<float> host_scale;  // folded batch norm scale (empty: none), kept for weight composition
+  int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
   int cin = 0, cout = 0, ks = 0;
@@ -75,9 +77,14 @@ class Detector {
   // A_k = out_k o in_k (3x3, C_k -> 64); B_k = out_k o up2 o in_{k+1} as four 2x2 phase convs on the
   // low-res grid (C_{k+1} -> 64).  [0] = p2, [1] = p3.
   ConvW fpn_a_[2], fpn_b_[2];
+  // bin_conv1 over cat[up8(p5), up4(p4), up2(p3), p2] as four terms accumulated in its f32 output: phase
+  // convs on the low-res grids of p5 / p4 / p3 ([0] = p3 x2, [1] = p4 x4, [2] = p5 x8) and a plain 3x3 conv
+  // of p2 that adds the bias and applies the ReLU; bin_bn1's scale is folded into all four weight sets.
+  ConvW bin_up_[3], bin_p2_;
   ConvW finish_composed(std::vector<float>&& t, int cout, int cin, int ks);
   ConvW compose_lateral(const ConvW& out, const ConvW& in);
   ConvW compose_upsampled(const ConvW& out, const ConvW& in_up);
+  ConvW phase_conv(const std::vector<double>& taps, int cout, int cin, int up);
   bool fpn_composed_ = true;  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
