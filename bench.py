@@ -36,6 +36,7 @@ from ocr_rs_amd import capi  # noqa: E402
 from ocr_rs_amd import weights as W  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the headline vendor figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_640_IMAGE = 48.365568  # SURVEY.md section 8(d) / BASELINE.md section 2
 
@@ -50,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip recognition / post-processing side numbers")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = the reference's arithmetic (BASELINE configs[1], the headline); bf16 = the opt-in "
+                         "OCR_PRECISION_BF16 trunk/FPN (configs[4]), reported as its own line")
     return ap.parse_args()
 
 
@@ -143,6 +147,9 @@ def main():
     n, s = a.batch, a.size
     det_w = W.make_det_weights(0)
     det = capi.Detector(W.pack_blob(det_w), local)
+    if a.dtype == "bf16":
+        det.set_precision(capi.PRECISION_BF16)
+    peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
     stream = torch.cuda.Stream(device=local)
     det.set_stream(stream.cuda_stream)
     x = torch.from_numpy(W.synth_image_batch(1 + rank, n, s, s)).to(f"cuda:{local}")
@@ -174,6 +181,7 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream
     roof = None
+    executed_gflop = None
     if rank == 0:
         agg = {}
         reps = 3
@@ -187,8 +195,9 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (ms, fl, by, cnt) = dom
         achieved = fl / (ms * 1e-3) / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+        executed_gflop = sum(v[1] for v in agg.values()) / reps / 1e9
+        roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc_traffic(name, n, s),
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
                 "avg_launch_gflop": round(fl / cnt / 1e9, 3),
@@ -250,11 +259,15 @@ def main():
         line = {
             "metric": "images/sec (640x640 detect)", "value": round(total_images / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"detection forward (ResNet18+FPN+prob head, fused binarize), batch {n} x 1x{s}x{s} "
-                                   f"f32 frames per GPU, BASELINE configs[1]",
+                                   f"f32 frames per GPU, BASELINE configs[1]"
+                                   + (" in the opt-in bf16 precision of configs[4]" if a.dtype == "bf16" else ""),
                        "global_batch": n * world, "frame": [s, s], "parallelism": f"replica x{world}, frames sharded"},
-            "tflops_algorithmic": round(total_images * GFLOP_PER_640_IMAGE * (s * s) / (640 * 640) / elapsed / 1e3, 2),
+            # the reference graph's layer-by-layer work per second, and what the kernels execute
+            # after folding the FPN laterals / upsampled concat quarters into phase convs
+            "tflops_reference_graph": round(total_images * GFLOP_PER_640_IMAGE * (s * s) / (640 * 640) / elapsed / 1e3, 2),
+            "tflops_executed": None if executed_gflop is None else round(executed_gflop * a.steps * world / elapsed / 1e3, 2),
             "roofline": roof,
         }
         if gathered is not None:

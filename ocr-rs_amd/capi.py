@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
         L.ocr_test_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.POINTER(C.c_float)]
         L.ocr_test_conv_run.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] +
                                         [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2)
+        L.ocr_test_set_conv_tile.argtypes = [C.c_int]
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib

@@ -618,6 +618,10 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
     down(out2, d_out2, out_e, out_bf16);
   });
 }
+int ocr_test_set_conv_tile(int t) {
+  ocr::set_conv_tile_override(t);
+  return OCR_OK;
+}
 // micro-benchmark of one conv_igemm launch shape on constant data (kernel tuning aid)
 int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, int ks, int stride, int src_mode,
                         int iters, float* ms_out) {

@@ -73,6 +73,7 @@ struct ConvDesc {
 
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvDesc& d);
+void set_conv_tile_override(int t);  // tuning aid: 0 = automatic
 
 // stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
 void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,

@@ -362,7 +362,16 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   const int rr0 = tid / CPR;           // its row in pass 0
   const int col = n0 + c4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  __shared__ int row_aux[BM];   // per tile row: offset of its up_residual pixel / shuffled output pixel
+  // per tile row: offset of its up_residual pixel / shuffled output pixel.  Lives behind the accumulator tile
+  // in the (now free) operand stages when there is room, so that the 64x64 variant needs exactly 32 KB of LDS
+  // and five workgroups fit a CU (160 KB); only the 128x128 tile fills both stages and needs its own array.
+  int* row_aux;
+  if constexpr (BM * BN * 4 + BM * 4 <= 2 * STAGE) {
+    row_aux = reinterpret_cast<int*>(lds + BM * BN * 4);
+  } else {
+    __shared__ int row_aux_own[BM];
+    row_aux = row_aux_own;
+  }
   __syncthreads();              // every wave is done reading the last operand stage
   {
     const int colq = lane & 31;
@@ -534,14 +543,25 @@ static void check(const ConvDesc& d) {
     fail(OCR_ERR_INVALID, "%s: bf16 -> f32 exists for the CAT4, 3x3 s1 and PHASE convs only", d.name);
 }
 
-// Tile choice: the largest tile that still leaves >= 8 tiles per CU (256 CUs), so that the
-// last partial round of tiles costs little; small tiles keep their MFMA rate because the
-// DMA loop has almost no per-step overhead.
+// Tile choice (measured per layer shape with tools/bench_conv_tiles.py, profiles/r01_tile_scan.txt).
+// f32: the MFMA time of a K-step is long (64 cycles per 32x32x2), so the small tile loses nothing in the
+// loop and wins on residency (5 workgroups per CU hide each other's prologue / epilogue / barrier waits)
+// and on the last partial round of tiles: 64x64 for every 2x2 / 3x3 conv.  The 1x1 convs are HBM-bound and
+// keep the largest tile that still leaves >= 8 tiles per CU.
+// bf16: a K-step is 4x shorter, operand traffic per flop decides: 128x128 for the deep layers (Cin >= 256),
+// 128x64 otherwise.
 enum Tile { T128x128, T128x64, T64x64 };
+static int g_tile_override = 0;  // tuning aid (ocr_test_set_conv_tile): 1 = 128x128, 2 = 128x64, 3 = 64x64
+void set_conv_tile_override(int t) { g_tile_override = t; }
 static Tile pick_tile(const ConvDesc& d) {
+  if (g_tile_override == 1 && d.Cout % 128 == 0) return T128x128;
+  if (g_tile_override == 2) return T128x64;
+  if (g_tile_override == 3) return T64x64;
   const long long M = (long long)d.N * d.Ho * d.Wo;
   const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : 1;
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
+  if (d.in_bf16 && d.ks > 1) return (d.Cout % 128 == 0 && d.Cin >= 256) ? T128x128 : T128x64;
+  if (d.ks > 1 && d.src_mode == SRC_PLAIN) return T64x64;
   if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
   if (blocks(128, 64) >= 2048) return T128x64;
   return T64x64;

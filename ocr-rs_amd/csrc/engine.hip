@@ -545,9 +545,10 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   }
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
-  if (fpn_composed_) {
+  if (fpn_composed_ && !bf) {
     // the three upsampled quarters of the concat as phase convs on their own grids, coarse to fine, then the
-    // p2 quarter with bias + ReLU; partial sums live in b1 (f32 in either precision)
+    // p2 quarter with bias + ReLU; partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more
+    // HBM time than the skipped MFMA work saves, so that precision keeps the single gathered conv)
     for (int l = 2; l >= 0; --l) {
       Extra up;
       up.store = STORE_PHASE;

@@ -284,3 +284,37 @@ def test_rec_single_crop_and_empty(rec, rec_w):
     assert rec.classify_host(crops)[0].tolist() == T.rec_classify(T.rec_forward(rec_w, crops))[0].tolist()
     labels, probs = rec.classify_host(np.zeros((0, 784), np.float32))
     assert labels.shape == (0,)
+
+
+def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
+    """The default engine folds in2/in3 into out2/out3 (lateral conv + phase convs on the low-res grid) and
+    splits bin_conv1 over the concat into phase convs (DESIGN.md section 3).  Exact in real arithmetic;
+    in f32 it re-associates sums, so it is held to the same bars as everything else: p2 / p3 and the
+    bin_conv1 output against the oracle's activations, the map within TOL of the oracle and of the
+    layer-by-layer engine (OCR_FPN_UNFUSED=1)."""
+    n, h, w = 2, 96, 160
+    x = W.synth_image_batch(21, n, h, w)
+    st = {}
+    ref = T.det_forward(det_w, x, st)
+    prob = det.forward_host(x)
+    fuse = st["fuse"]                                   # N x 256 x H/4 x W/4 = cat[p5, p4, p3, p2]
+    p2 = det.debug_stage(9, (n, h // 4, w // 4, 64))     # returned as NCHW
+    p3 = det.debug_stage(10, (n, h // 8, w // 8, 64))
+    b1 = det.debug_stage(13, (n, h // 4, w // 4, 64))
+    assert _rel(p2, fuse[:, 192:256]) < 2e-5
+    assert _rel(p3, fuse[:, 128:192, ::2, ::2]) < 2e-5
+    assert _rel(b1, st["bin1"]) < 2e-5
+    assert np.abs(prob - ref).max() < TOL
+    monkeypatch.setenv("OCR_FPN_UNFUSED", "1")
+    plain = capi.Detector(W.pack_blob(det_w), 0)
+    try:
+        prob_plain = plain.forward_host(x)
+        sum2 = plain.debug_stage(5, (n, h // 4, w // 4, 256))     # only the layer-wise graph materialises it
+        assert sum2.shape[1] == 256
+    finally:
+        plain.close()
+    d = float(np.abs(prob - prob_plain).max())
+    print(f"composed vs layer-wise FPN: max |dp| = {d:.3e}")
+    assert d < 1e-5
+    with pytest.raises(capi.OcrError):
+        det.debug_stage(5, (n, h // 4, w // 4, 256))

@@ -15,14 +15,16 @@ TILE = {"128, 128": "128x128", "128, 64": "128x64", "64, 64": "64x64"}
 
 
 def pretty(name: str) -> str:
-    # "void ocr::igemm::conv_igemm_f32<128, 64, 3, 1, 0, 0>(...)" -> bench.py's kernel label
-    if "conv_igemm_f32<" not in name:
+    # "void ocr::igemm::conv_igemm<float, float, 64, 64, 3, 1, 0, 0>(...)" -> bench.py's kernel label
+    if "conv_igemm<" not in name:
         return "stem_conv7x7_bn_relu_maxpool" if "stem_kernel" in name else \
                "convt2x2_sigmoid" if "convt2_sigmoid" in name else \
                "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
-    tile = f"{a[0]}x{a[1]}"
-    return f"conv_igemm_f32<{tile},k{a[2]},s{a[3]},{'CAT4' if a[4] == '2' else 'PLAIN'}{',SHUFFLE2' if a[5] == '1' else ''}>"
+    ty = "bf16" if "bf16" in a[0] or "__bf16" in a[0] else "f32"
+    tile = f"{a[2]}x{a[3]}"
+    store = {"0": "", "1": ",SHUFFLE2", "2": ",PHASE"}[a[7]]
+    return f"conv_igemm_{ty}<{tile},k{a[4]},s{a[5]},{'CAT4' if a[6] == '2' else 'PLAIN'}{store}>"
 
 
 def load(d, counter):
