@@ -639,6 +639,16 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
     OCR_HIP(hipMalloc(reinterpret_cast<void**>(&out), out_e * 4));
     OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(in), 0x3f8ccccd, in_e, s));   // 1.1f
     OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wt), 0x3c23d70a, w_e, s));    // 0.01f
+    if (src_mode & 32) {  // random operands: MFMA power (and with it the clock) depends on the data
+      src_mode &= ~32;
+      std::vector<float> h(std::max(in_e, w_e));
+      uint32_t st = 12345u;
+      auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+      for (size_t i = 0; i < in_e; ++i) h[i] = rnd();
+      OCR_HIP(hipMemcpy(in, h.data(), in_e * 4, hipMemcpyHostToDevice));
+      for (size_t i = 0; i < w_e; ++i) h[i] = 0.05f * rnd();
+      OCR_HIP(hipMemcpy(wt, h.data(), w_e * 4, hipMemcpyHostToDevice));
+    }
     ConvDesc d{};
     d.src[0] = in;
     d.src_mode = SRC_PLAIN;

@@ -153,6 +153,12 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     pa = ph >> p.up_shift;
     pb = ph & ((1 << p.up_shift) - 1);
   }
+  // PHASE: only the first and the last phase of a row / column of phases see two low-res rows / columns; the
+  // phases in between see one (their second tap has zero weight and is skipped).  Active taps are the prefix
+  // t < nt of the tap order t = kh * nw + kw, which is also the order of this phase's weights.
+  const int last_ph = (1 << p.up_shift) - 1;
+  const int nw = (STORE == STORE_PHASE) ? ((pb == 0 || pb == last_ph) ? 2 : 1) : KS;
+  const int nt = (STORE == STORE_PHASE) ? (((pa == 0 || pa == last_ph) ? 2 : 1) * nw) : KS * KS;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -199,7 +205,11 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // offsets of all taps for source s (PLAIN: the one input tensor; CAT4: p5,p4,p3,p2 = s 0..3,
   // nearest-upsampled by 8,4,2,1, 64 channels each)
   auto tap_offset = [&](int s, int t, int i) -> unsigned {
-    const int kh = t / KS, kw = t - kh * KS;
+    int kh = t / KS, kw = t - kh * KS;
+    if constexpr (STORE == STORE_PHASE) {
+      kh = nw == 2 ? t >> 1 : t;
+      kw = nw == 2 ? t & 1 : 0;
+    }
     const int ih = ih0[i] + kh, iw = iw0[i] + kw;
     const bool ok = (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
     unsigned off;
@@ -294,9 +304,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     for (int c = 0; c < pass_chunks; ++c) {
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
+        if (STORE == STORE_PHASE && t >= nt) continue;  // wave-uniform
         const int nxt = par ^ 1;
         // DMA of the next K-step flies while this one is multiplied
-        if (t + 1 < NTAP) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c, s * 64);
+        if (t + 1 < NTAP && t + 1 < nt) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c, s * 64);
         else if (c + 1 < pass_chunks) issue_plain(nxt, avoff[0], 0, c + 1, s * 64);
         else if (SRC == SRC_CAT4 && s + 1 < NSRC) issue_plain(nxt, next0, 0, 0, (s + 1) * 64);
         compute(par);

@@ -123,6 +123,9 @@ ConvW Detector::compose_lateral(const ConvW& out, const ConvW& in) {
 ConvW Detector::phase_conv(const std::vector<double>& t, int cout, int cin, int up) {
   std::vector<float> w((size_t)up * up * cout * 4 * cin);
   auto tap_of = [up](int a, int d) { return a == 0 ? (d == 0 ? 0 : 1) : (a == up - 1 && d == 2) ? 1 : 0; };
+  // phases strictly inside a row / column of phases use one tap in that direction; the kernel walks the
+  // active taps as the prefix of the order t = kh * nw + kw (nw = taps per row of this phase) and skips the rest
+  auto taps_of = [up](int a) { return (a == 0 || a == up - 1) ? 2 : 1; };
   std::vector<double> acc((size_t)4 * cin);
   for (int a = 0; a < up; ++a)
     for (int b = 0; b < up; ++b)
@@ -130,7 +133,7 @@ ConvW Detector::phase_conv(const std::vector<double>& t, int cout, int cin, int 
         std::fill(acc.begin(), acc.end(), 0.0);
         for (int dy = 0; dy < 3; ++dy)
           for (int dx = 0; dx < 3; ++dx) {
-            const int tp = tap_of(a, dy) * 2 + tap_of(b, dx);
+            const int tp = tap_of(a, dy) * taps_of(b) + tap_of(b, dx);
             const double* src = &t[((size_t)o * 9 + dy * 3 + dx) * cin];
             for (int i = 0; i < cin; ++i) acc[(size_t)tp * cin + i] += src[i];
           }
@@ -477,7 +480,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     launch_conv_igemm(d, stream_);
     const double M = (double)n * d.Ho * d.Wo;
     const double reps = ex.store == STORE_PHASE ? (double)(cw.up * cw.up) : 1.0;  // phase convs per low-res pixel
-    const double K = (double)cw.ks * cw.ks * cw.cin * reps;
+    // taps executed per low-res pixel over all phases: (up + 2)^2 (edge phases 2, inner phases 1 per direction)
+    const double K = ex.store == STORE_PHASE ? (double)cw.cin * (cw.up + 2) * (cw.up + 2) : (double)cw.ks * cw.ks * cw.cin;
     double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
     if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
     const double oes = d.out_bf16 ? 2.0 : 4.0;
