@@ -57,6 +57,10 @@ struct ConvDesc {
   int Ho, Wo, Cout;
   int ks, stride, pad;
   int up;                 // STORE_PHASE: upsampling factor
+  // batched GEMM (1x1 s1 PLAIN NHWC only, no residual / out2): `batch` independent problems of the same
+  // shape, problem b reading src + b * M*Cin, wgt + b * Cout*Cin and writing out + b * M*Cout (elements);
+  // src_bytes / wgt_bytes cover all of them.  0 or 1 = a single problem.
+  int batch;
   const void* wgt;
   const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32
   const float* bias;
@@ -78,6 +82,12 @@ void set_conv_tile_override(int t);  // tuning aid: 0 = automatic
 // stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
 void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,
                  void* out, int out_bf16, int N, int H, int W, hipStream_t s);
+// Winograd F(2x2, 3x3) transforms around a batched 16-problem GEMM (winograd.hip): 3x3 s1 p1 convs of the deep,
+// small-grid layers.  x: [N][H][W][C] f32 -> v: [16][T][C], T = N * ceil(H/2) * ceil(W/2) tiles (zero padding
+// and odd sizes handled here); m: [16][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.
+void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s);
+void launch_winograd_output(const float* m, const float* scale, const float* bias, const float* residual, int relu,
+                            float* y, int N, int H, int W, int K, hipStream_t s);
 // tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);

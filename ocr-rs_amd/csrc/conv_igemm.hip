@@ -99,6 +99,7 @@ struct ConvArgs {
   int nblk;     // total blocks
   int nblk_m;   // tiles along M (PHASE: per phase; the grid holds up*up phases)
   int up_shift; // PHASE: log2 of the upsampling factor (1, 2, 3)
+  int batch;    // batched GEMM: number of problems (grid slices along M); 1 otherwise
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
 };
 
@@ -153,6 +154,14 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     pa = ph >> p.up_shift;
     pb = ph & ((1 << p.up_shift) - 1);
   }
+  // batched GEMM: slice bz of the grid is problem bz (own A, B and output blocks)
+  int bz = 0;
+  if constexpr (STORE == STORE_NHWC && KS == 1 && STRIDE == 1 && SRC == SRC_PLAIN) {
+    if (p.batch > 1) {
+      bz = tile_m / p.nblk_m;
+      tile_m -= bz * p.nblk_m;
+    }
+  }
   // PHASE: only the first and the last phase of a row / column of phases see two low-res rows / columns; the
   // phases in between see one (their second tap has zero weight and is skipped).  Active taps are the prefix
   // t < nt of the tap order t = kh * nw + kw, which is also the order of this phase's weights.
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       ih0[i] = oh * STRIDE - p.pad + (pa > 0);
       iw0[i] = ow * STRIDE - p.pad + (pb > 0);
       if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; the pixel offset depends on the source
-      else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin * EB + gq * 16;  // bytes
+      else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin * EB + gq * 16 + bz * p.M * p.Cin * EB;  // bytes
     } else {
       ih0[i] = -(1 << 20);  // every tap out of range -> zeros
       iw0[i] = 0;
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   }
   unsigned bvoff[BI];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)((ph * p.Cout + n0 + r + 32 * i) * (KS * KS) * p.Cin * EB + gq * 16);
+  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + r + 32 * i) * (KS * KS) * p.Cin * EB + gq * 16);
 
   // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
   // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
           const int m = mbase + (e & 3) + 8 * (e >> 2);
           float v = acc[i][j][e] * sc + bi + res[e];
           if (p.relu) v = fmaxf(v, 0.f);
-          if (full_tile || m < p.M) Elem<TO>::store1(p.out, (size_t)m * p.Cout + col, v);
+          if (full_tile || m < p.M) Elem<TO>::store1(p.out, ((size_t)bz * p.M + m) * p.Cout + col, v);
         }
         __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile at a time: keeps the residual staging at 16 registers
       }
@@ -494,7 +503,8 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.nblk_n = d.Cout / BN;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.up_shift = d.up == 8 ? 3 : d.up == 4 ? 2 : 1;
-  a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : 1);
+  a.batch = d.batch > 1 ? d.batch : 1;
+  a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
   static const int extra_lds = getenv("OCR_CONV_EXTRA_LDS") ? atoi(getenv("OCR_CONV_EXTRA_LDS")) : 0;  // tuning knob: caps residency
@@ -528,11 +538,16 @@ static void check(const ConvDesc& d) {
       fail(OCR_ERR_INVALID, "%s: output grid %dx%d does not follow from input %dx%d", d.name, d.Ho, d.Wo, d.Hin, d.Win);
   }
   if ((long long)d.N * d.Ho * d.Wo >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: M overflows int", d.name);
+  const int nb = d.batch > 1 ? d.batch : 1;
+  if (nb > 1 && (d.ks != 1 || d.stride != 1 || d.src_mode != SRC_PLAIN || d.store_mode != STORE_NHWC || d.residual || d.out2 ||
+                 d.in_bf16 || d.out_bf16 || !d.out))
+    fail(OCR_ERR_INVALID, "%s: batched GEMM needs a plain f32 1x1 s1 conv without residual", d.name);
+  if ((long long)nb * d.N * d.Ho * d.Wo * d.Cout >= (1ll << 40)) fail(OCR_ERR_INVALID, "%s: batched output too large", d.name);
   // the kernel addresses its operands with 32-bit BYTE offsets below the out-of-range marker 2^31
-  const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)d.N * d.Hin * d.Win * d.Cin * eb;
+  const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)nb * d.N * d.Hin * d.Win * d.Cin * eb;
   if (in_bytes >= (1ll << 31) || (long long)d.src_bytes >= (1ll << 31) || (long long)d.src_bytes < in_bytes)
     fail(OCR_ERR_INVALID, "%s: input of %lld bytes (addressable %zu) must be < 2^31 bytes; split the batch", d.name, in_bytes, d.src_bytes);
-  if ((long long)d.wgt_bytes != (long long)(phase2 ? d.up * d.up : 1) * d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if ((long long)d.wgt_bytes != (long long)(phase2 ? d.up * d.up : nb) * d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
   if ((long long)d.wgt_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: weights too large", d.name);
   if (d.src_mode != SRC_PLAIN && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: source mode %d", d.name, d.src_mode);
   if (d.src_mode == SRC_CAT4) {
@@ -569,10 +584,10 @@ static Tile pick_tile(const ConvDesc& d) {
   if (g_tile_override == 2) return T128x64;
   if (g_tile_override == 3) return T64x64;
   const long long M = (long long)d.N * d.Ho * d.Wo;
-  const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : 1;
+  const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : (d.batch > 1 ? d.batch : 1);
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
   if (d.in_bf16 && d.ks > 1) return (d.Cout % 128 == 0 && d.Cin >= 256) ? T128x128 : T128x64;
-  if (d.ks > 1 && d.src_mode == SRC_PLAIN) return T64x64;
+  if ((d.ks > 1 || d.batch > 1) && d.src_mode == SRC_PLAIN) return T64x64;
   if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
   if (blocks(128, 64) >= 2048) return T128x64;
   return T64x64;
@@ -583,7 +598,8 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
   snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
-           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8") : "");
+           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8")
+           : d.batch > 1 ? ",BATCHED" : "");
   // names must outlive the call: intern them
   static thread_local std::vector<std::string>* pool = new std::vector<std::string>();
   for (const auto& s : *pool)

@@ -107,6 +107,28 @@ ConvW Detector::finish_composed(std::vector<float>&& t, int cout, int cin, int k
   return cw;
 }
 
+// U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]] (f64, rounded once), laid out
+// [16 = 4 i + j][Cout][Cin]: sixteen 1x1-conv weight matrices for conv_igemm's batched mode
+void Detector::add_winograd_weights(ConvW& cw) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const size_t kc = (size_t)cw.cout * cw.cin;
+  std::vector<float> u(16 * kc);
+  for (int o = 0; o < cw.cout; ++o)
+    for (int c = 0; c < cw.cin; ++c) {
+      double g[3][3];
+      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = cw.host[((size_t)o * 9 + t) * cw.cin + c];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          double acc = 0.0;
+          for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < 3; ++q) acc += G[i][p] * g[p][q] * G[j][q];
+          u[(size_t)(4 * i + j) * kc + (size_t)o * cw.cin + c] = (float)acc;
+        }
+    }
+  cw.wino = arena_.upload(u);
+  cw.wino_bytes = u.size() * sizeof(float);
+}
+
 // A_k = out_k o in_k
 ConvW Detector::compose_lateral(const ConvW& out, const ConvW& in) {
   const std::vector<double> t = compose_taps(out, in);
@@ -155,7 +177,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
   WeightBlob wb(blob, bytes);
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-  arena_.reserve((size_t)104 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
+  arena_.reserve((size_t)192 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -185,6 +207,16 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
   for (int l = 0; l < 4; ++l) {
     in_[l] = make_conv(wb, "in" + std::to_string(l + 2) + ".weight", "", 256, 64 << l, 1);
     out_[l] = make_conv(wb, "out" + std::to_string(l + 2) + ".weight", "", 64, 256, 3);
+  }
+  {
+    const char* e = getenv("OCR_WINOGRAD");
+    if (e) winograd_min_cin_ = atoi(e) > 0 ? atoi(e) : (1 << 30);
+  }
+  for (int l = 0; l < 4; ++l) {
+    if ((64 << l) < winograd_min_cin_) continue;
+    add_winograd_weights(layer_[l][0][1]);
+    add_winograd_weights(layer_[l][1][0]);
+    add_winograd_weights(layer_[l][1][1]);
   }
   {
     const char* e = getenv("OCR_FPN_UNFUSED");
@@ -364,6 +396,19 @@ void Detector::ensure_workspace(int n, int h, int w) {
     pofs += px * 64;
   }
   b1_ = reinterpret_cast<float*>(alloc(N * (h / 4) * (w / 4) * 64 * 4));
+  wino_v_ = wino_m_ = nullptr;
+  {
+    size_t need = 0;  // 16 * tiles * channels of the largest Winograd layer
+    for (int l = 0; l < 4; ++l)
+      if (layer_[l][1][0].wino) {
+        const size_t th = ((h >> (2 + l)) + 1) / 2, tw = ((w >> (2 + l)) + 1) / 2;
+        need = std::max(need, (size_t)16 * N * th * tw * ((size_t)64 << l));
+      }
+    if (need) {
+      wino_v_ = reinterpret_cast<float*>(alloc(need * 4));
+      wino_m_ = reinterpret_cast<float*>(alloc(need * 4));
+    }
+  }
   tr1buf_ = fused_tail_ ? nullptr : reinterpret_cast<float*>(alloc(N * (h / 2) * (w / 2) * 64 * 4));
   ws_bf16_ = bf16_;
   ws_n_ = n;
@@ -496,6 +541,48 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   rec.end("stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
           (double)n * h * w * 4 + (double)n * h4 * w4 * 64 * (double)es);
 
+  // 3x3 s1 conv + BN (+ residual) + ReLU of the deep layers as Winograd F(2x2,3x3): input transform, sixteen
+  // [tiles x Cin] x [Cin x Cout] GEMMs in one batched launch, output transform with the epilogue (f32 only)
+  auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual) {
+    const size_t th = (hh + 1) / 2, tw = (ww + 1) / 2, T = (size_t)n * th * tw;
+    if (bf || !cw.wino || !wino_v_ || 16 * T * std::max(cw.cin, cw.cout) * 4 >= ((size_t)1 << 31)) {
+      Extra ex;
+      ex.residual = residual;
+      conv(name, cw, src, hh, ww, 1, out, true, ex);
+      return;
+    }
+    rec.begin();
+    launch_winograd_input(static_cast<const float*>(src), wino_v_, n, hh, ww, cw.cin, stream_);
+    rec.end("winograd_input_transform", 0.0, (double)n * hh * ww * cw.cin * 4.0 + 16.0 * T * cw.cin * 4.0);
+    ConvDesc d{};
+    d.src[0] = wino_v_;
+    d.src_mode = SRC_PLAIN;
+    d.src_bytes = 16 * T * cw.cin * 4;
+    d.wgt = cw.wino;
+    d.wgt_bytes = cw.wino_bytes;
+    d.batch = 16;
+    d.N = 1;
+    d.Hin = d.Ho = 1;
+    d.Win = d.Wo = (int)T;
+    d.Cin = cw.cin;
+    d.Cout = cw.cout;
+    d.ks = 1;
+    d.stride = 1;
+    d.pad = 0;
+    d.store_mode = STORE_NHWC;
+    d.out = wino_m_;
+    d.name = name;
+    rec.begin();
+    launch_conv_igemm(d, stream_);
+    rec.end(conv_igemm_kernel_name(d), 2.0 * 16.0 * T * cw.cin * cw.cout,
+            16.0 * 4.0 * ((double)T * cw.cin + (double)T * cw.cout + (double)cw.cin * cw.cout));
+    rec.begin();
+    launch_winograd_output(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), 1, static_cast<float*>(out), n, hh,
+                           ww, cw.cout, stream_);
+    rec.end("winograd_output_transform", 0.0,
+            16.0 * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
+  };
+
   // ResNet-18 trunk, model.rs:113-120 (basic_block :40-55)
   const void* cur = s_;
   for (int l = 0; l < 4; ++l) {
@@ -509,11 +596,9 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
       conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
       sc.residual = d_[l];
     }
-    conv("layer.conv2", layer_[l][0][1], t_[l], ho, wo, 1, a_[l], true, sc);
-    conv("layer.conv1", layer_[l][1][0], a_[l], ho, wo, 1, t_[l], true);
-    Extra sc2;
-    sc2.residual = a_[l];
-    conv("layer.conv2", layer_[l][1][1], t_[l], ho, wo, 1, x_[l], true, sc2);
+    conv3x3("layer.conv2", layer_[l][0][1], t_[l], ho, wo, a_[l], sc.residual);
+    conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
+    conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
     cur = x_[l];
   }
   // FPN laterals in5..in2 (model.rs:115-123), coarse to fine; each also emits the top-down sum

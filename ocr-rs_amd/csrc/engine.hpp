@@ -31,6 +31,8 @@ struct ConvW {
   void* w_bf16 = nullptr;  // same layout in bf16 (filled by Detector::set_precision)
   std::vector<float> host; // the f32 layout, kept for the bf16 conversion
   std::vector<float> host_scale;  // folded batch norm scale (empty: none), kept for weight composition
+  float* wino = nullptr;   // Winograd F(2x2,3x3) weights U = G g G^T as [16][Cout][Cin] (3x3 s1 convs of the deep layers)
+  size_t wino_bytes = 0;
   int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
@@ -85,7 +87,11 @@ class Detector {
   ConvW compose_lateral(const ConvW& out, const ConvW& in);
   ConvW compose_upsampled(const ConvW& out, const ConvW& in_up);
   ConvW phase_conv(const std::vector<double>& taps, int cout, int cin, int up);
-  bool fpn_composed_ = true;  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
+  bool fpn_composed_ = true;
+  // Winograd for 3x3 s1 trunk convs with Cin >= this (f32 precision only); OCR_WINOGRAD=0 disables, =<cin> overrides
+  int winograd_min_cin_ = 256;
+  float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [16][T][C] and [16][T][K] scratch of the layer in flight
+  void add_winograd_weights(ConvW& cw);  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;

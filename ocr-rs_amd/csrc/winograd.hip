@@ -1,0 +1,144 @@
+// Winograd F(2x2, 3x3) transforms for the deep 3x3 s1 p1 convs of the detector trunk (layer3 / layer4,
+// /root/reference/src/text_detection/model.rs:40-55): y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile,
+// 16 multiplies instead of 36 per (tile, cin, cout).  The 16 element-wise products over all tiles and channels
+// are 16 independent GEMMs [T x C] x [C x K] and run on the matrix cores through conv_igemm's batched mode;
+// the kernels here are the HBM-bound ends: d -> V = B^T d B and M -> Y = A^T M A (+ folded BN, residual, ReLU).
+//
+//   B^T = | 1  0 -1  0 |     G = | 1    0    0  |     A^T = | 1 1  1  0 |
+//         | 0  1  1  0 |         | 1/2  1/2  1/2|           | 0 1 -1 -1 |
+//         | 0 -1  1  0 |         | 1/2 -1/2  1/2|
+//         | 0  1  0 -1 |         | 0    0    1  |
+//
+// Only additions and subtractions of f32 values happen here (the 1/2 factors live in the host-side weight
+// transform, engine.hip), so the results differ from the direct convolution by summation order / a few ulp.
+#include "common.hpp"
+
+namespace ocr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one thread = one tile x 4 channels; consecutive threads walk the channels of a tile (coalesced 16-byte
+// accesses on both sides).  v layout [16][T][C].
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H, int W,
+                                                             int C, int th, int tw, long long T) {
+  const int c4n = C >> 2;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= T * c4n) return;
+  const long long t = gid / c4n;
+  const int c = (int)(gid - t * c4n) * 4;
+  const int tx = (int)(t % tw);
+  const long long r = t / tw;
+  const int ty = (int)(r % th);
+  const long long n = r / th;
+  const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+  f32x4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yy = y0 + i, xx = x0 + j;
+      const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      d[i][j] = ok ? *reinterpret_cast<const f32x4*>(x + ((n * H + yy) * W + xx) * C + c) : zero;
+    }
+  f32x4 r4[4][4];  // B^T d
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r4[0][j] = d[0][j] - d[2][j];
+    r4[1][j] = d[1][j] + d[2][j];
+    r4[2][j] = d[2][j] - d[1][j];
+    r4[3][j] = d[1][j] - d[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // (B^T d) B
+    const f32x4 v0 = r4[i][0] - r4[i][2];
+    const f32x4 v1 = r4[i][1] + r4[i][2];
+    const f32x4 v2 = r4[i][2] - r4[i][1];
+    const f32x4 v3 = r4[i][1] - r4[i][3];
+    float* o = v + ((size_t)(4 * i) * T + t) * C + c;
+    const size_t step = (size_t)T * C;
+    *reinterpret_cast<f32x4*>(o) = v0;
+    *reinterpret_cast<f32x4*>(o + step) = v1;
+    *reinterpret_cast<f32x4*>(o + 2 * step) = v2;
+    *reinterpret_cast<f32x4*>(o + 3 * step) = v3;
+  }
+}
+
+// one thread = one tile x 4 output channels.  m layout [16][T][K]; y NHWC.
+__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
+                                                              const float* __restrict__ bias, const float* __restrict__ residual,
+                                                              int relu, float* __restrict__ y, int H, int W, int K, int th,
+                                                              int tw, long long T) {
+  const int k4n = K >> 2;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= T * k4n) return;
+  const long long t = gid / k4n;
+  const int k = (int)(gid - t * k4n) * 4;
+  const int tx = (int)(t % tw);
+  const long long r = t / tw;
+  const int ty = (int)(r % th);
+  const long long n = r / th;
+  const size_t step = (size_t)T * K;
+  const float* src = m + (size_t)t * K + k;
+  f32x4 a[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[i][j] = *reinterpret_cast<const f32x4*>(src + (size_t)(4 * i + j) * step);
+  f32x4 u[2][4];  // A^T M
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u[0][j] = a[0][j] + a[1][j] + a[2][j];
+    u[1][j] = a[1][j] - a[2][j] - a[3][j];
+  }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x4*>(scale + k);
+  if (bias) bi = *reinterpret_cast<const f32x4*>(bias + k);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const f32x4 o0 = u[p][0] + u[p][1] + u[p][2];
+    const f32x4 o1 = u[p][1] - u[p][2] - u[p][3];
+    const int yy = 2 * ty + p;
+    if (yy >= H) continue;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int xx = 2 * tx + q;
+      if (xx >= W) continue;
+      const size_t o = ((n * H + yy) * W + xx) * (size_t)K + k;
+      f32x4 val = (q ? o1 : o0) * sc + bi;
+      if (residual) val += *reinterpret_cast<const f32x4*>(residual + o);
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(y + o) = val;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || C % 4) fail(OCR_ERR_INVALID, "winograd input: bad shape N=%d H=%d W=%d C=%d", N, H, W, C);
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  const long long T = (long long)N * th * tw;
+  const long long threads = T * (C / 4);
+  if (threads >= (1ll << 31) * 256) fail(OCR_ERR_INVALID, "winograd input: too large");
+  hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, v, H, W, C, th, tw, T);
+  OCR_HIP(hipGetLastError());
+}
+
+void launch_winograd_output(const float* m, const float* scale, const float* bias, const float* residual, int relu, float* y,
+                            int N, int H, int W, int K, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || K % 4) fail(OCR_ERR_INVALID, "winograd output: bad shape N=%d H=%d W=%d K=%d", N, H, W, K);
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  const long long T = (long long)N * th * tw;
+  const long long threads = T * (K / 4);
+  if (threads >= (1ll << 31) * 256) fail(OCR_ERR_INVALID, "winograd output: too large");
+  hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, scale, bias, residual,
+                     relu, y, H, W, K, th, tw, T);
+  OCR_HIP(hipGetLastError());
+}
+
+}  // namespace ocr
