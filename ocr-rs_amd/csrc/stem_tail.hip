@@ -10,13 +10,24 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TPH = 4, TPW = 8;                 // pooled output tile per workgroup
-constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1;  // conv rows/cols feeding it (3x3 s2 window): 9 x 17
-constexpr int NPIX = CR * CC;                   // 153 conv pixels per workgroup
-constexpr int MTILES = (NPIX + 31) / 32;        // as 5 MFMA row tiles of 32 pixels
+constexpr int TPH = 4, TPW = 6;                 // pooled output tile per workgroup
+constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1;  // conv rows/cols feeding it (3x3 s2 window): 9 x 13
+constexpr int NPIX = CR * CC;                   // 117 conv pixels per workgroup
+constexpr int MTILES = (NPIX + 31) / 32;        // as 4 MFMA row tiles of 32 pixels: one per wave
 constexpr int IR = 2 * (CR - 1) + 7;            // input rows feeding the conv tile (7x7 s2): 23
-constexpr int ICP = 2 * (CC - 1) + 7 + 1;       // input columns (39), padded to 40
-constexpr int KSTEPS = 25;                      // K = 49 taps padded to 50 = 25 MFMA steps of 2
+constexpr int ICP = 2 * (CC - 1) + 7 + 1;       // input columns (31), padded to 32
+static_assert(MTILES == 4, "one pixel tile per wave");
+// LDS image of the input tile: even and odd columns in separate planes, so that the stride-2 walk of the
+// conv pixels along x becomes a unit-stride walk (lane i -> word i: no bank conflicts on the A operand);
+// 22 words per plane row keeps the 2-3 pixel rows that a 32-pixel MFMA tile spans on different banks.
+constexpr int PW = 22;
+static_assert(2 * PW >= ICP, "plane row holds half of the tile's columns");
+constexpr int PLANE = IR * PW;
+// K order: MFMA step s = 4 kh + jp multiplies taps (kh, 2 jp) on lanes 0-31 and (kh, 2 jp + 1) on lanes 32-63;
+// in the plane layout those two samples are exactly PLANE words apart for every step, so one per-lane base
+// address plus a compile-time immediate serves all steps.  kw = 7 is a zero-weight pad: 28 steps for 49 taps.
+constexpr int KSTEPS = 28;
+constexpr int TL = 4;                           // tiles per workgroup along x                      // K = 49 taps padded to 50 = 25 MFMA steps of 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -24,60 +35,69 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // K = 49 taps.  The A operand is read straight from the LDS input tile - lane l supplies pixel
 // (l & 31) and tap 2s + (l >> 5), one ds_read_b32 per MFMA whose address is a per-lane base plus
 // a compile-time tap offset - and the 49x64 weights sit in registers (50 per lane).
-// grid (Wp/TPW, Hp/TPH, N), 256 threads; the 10 (pixel tile, channel half) units are dealt to the
-// 4 waves round-robin.  BN + ReLU on the accumulators, conv tile to LDS, then the 3x3 s2 max pool.
+// grid (Wp/(TPW*TL), Hp/TPH, N), 256 threads = 4 waves: wave w owns pixel tile w for both channel halves (one
+// A read feeds two MFMAs, every wave does the same amount of work).  BN + ReLU on the accumulators, conv tile
+// to LDS, then the 3x3 s2 max pool.
+constexpr int NT = 64 * MTILES;
 template <typename TO>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
+__global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
                                                    TO* __restrict__ out, int H, int W) {
-  __shared__ __attribute__((aligned(16))) float in_s[IR * ICP];
-  __shared__ float conv_s[NPIX][64];
+  __shared__ __attribute__((aligned(16))) float in_s[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) float conv_s[NPIX][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.z;
-  const int ph0 = blockIdx.y * TPH, pw0 = blockIdx.x * TPW;
+  const int ph0 = blockIdx.y * TPH;
   const int Hc = H >> 1, Wc = W >> 1, Hp = H >> 2, Wp = W >> 2;
-  const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;
-  const int ir0 = 2 * cr0 - 3, ic0 = 2 * cc0 - 3;
+  const int cr0 = 2 * ph0 - 1;
+  const int ir0 = 2 * cr0 - 3;
   const float* xin = x + (size_t)n * H * W;
-  for (int i = tid; i < IR * ICP; i += 256) {
-    const int rr = i / ICP, cc = i - rr * ICP;
-    const int ih = ir0 + rr, iw = ic0 + cc;
-    float v = 0.f;  // zero padding of conv1 (and the pad column)
-    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[(size_t)ih * W + iw];
-    in_s[i] = v;
-  }
   const int half = lane >> 5, l31 = lane & 31;
   // B operand: weight of tap 2s + half for channel 32 ct + (lane & 31); the padded tap 49 is zero
   float wreg[2][KSTEPS];
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) {
-    const int k = 2 * s + half;
+    const int kh = s >> 2, kw = 2 * (s & 3) + half;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) wreg[ct][s] = k < 49 ? w49x64[k * 64 + 32 * ct + l31] : 0.f;
+    for (int ct = 0; ct < 2; ++ct) wreg[ct][s] = kw < 7 ? w49x64[(kh * 7 + kw) * 64 + 32 * ct + l31] : 0.f;
   }
-  __syncthreads();
+  const float sc0 = scale[l31], bi0 = bias[l31], sc1 = scale[32 + l31], bi1 = bias[32 + l31];
+  // a workgroup walks TL tiles along x with the weights resident in registers
+  for (int tl = 0; tl < TL; ++tl) {
+  const int pw0 = (blockIdx.x * TL + tl) * TPW;
+  if (pw0 >= Wp) break;
+  const int cc0 = 2 * pw0 - 1;
+  const int ic0 = 2 * cc0 - 3;
+  for (int i = tid; i < IR * ICP; i += NT) {
+    const int rr = i / ICP, cc = i - rr * ICP;
+    const int ih = ir0 + rr, iw = ic0 + cc;
+    float v = 0.f;  // zero padding of conv1 (and the pad column)
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[(size_t)ih * W + iw];
+    in_s[(cc & 1) * PLANE + rr * PW + (cc >> 1)] = v;
+  }
+  __syncthreads();  // also: every wave has left the previous tile's pool phase (conv_s is free)
 
-  for (int unit = wv; unit < 2 * MTILES; unit += 4) {
-    const int mt = unit >> 1, ct = unit & 1;
+  {
+    const int mt = wv;
     const int pix = min(32 * mt + l31, NPIX - 1);  // rows past the tile repeat its last pixel (never stored)
     const int pr = pix / CC, pc = pix - pr * CC;
-    const int base = 2 * pr * ICP + 2 * pc;        // top-left input sample of this pixel's 7x7 window
-    f32x16 acc;
+    const int base = 2 * pr * PW + pc + half * PLANE;  // top-left sample of this pixel's window, this lane's plane
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+#ifndef STEM_NO_MFMA
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-      // tap of this lane: k = 2s + half; (kh, kw) = (k / 7, k % 7); tap 49 re-reads tap 48 (weight 0)
-      const int k0 = 2 * s, k1 = 2 * s + 1 < 49 ? 2 * s + 1 : 48;
-      const int off0 = (k0 / 7) * ICP + k0 % 7, off1 = (k1 / 7) * ICP + k1 % 7;
-      const float a = in_s[base + (half ? off1 : off0)];
-      acc = ct ? __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][s], acc, 0, 0, 0)
-               : __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][s], acc, 0, 0, 0);
+      const float a = in_s[base + (s >> 2) * PW + (s & 3)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][s], acc1, 0, 0, 0);
     }
+#else
+    acc0[0] = in_s[base] * wreg[0][0];
+    acc1[0] = in_s[base] * wreg[1][0];
+#endif
     // C/D map: column (channel) = lane & 31, row (pixel) = (e&3) + 8 (e>>2) + 4 (lane>>5)
-    const int ch = 32 * ct + l31;
-    const float sc = scale[ch], bi = bias[ch];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -86,24 +106,41 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         // conv positions outside the conv grid are max-pool padding: they never win against the
         // always-valid window centre because ReLU output is >= 0.
         const bool valid = (unsigned)(cr0 + qr) < (unsigned)Hc && (unsigned)(cc0 + qc) < (unsigned)Wc;
-        conv_s[p][ch] = valid ? fmaxf(acc[e] * sc + bi, 0.f) : 0.f;
+        conv_s[p][l31] = valid ? fmaxf(acc0[e] * sc0 + bi0, 0.f) : 0.f;
+        conv_s[p][32 + l31] = valid ? fmaxf(acc1[e] * sc1 + bi1, 0.f) : 0.f;
       }
     }
   }
   __syncthreads();
-  for (int o = tid; o < TPH * TPW * 64; o += 256) {
-    const int ch = o & 63, pp = o >> 6;
+  // 3x3 s2 max pool: one thread = one pooled pixel x 4 channels (b128 LDS reads, 16-byte stores)
+#ifdef STEM_NO_POOL
+  if (H < 0)
+#endif
+  for (int o = tid; o < TPH * TPW * 16; o += NT) {
+    const int c4 = (o & 15) * 4, pp = o >> 4;
     const int py = pp / TPW, px = pp - py * TPW;
     const int ph = ph0 + py, pw = pw0 + px;
     if (ph < Hp && pw < Wp) {
-      float m = 0.f;
+      f32x4 m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, conv_s[(2 * py + dy) * CC + 2 * px + dx][ch]);
-      out[(((size_t)n * Hp + ph) * Wp + pw) * 64 + ch] = (TO)m;
+        for (int dx = 0; dx < 3; ++dx) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&conv_s[(2 * py + dy) * CC + 2 * px + dx][c4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+      TO* dst = out + (((size_t)n * Hp + ph) * Wp + pw) * 64 + c4;
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = m;
+      } else {
+        typedef TO to4 __attribute__((ext_vector_type(4)));
+        to4 h = {(TO)m[0], (TO)m[1], (TO)m[2], (TO)m[3]};
+        *reinterpret_cast<to4*>(dst) = h;
+      }
     }
   }
+  }  // tl
 }
 
 // 16 lanes per input pixel (64 channels as 16 x float4, coalesced), xor-reduce, 4 taps out.
@@ -151,9 +188,9 @@ void launch_stem(const float* x, const float* w49x64, const float* scale, const 
                  int H, int W, hipStream_t s) {
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
-  dim3 grid((Wp + TPW - 1) / TPW, (Hp + TPH - 1) / TPH, N);
-  if (out_bf16) hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(256), 0, s, x, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
-  else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, x, w49x64, scale, bias, static_cast<float*>(out), H, W);
+  dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
+  if (out_bf16) hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(NT), 0, s, x, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
+  else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(NT), 0, s, x, w49x64, scale, bias, static_cast<float*>(out), H, W);
   OCR_HIP(hipGetLastError());
 }
 
