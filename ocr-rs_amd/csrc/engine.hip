@@ -177,6 +177,16 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
   WeightBlob wb(blob, bytes);
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
+  {
+    const char* e = getenv("OCR_OVERLAP");
+    overlap_ = e && e[0] == '1';
+    if (overlap_) {
+      OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+      OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&ev_x3_, hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
+    }
+  }
   arena_.reserve((size_t)192 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
@@ -241,7 +251,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     for (int l = 0; l < 3; ++l) bin_up_[l] = phase_conv(slice(2 - l), 64, 64, 2 << l);
     const std::vector<double> t2 = slice(3);
     bin_p2_ = finish_composed(std::vector<float>(t2.begin(), t2.end()), 64, 64, 3);
-    bin_p2_.bias = bin1_.bias;
+    bin_up_[2].bias = bin1_.bias;  // the p5 term is accumulated last: it adds the bias and applies the ReLU
   }
   {  // bin_conv_tr1 [Cin=64][Cout=64][2][2] + bias, then bin_bn2:
      // GEMM B rows = (a*2+b)*64 + co over K = ci; (acc + bias)*s + t = acc*s + (bias*s + t)
@@ -334,6 +344,13 @@ void Detector::free_workspace() {
 Detector::~Detector() {
   (void)hipSetDevice(device_);
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
+  if (side_stream_) {
+    (void)hipStreamSynchronize(side_stream_);
+    (void)hipStreamDestroy(side_stream_);
+    (void)hipEventDestroy(ev_x2_);
+    (void)hipEventDestroy(ev_x3_);
+    (void)hipEventDestroy(ev_side_);
+  }
   free_workspace();
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
@@ -479,6 +496,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   };
   const bool bf = bf16_;
   const size_t es = bf ? 2 : 4;
+  hipStream_t cs = stream_;  // stream of the launches below (the side stream while the FPN branch is enqueued)
+  const bool overlap = overlap_ && !prof && fpn_composed_ && !bf16_;
   auto conv = [&](const char* name, const ConvW& cw, const void* src, int hin, int win, int stride, void* out,
                   bool relu, const Extra& ex = Extra()) {
     ConvDesc d{};
@@ -522,7 +541,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.out = out;
     d.name = name;
     rec.begin();
-    launch_conv_igemm(d, stream_);
+    launch_conv_igemm(d, cs);
     const double M = (double)n * d.Ho * d.Wo;
     const double reps = ex.store == STORE_PHASE ? (double)(cw.up * cw.up) : 1.0;  // phase convs per low-res pixel
     // taps executed per low-res pixel over all phases: (up + 2)^2 (edge phases 2, inner phases 1 per direction)
@@ -583,6 +602,30 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
             16.0 * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
   };
 
+  // composed FPN level lv (0: p2, 1: p3) and its term of bin_conv1: p_k = A_k * x_k + B_k *' x_{k+1} - the
+  // upsampled term first (phase store), the lateral term on top - then that quarter of the concat into b1.
+  // bin_conv1's four terms accumulate in the order p2, p3, p4, p5; the last one adds the bias and the ReLU.
+  auto fpn_level = [&](int lv) {
+    Extra up;
+    up.store = STORE_PHASE;
+    conv("fpn.upsampled", fpn_b_[lv], x_[lv + 1], h >> (3 + lv), w >> (3 + lv), 1, p_[lv], false, up);
+    Extra lat;
+    lat.residual = p_[lv];
+    conv("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), 1, p_[lv], false, lat);
+    if (bf) return;  // the bf16 precision keeps the single gathered bin_conv1
+    if (lv == 0) {
+      Extra first;
+      first.f32_out = true;
+      conv("bin_conv1.p2", bin_p2_, p_[0], h4, w4, 1, b1_, false, first);
+    } else {
+      Extra t;
+      t.store = STORE_PHASE;
+      t.f32_out = true;
+      t.residual = b1_;
+      conv("bin_conv1.upsampled", bin_up_[0], p_[1], h >> 3, w >> 3, 1, b1_, false, t);
+    }
+  };
+
   // ResNet-18 trunk, model.rs:113-120 (basic_block :40-55)
   const void* cur = s_;
   for (int l = 0; l < 4; ++l) {
@@ -600,6 +643,16 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
     conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
     cur = x_[l];
+    if (overlap && (l == 1 || l == 2)) {
+      // x_{l+1}... is ready: p2 (after layer2) / p3 (after layer3) and their bin_conv1 terms only need the trunk
+      // features computed so far, so they go to the side stream and run next to the deeper layers
+      hipEvent_t ev = l == 1 ? ev_x2_ : ev_x3_;
+      OCR_HIP(hipEventRecord(ev, stream_));
+      OCR_HIP(hipStreamWaitEvent(side_stream_, ev, 0));
+      cs = side_stream_;
+      fpn_level(l - 1);
+      cs = stream_;
+    }
   }
   // FPN laterals in5..in2 (model.rs:115-123), coarse to fine; each also emits the top-down sum
   // up2(in_{k+1}) + in_k that the out_k conv consumes (model.rs:126-137)
@@ -613,14 +666,12 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     }
     conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
     conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
-    // p3, p2 = A_k * x_k + B_k *' x_{k+1}: the upsampled term first (phase store), the lateral term on top
-    for (int l = 1; l >= 0; --l) {
-      Extra up;
-      up.store = STORE_PHASE;
-      conv("fpn.upsampled", fpn_b_[l], x_[l + 1], h >> (3 + l), w >> (3 + l), 1, p_[l], false, up);
-      Extra lat;
-      lat.residual = p_[l];
-      conv("fpn.lateral", fpn_a_[l], x_[l], h >> (2 + l), w >> (2 + l), 1, p_[l], false, lat);
+    if (overlap) {
+      OCR_HIP(hipEventRecord(ev_side_, side_stream_));
+      OCR_HIP(hipStreamWaitEvent(stream_, ev_side_, 0));
+    } else {
+      fpn_level(0);
+      fpn_level(1);
     }
   } else {
     for (int l = 2; l >= 0; --l) {
@@ -635,20 +686,16 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   }
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
   if (fpn_composed_ && !bf) {
-    // the three upsampled quarters of the concat as phase convs on their own grids, coarse to fine, then the
-    // p2 quarter with bias + ReLU; partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more
+    // the p2 quarter as a plain 3x3 conv and the three upsampled quarters as phase convs on their own grids;
+    // partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more
     // HBM time than the skipped MFMA work saves, so that precision keeps the single gathered conv)
-    for (int l = 2; l >= 0; --l) {
+    for (int l = 1; l <= 2; ++l) {  // p4, then p5 with bias + ReLU (the p2 and p3 terms are in b1 already)
       Extra up;
       up.store = STORE_PHASE;
       up.f32_out = true;
-      if (l < 2) up.residual = b1_;
-      conv("bin_conv1.upsampled", bin_up_[l], p_[l + 1], h >> (3 + l), w >> (3 + l), 1, b1_, false, up);
+      up.residual = b1_;
+      conv("bin_conv1.upsampled", bin_up_[l], p_[l + 1], h >> (3 + l), w >> (3 + l), 1, b1_, l == 2, up);
     }
-    Extra last;
-    last.residual = b1_;
-    last.f32_out = true;
-    conv("bin_conv1.p2", bin_p2_, p_[0], h4, w4, 1, b1_, true, last);
   } else {
     Extra c4;
     c4.cat4 = true;

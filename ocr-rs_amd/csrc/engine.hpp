@@ -69,6 +69,11 @@ class Detector {
 
   int device_;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+  // OCR_OVERLAP=1: the FPN branch (p2, p3 and their bin_conv1 terms) runs on a second stream next to layer3 /
+  // layer4, filling the ramps and drains of the trunk's launches
+  bool overlap_ = false;
+  hipStream_t side_stream_ = nullptr;
+  hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr;
   DeviceArena arena_;
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
   ConvW layer_[4][2][2];  // [layer][block][conv1|conv2]

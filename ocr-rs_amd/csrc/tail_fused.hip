@@ -21,6 +21,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+// LDS-DMA load as inline asm (see conv_igemm.hip::dma16: the builtin form makes the compiler wait for the
+// DMA in front of every following ds_read)
+template <typename R>
+__device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
 struct TailArgs {
   const float* y;      // bin_conv1 output, NHWC [M][64]
   const float* wt1;    // [4 taps][64 co][64 ci]
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   tab_b[tid] = p.b4[tid];
   tab_w2[tid] = p.w2t[tid];
 
+  const unsigned lds_a = (unsigned)(size_t)(lds_void*)As, lds_w = (unsigned)(size_t)(lds_void*)Ws;
   // DMA: lane fills slot q of rows r + 32 i with global chunk q ^ f(r) (see conv_igemm.hip)
   const int r = tid >> 3, q = tid & 7;
   const int gq = q ^ ((r >> 1) & 7);
@@ -69,15 +80,15 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
     for (int i = 0; i < TP / 32; ++i) {
       const int m = m0 + r + 32 * i;
       const unsigned off = m < p.M ? (unsigned)((m * 64 + kc * 32 + gq * 4) * 4) : 0x80000000u;  // rows past M read as zeros
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lds_void*)(As + kc * TP * 32 + (32 * i + 8 * wave) * 32), 16, off, 0, 0, 0);
+      dma16(y_rsrc, __builtin_amdgcn_readfirstlane(lds_a + (unsigned)((kc * TP * 32 + (32 * i + 8 * wave) * 32) * 4)), off, 0);
     }
   auto issue_w = [&](int t, int buf) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(Ws + buf * W_FLOATS + kc * 64 * 32 + (32 * i + 8 * wave) * 32), 16,
-                                                 (unsigned)(((r + 32 * i) * 64 + kc * 32 + gq * 4) * 4), t * 64 * 64 * 4, 0, 0);
+        dma16(w_rsrc, __builtin_amdgcn_readfirstlane(lds_w + (unsigned)((buf * W_FLOATS + kc * 64 * 32 + (32 * i + 8 * wave) * 32) * 4)),
+              (unsigned)(((r + 32 * i) * 64 + kc * 32 + gq * 4) * 4), t * 64 * 64 * 4);
   };
   issue_w(0, 0);
 
