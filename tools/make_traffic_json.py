@@ -19,7 +19,9 @@ def pretty(name: str) -> str:
     if "conv_igemm<" not in name:
         return "stem_conv7x7_bn_relu_maxpool" if "stem_kernel" in name else \
                "convt2x2_sigmoid" if "convt2_sigmoid" in name else \
-               "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else name.split("(")[0]
+               "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else \
+               "winograd_input_transform" if "winograd_input" in name else \
+               "winograd_output_transform" if "winograd_output" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
     ty = "bf16" if "bf16" in a[0] or "__bf16" in a[0] else "f32"
     tile = f"{a[2]}x{a[3]}"
