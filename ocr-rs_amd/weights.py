@@ -179,3 +179,37 @@ def unpack_blob(blob: bytes) -> Dict[str, np.ndarray]:
         shape = (d0, d1, d2, d3)[:ndim]
         out[name.rstrip(b"\0").decode()] = np.frombuffer(blob, dtype=np.float32, count=count, offset=off).reshape(shape)
     return out
+
+
+def load_varstore(path: str, kind: str | None = None) -> Dict[str, np.ndarray]:
+    """Named tensors of a tch `VarStore::save` file (what `vs.load(file)` reads back,
+    /root/reference/src/text_detection/mod.rs:41-44, char_recognition/mod.rs:46, utils.rs:55-63).
+
+    tch 0.3.0 writes such a file through torch-sys' `at_save_multi`: one
+    `torch::serialize::OutputArchive`, every variable `write(name, tensor)`-n under its dotted
+    VarStore path, `save_to(file)` - i.e. a TorchScript-module zip whose parameters carry the
+    VarStore names.  `torch.jit.load` opens exactly that container (libtorch keeps reading archives of
+    older versions), so the import is: load, walk parameters and buffers, convert to f32 numpy.
+    `kind` = "det" / "rec" additionally checks names and shapes against the graph this library
+    runs (det_param_specs / rec_param_specs) and fails with the list of what is missing or misshapen.
+
+    Not pinned by the reference: it ships no weight file (.gitignore:16).  Pinned here against
+    an archive written by the same libtorch C++ calls (tests/golden/make_varstore_fixture.cpp)."""
+    import torch  # plumbing only: the archive reader
+
+    module = torch.jit.load(path, map_location="cpu")
+    out: Dict[str, np.ndarray] = {}
+    for name, t in list(module.named_parameters()) + list(module.named_buffers()):
+        out[name] = np.ascontiguousarray(t.detach().to(torch.float32).cpu().numpy())
+    if kind is not None:
+        specs = {"det": det_param_specs, "rec": rec_param_specs}[kind]()
+        problems = []
+        for name, shape in specs:
+            if name not in out:
+                problems.append(f"missing {name} {shape}")
+            elif tuple(out[name].shape) != tuple(shape):
+                problems.append(f"{name}: shape {tuple(out[name].shape)}, expected {shape}")
+        if problems:
+            raise ValueError(f"{path} is not a {kind} VarStore of this graph: " + "; ".join(problems[:8])
+                             + (f" (+{len(problems) - 8} more)" if len(problems) > 8 else ""))
+    return out
