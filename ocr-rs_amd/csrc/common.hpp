@@ -38,7 +38,10 @@ struct Error : std::runtime_error {
 
 // ---- kernel launch descriptors ------------------------------------------------
 
-enum SrcMode { SRC_PLAIN = 0, SRC_CAT4 = 2 };
+// SRC_PYR4 (with STORE_PHASE, up 8): bin_conv1 over cat[up8(p5), up4(p4), up2(p3), p2] computed per output
+// phase (y mod 8, x mod 8): a tile row is one cell of the p5 grid, its K dimension walks the 1-4 taps each
+// upsampled level contributes at that phase and the 9 taps of p2; weights [64 phases][Cout][21 taps][64].
+enum SrcMode { SRC_PLAIN = 0, SRC_CAT4 = 2, SRC_PYR4 = 3 };
 // STORE_PHASE: the conv is the low-res form of "3x3 conv of a nearest-x-up upsampled tensor" (up = 2, 4, 8):
 // ks = 2, up*up weight sets [phase = up a + b][Cout][2x2][Cin], output pixel (up i + a, up j + b) of a
 // [N][up Ho][up Wo][Cout] tensor; the 2x2 window starts at row i-1 for a = 0 and at row i otherwise.

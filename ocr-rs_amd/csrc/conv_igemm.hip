@@ -166,8 +166,14 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // phases in between see one (their second tap has zero weight and is skipped).  Active taps are the prefix
   // t < nt of the tap order t = kh * nw + kw, which is also the order of this phase's weights.
   const int last_ph = (1 << p.up_shift) - 1;
-  const int nw = (STORE == STORE_PHASE) ? ((pb == 0 || pb == last_ph) ? 2 : 1) : KS;
-  const int nt = (STORE == STORE_PHASE) ? (((pa == 0 || pa == last_ph) ? 2 : 1) * nw) : KS * KS;
+  int nw = (STORE == STORE_PHASE) ? ((pb == 0 || pb == last_ph) ? 2 : 1) : KS;
+  int nt = (STORE == STORE_PHASE) ? (((pa == 0 || pa == last_ph) ? 2 : 1) * nw) : KS * KS;
+  // PYR4: taps of source s (0 = p5 .. 2 = p3 upsampled by u = 8 >> s, 3 = p2) at this output phase
+  auto pyr_taps = [&](int s, int phase) { const int u = 8 >> s, q = phase & (u - 1); return s == 3 ? 3 : (q == 0 || q == u - 1) ? 2 : 1; };
+  if constexpr (SRC == SRC_PYR4) {
+    nw = pyr_taps(0, pb);
+    nt = pyr_taps(0, pa) * nw;
+  }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -190,7 +196,11 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       const int ow = rem - oh * p.Wo;
       ih0[i] = oh * STRIDE - p.pad + (pa > 0);
       iw0[i] = ow * STRIDE - p.pad + (pb > 0);
-      if constexpr (SRC == SRC_CAT4) abase[i] = n;  // image index; the pixel offset depends on the source
+      if constexpr (SRC == SRC_PYR4) {  // the row is cell (oh, ow) of the p5 grid
+        ih0[i] = oh;
+        iw0[i] = ow;
+      }
+      if constexpr (SRC == SRC_CAT4 || SRC == SRC_PYR4) abase[i] = n;  // image index; the pixel offset depends on the source
       else abase[i] = ((n * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.Cin * EB + gq * 16 + bz * p.M * p.Cin * EB;  // bytes
     } else {
       ih0[i] = -(1 << 20);  // every tap out of range -> zeros
@@ -199,8 +209,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     }
   }
   unsigned bvoff[BI];
+  constexpr int PYR_TAPS = 21;  // weight row of SRC_PYR4: 4 + 4 + 4 tap slots of p5, p4, p3 and 9 of p2
+  const int wrow = SRC == SRC_PYR4 ? PYR_TAPS * 64 : KS * KS * p.Cin;
 #pragma unroll
-  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + r + 32 * i) * (KS * KS) * p.Cin * EB + gq * 16);
+  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + r + 32 * i) * wrow * EB + gq * 16);
 
   // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
   // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
@@ -215,7 +227,19 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // nearest-upsampled by 8,4,2,1, 64 channels each)
   auto tap_offset = [&](int s, int t, int i) -> unsigned {
     int kh = t / KS, kw = t - kh * KS;
-    if constexpr (STORE == STORE_PHASE) {
+    if constexpr (SRC == SRC_PYR4) {
+      // source pixel of output (8 i + pa, 8 j + pb) at the source's resolution, window start and tap decode
+      const int ush = 3 - s, u = 1 << ush;
+      const int snw = pyr_taps(s, pb);
+      kh = snw == 3 ? t / 3 : snw == 2 ? t >> 1 : t;
+      kw = t - kh * snw;
+      const int ys = (ih0[i] << s) + (pa >> ush) - ((s == 3 || (pa & (u - 1)) == 0) ? 1 : 0) + kh;
+      const int xs = (iw0[i] << s) + (pb >> ush) - ((s == 3 || (pb & (u - 1)) == 0) ? 1 : 0) + kw;
+      const int Hs = p.Hin << s, Ws = p.Win << s;
+      const bool inside = (unsigned)ys < (unsigned)Hs && (unsigned)xs < (unsigned)Ws;
+      const unsigned o = (unsigned)((p.src_off[s] + ((abase[i] * Hs + ys) * Ws + xs) * 64) * EB + gq * 16);
+      return inside ? o : OOB;
+    } else if constexpr (STORE == STORE_PHASE) {
       kh = nw == 2 ? t >> 1 : t;
       kw = nw == 2 ? t & 1 : 0;
     }
@@ -231,6 +255,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     return ok ? off : OOB;
   };
   auto prep_source = [&](int s) {
+    if constexpr (SRC == SRC_PYR4) {
+      nw = pyr_taps(s, pb);
+      nt = pyr_taps(s, pa) * nw;
+    }
 #pragma unroll
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
@@ -296,8 +324,9 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   };
 
   // One pass = all channel chunks of one source (PLAIN: the only one; CAT4: four passes of 2 chunks).
-  constexpr int NSRC = SRC == SRC_CAT4 ? 4 : 1;
-  const int pass_chunks = SRC == SRC_CAT4 ? 64 / BK : csteps;
+  constexpr bool MULTI = SRC == SRC_CAT4 || SRC == SRC_PYR4;
+  constexpr int NSRC = MULTI ? 4 : 1;
+  const int pass_chunks = MULTI ? 64 / BK : csteps;
   int par = 0;  // LDS stage holding the K-step about to be multiplied
   issue_plain(0, avoff[0], 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -306,26 +335,29 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     // first K-step of the NEXT source needs that source's tap-0 offsets while this source's
     // table is still live: computed up front (AI registers)
     unsigned next0[AI];
-    if constexpr (SRC == SRC_CAT4) {
+    if constexpr (MULTI) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) next0[i] = tap_offset(min(s + 1, NSRC - 1), 0, i);
     }
+    // B operand position of this source's taps: CAT4 - channel block s of every tap; PYR4 - tap slots 4 s ..
+    const int tap0 = SRC == SRC_PYR4 ? 4 * s : 0, kb = SRC == SRC_CAT4 ? s * 64 : 0;
+    const int tap0n = SRC == SRC_PYR4 ? 4 * (s + 1) : 0, kbn = SRC == SRC_CAT4 ? (s + 1) * 64 : 0;
     for (int c = 0; c < pass_chunks; ++c) {
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
         if (STORE == STORE_PHASE && t >= nt) continue;  // wave-uniform
         const int nxt = par ^ 1;
         // DMA of the next K-step flies while this one is multiplied
-        if (t + 1 < NTAP && t + 1 < nt) issue_plain(nxt, avoff[(t + 1) % NTAP], t + 1, c, s * 64);
-        else if (c + 1 < pass_chunks) issue_plain(nxt, avoff[0], 0, c + 1, s * 64);
-        else if (SRC == SRC_CAT4 && s + 1 < NSRC) issue_plain(nxt, next0, 0, 0, (s + 1) * 64);
+        if (t + 1 < NTAP && t + 1 < nt) issue_plain(nxt, avoff[(t + 1) % NTAP], tap0 + t + 1, c, kb);
+        else if (c + 1 < pass_chunks) issue_plain(nxt, avoff[0], tap0, c + 1, kb);
+        else if (MULTI && s + 1 < NSRC) issue_plain(nxt, next0, tap0n, 0, kbn);
         compute(par);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
         __syncthreads();                                   // ... and so has everyone's; the old stage is free
         par ^= 1;
       }
     }
-    if constexpr (SRC == SRC_CAT4) {
+    if constexpr (MULTI) {
       if (s + 1 < NSRC) prep_source(s + 1);
     }
   }
@@ -477,12 +509,13 @@ static void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
 template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
 void launch_inst(const ConvDesc& d, hipStream_t s) {
   ConvArgs a{};
-  a.src = d.src_mode == SRC_CAT4 ? d.src_base : d.src[0];
+  const bool multi = d.src_mode == SRC_CAT4 || d.src_mode == SRC_PYR4;
+  a.src = multi ? d.src_base : d.src[0];
   a.src_bytes = (unsigned)d.src_bytes;
   a.wgt_bytes = (unsigned)d.wgt_bytes;
   // element offsets of the CAT4 sources inside their shared allocation
   for (int i = 0; i < 4; ++i)
-    a.src_off[i] = d.src_mode == SRC_CAT4 ? (int)((static_cast<const char*>(d.src[i]) - static_cast<const char*>(d.src_base)) / (long)sizeof(TI)) : 0;
+    a.src_off[i] = multi ? (int)((static_cast<const char*>(d.src[i]) - static_cast<const char*>(d.src_base)) / (long)sizeof(TI)) : 0;
   a.wgt = d.wgt;
   a.scale = d.scale;
   a.bias = d.bias;
@@ -523,6 +556,23 @@ static void check(const ConvDesc& d) {
   if (d.Cin % bk != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, bk);
   if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
   const bool phase2 = d.store_mode == STORE_PHASE;
+  if (d.src_mode == SRC_PYR4) {
+    // rows = cells of the p5 grid (Hin x Win), output [N][8 Hin][8 Win][64], four 64-channel sources in ONE allocation
+    if (!phase2 || d.up != 8 || d.ks != 3 || d.stride != 1 || d.pad != 0 || d.Cin != 64 || d.Cout != 64 || d.Ho != d.Hin ||
+        d.Wo != d.Win || d.out2 || d.residual || !d.out || d.in_bf16 || d.out_bf16 || d.batch > 1)
+      fail(OCR_ERR_INVALID, "%s: PYR4 needs the f32 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
+    if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large", d.name);
+    if ((long long)d.wgt_bytes != 64ll * d.Cout * 21 * 64 * eb) fail(OCR_ERR_INVALID, "%s: PYR4 weight bytes", d.name);
+    if ((long long)d.src_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: sources must be < 2^31 bytes; split the batch", d.name);
+    for (int i = 0; i < 4; ++i) {
+      const long long need = (long long)d.N * (d.Hin << i) * (d.Win << i) * 64 * eb;
+      const long long off = static_cast<const char*>(d.src[i]) - static_cast<const char*>(d.src_base);
+      if (!d.src[i] || off < 0 || off % eb || off + need > (long long)d.src_bytes)
+        fail(OCR_ERR_INVALID, "%s: PYR4 source %d lies outside the shared allocation", d.name, i);
+    }
+    if (!d.wgt) fail(OCR_ERR_INVALID, "%s: null operand", d.name);
+    return;
+  }
   if (phase2) {
     // up*up 2x2 phase convs on the low-res grid: out is [N][up Ho][up Wo][Cout], wgt [up*up][Cout][2x2][Cin]
     if (d.up != 2 && d.up != 4 && d.up != 8) fail(OCR_ERR_INVALID, "%s: PHASE store with up = %d", d.name, d.up);
@@ -586,6 +636,7 @@ static Tile pick_tile(const ConvDesc& d) {
   const long long M = (long long)d.N * d.Ho * d.Wo;
   const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : (d.batch > 1 ? d.batch : 1);
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
+  if (d.src_mode == SRC_PYR4) return T64x64;
   if (d.in_bf16 && d.ks > 1) return (d.Cout % 128 == 0 && d.Cin >= 256) ? T128x128 : T128x64;
   if ((d.ks > 1 || d.batch > 1) && d.src_mode == SRC_PLAIN) return T64x64;
   if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
@@ -598,7 +649,7 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
   snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
-           d.src_mode == SRC_CAT4 ? "CAT4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8")
+           d.src_mode == SRC_CAT4 ? "CAT4" : d.src_mode == SRC_PYR4 ? "PYR4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8")
            : d.batch > 1 ? ",BATCHED" : "");
   // names must outlive the call: intern them
   static thread_local std::vector<std::string>* pool = new std::vector<std::string>();
@@ -632,6 +683,7 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
     fail(OCR_ERR_INVALID, "%s: no bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
   }
   if (d.store_mode == STORE_SHUFFLE2) return launch_tiles<float, float, 1, 1, SRC_PLAIN, STORE_SHUFFLE2>(d, s);
+  if (d.src_mode == SRC_PYR4) return launch_inst<float, float, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
   if (d.store_mode == STORE_PHASE) return launch_tiles<float, float, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
   if (d.src_mode == SRC_CAT4) return launch_tiles<float, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
   if (d.ks == 3 && d.stride == 1) return launch_tiles<float, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);

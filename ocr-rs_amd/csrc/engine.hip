@@ -187,7 +187,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       OCR_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
     }
   }
-  arena_.reserve((size_t)192 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
+  arena_.reserve((size_t)224 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -252,6 +252,44 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     const std::vector<double> t2 = slice(3);
     bin_p2_ = finish_composed(std::vector<float>(t2.begin(), t2.end()), 64, 64, 3);
     bin_up_[2].bias = bin1_.bias;  // the p5 term is accumulated last: it adds the bias and applies the ReLU
+    {
+      const char* e = getenv("OCR_BIN_PYR");
+      bin_pyr_on_ = !(e && e[0] == '0');
+    }
+    if (bin_pyr_on_) {
+      // [phase = 8 a + b][cout][slot][64]: slots 4 s + (th * nw + tw) for the upsampled sources s = 0 (p5, up 8),
+      // 1 (p4, up 4), 2 (p3, up 2) with the tap merging of phase_conv(), slots 12 + 3 dy + dx for p2
+      std::vector<float> w((size_t)64 * 64 * 21 * 64, 0.f);
+      std::vector<double> acc((size_t)4 * 64);
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const std::vector<double> t = slice(sidx);  // [cout][9][64], bin_bn1 scale folded
+        const int up = 8 >> sidx;
+        auto tap_of = [up](int a, int d) { return a == 0 ? (d == 0 ? 0 : 1) : (a == up - 1 && d == 2) ? 1 : 0; };
+        auto taps_of = [up](int a) { return (a == 0 || a == up - 1) ? 2 : 1; };
+        for (int a = 0; a < 8; ++a)
+          for (int b = 0; b < 8; ++b)
+            for (int o = 0; o < 64; ++o) {
+              float* dst = &w[(((size_t)(a * 8 + b) * 64 + o) * 21 + (sidx < 3 ? 4 * sidx : 12)) * 64];
+              if (sidx == 3) {
+                for (int k = 0; k < 9; ++k)
+                  for (int c = 0; c < 64; ++c) dst[k * 64 + c] = (float)t[((size_t)o * 9 + k) * 64 + c];
+                continue;
+              }
+              const int as = a & (up - 1), bs = b & (up - 1);
+              std::fill(acc.begin(), acc.end(), 0.0);
+              for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                  const int tp = tap_of(as, dy) * taps_of(bs) + tap_of(bs, dx);
+                  const double* src = &t[((size_t)o * 9 + dy * 3 + dx) * 64];
+                  for (int c = 0; c < 64; ++c) acc[(size_t)tp * 64 + c] += src[c];
+                }
+              for (size_t i = 0; i < acc.size(); ++i) dst[i] = (float)acc[i];
+            }
+      }
+      bin_pyr_ = finish_composed(std::move(w), 64, 64, 3);
+      bin_pyr_.up = 8;
+      bin_pyr_.bias = bin1_.bias;
+    }
   }
   {  // bin_conv_tr1 [Cin=64][Cout=64][2][2] + bias, then bin_bn2:
      // GEMM B rows = (a*2+b)*64 + co over K = ci; (acc + bias)*s + t = acc*s + (bias*s + t)
@@ -491,6 +529,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     const void* up_residual = nullptr;
     void* out2 = nullptr;
     bool cat4 = false;
+    bool pyr4 = false;      // SRC_PYR4: the four pyramid levels as sources of one phase-conv launch
     bool f32_out = false;   // bf16 precision: keep this conv's result (and residual) in f32
     int store = STORE_NHWC;
   };
@@ -508,8 +547,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.up = cw.up;
     const size_t ies = in_bf ? 2 : 4;
     d.src[0] = src;
-    d.src_mode = ex.cat4 ? SRC_CAT4 : SRC_PLAIN;
-    if (ex.cat4) {
+    d.src_mode = ex.cat4 ? SRC_CAT4 : ex.pyr4 ? SRC_PYR4 : SRC_PLAIN;
+    if (ex.cat4 || ex.pyr4) {
       d.src[0] = p_[3];
       d.src[1] = p_[2];
       d.src[2] = p_[1];
@@ -526,7 +565,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.Cin = cw.cin;
     d.ks = cw.ks;
     d.stride = stride;
-    d.pad = ex.store == STORE_PHASE ? 1 : (cw.ks - 1) / 2;
+    d.pad = ex.pyr4 ? 0 : ex.store == STORE_PHASE ? 1 : (cw.ks - 1) / 2;
     d.Ho = ex.store == STORE_PHASE ? hin : (hin + 2 * d.pad - cw.ks) / stride + 1;
     d.Wo = ex.store == STORE_PHASE ? win : (win + 2 * d.pad - cw.ks) / stride + 1;
     d.Cout = cw.cout;
@@ -545,9 +584,12 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     const double M = (double)n * d.Ho * d.Wo;
     const double reps = ex.store == STORE_PHASE ? (double)(cw.up * cw.up) : 1.0;  // phase convs per low-res pixel
     // taps executed per low-res pixel over all phases: (up + 2)^2 (edge phases 2, inner phases 1 per direction)
-    const double K = ex.store == STORE_PHASE ? (double)cw.cin * (cw.up + 2) * (cw.up + 2) : (double)cw.ks * cw.ks * cw.cin;
+    // PYR4 per cell: (8+2)^2 + 4 (4+2)^2 + 16 (2+2)^2 tap-phases of the upsampled levels + 64 * 9 of p2
+    const double K = ex.pyr4 ? 64.0 * (100 + 144 + 256 + 576)
+                             : ex.store == STORE_PHASE ? (double)cw.cin * (cw.up + 2) * (cw.up + 2) : (double)cw.ks * cw.ks * cw.cin;
     double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
     if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
+    if (ex.pyr4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 4.0 + 16.0 + 64.0);
     const double oes = d.out_bf16 ? 2.0 : 4.0;
     double out_bytes = M * reps * cw.cout * oes * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
                                             (ex.up_residual ? 0.25 : 0.0));
@@ -612,7 +654,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     Extra lat;
     lat.residual = p_[lv];
     conv("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), 1, p_[lv], false, lat);
-    if (bf) return;  // the bf16 precision keeps the single gathered bin_conv1
+    if (bf || bin_pyr_on_) return;  // bf16 keeps the single gathered bin_conv1; PYR4 takes all four terms at once
     if (lv == 0) {
       Extra first;
       first.f32_out = true;
@@ -685,7 +727,14 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   }
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
-  if (fpn_composed_ && !bf) {
+  if (fpn_composed_ && !bf && bin_pyr_on_) {
+    // one launch: per output phase (y mod 8, x mod 8) the taps that phase needs from p5, p4, p3 and p2
+    Extra py;
+    py.pyr4 = true;
+    py.store = STORE_PHASE;
+    py.f32_out = true;
+    conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+  } else if (fpn_composed_ && !bf) {
     // the p2 quarter as a plain 3x3 conv and the three upsampled quarters as phase convs on their own grids;
     // partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more
     // HBM time than the skipped MFMA work saves, so that precision keeps the single gathered conv)

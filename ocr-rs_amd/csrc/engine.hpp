@@ -88,6 +88,11 @@ class Detector {
   // convs on the low-res grids of p5 / p4 / p3 ([0] = p3 x2, [1] = p4 x4, [2] = p5 x8) and a plain 3x3 conv
   // of p2 that adds the bias and applies the ReLU; bin_bn1's scale is folded into all four weight sets.
   ConvW bin_up_[3], bin_p2_;
+  // ... or all four terms in ONE launch (SRC_PYR4): per output phase (y mod 8, x mod 8) a weight row of 21 tap
+  // slots (4 + 4 + 4 for p5, p4, p3 and 9 for p2) x 64 channels; partial sums stay in the accumulators.
+  // OCR_BIN_PYR=0 keeps the four-launch form.
+  ConvW bin_pyr_;
+  bool bin_pyr_on_ = true;
   ConvW finish_composed(std::vector<float>&& t, int cout, int cin, int ks);
   ConvW compose_lateral(const ConvW& out, const ConvW& in);
   ConvW compose_upsampled(const ConvW& out, const ConvW& in_up);
