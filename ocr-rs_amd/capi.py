@@ -113,6 +113,8 @@ def lib() -> C.CDLL:
         L.ocr_test_conv_run.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] +
                                         [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2)
         L.ocr_test_set_conv_tile.argtypes = [C.c_int]
+        L.ocr_test_winograd_conv.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int] +
+                                             [C.c_void_p] * 3 + [C.c_int, C.c_void_p])
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
@@ -269,6 +271,20 @@ class Detector:
                                       stride, p(sc), p(bi), p(rs), p(ur), int(relu), int(bool(cat4_shape)),
                                       p(out), p(out2)))
         return out, out2
+
+    def debug_winograd_conv(self, x_nhwc, wgt_ohwi, scale=None, bias=None, residual=None, relu=False):
+        """3x3 s1 p1 conv through the Winograd path on caller data (test hook): N x H x W x Cout f32."""
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        x, wg = f(x_nhwc), f(wgt_ohwi)
+        n, h, w, cin = x.shape
+        cout = wg.shape[0]
+        assert wg.shape == (cout, 9, cin)
+        sc, bi, rs = f(scale), f(bias), f(residual)
+        p = lambda a: None if a is None else _ptr(a)
+        out = np.empty((n, h, w, cout), np.float32)
+        check(lib().ocr_test_winograd_conv(self._h, _ptr(x), n, h, w, cin, _ptr(wg), cout, p(sc), p(bi), p(rs),
+                                           int(relu), _ptr(out)))
+        return out
 
     def debug_box_scores(self, pred_hw: np.ndarray, polys):
         """Test hook: raw (sum, count) of the GPU box-score kernel for given polygons."""

@@ -618,6 +618,51 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
     down(out2, d_out2, out_e, out_bf16);
   });
 }
+// one 3x3 s1 p1 conv (+ scale / bias / residual / ReLU) through the Winograd F(2x2,3x3) path on caller data:
+// weight transform, input transform, batched 16-problem GEMM, output transform.  x: NHWC, wgt: [cout][9][cin].
+int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, int cin, const float* wgt, int cout,
+                           const float* scale, const float* bias, const float* residual, int relu, float* out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !x || !wgt || !out) fail(OCR_ERR_INVALID, "null argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const size_t th = (h + 1) / 2, tw = (w + 1) / 2, T = (size_t)n * th * tw;
+    const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
+    const std::vector<float> u = winograd_weights(wgt, cout, cin);
+    std::vector<void*> allocs;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    auto dev = [&](const float* src, size_t elems) -> float* {
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, elems * 4));
+      allocs.push_back(d);
+      if (src) OCR_HIP(hipMemcpy(d, src, elems * 4, hipMemcpyHostToDevice));
+      return static_cast<float*>(d);
+    };
+    float* d_x = dev(x, in_e);
+    float* d_u = dev(u.data(), u.size());
+    float* d_v = dev(nullptr, 16 * T * cin);
+    float* d_m = dev(nullptr, 16 * T * cout);
+    float* d_y = dev(nullptr, out_e);
+    const float* d_sc = scale ? dev(scale, cout) : nullptr;
+    const float* d_bi = bias ? dev(bias, cout) : nullptr;
+    const float* d_res = residual ? dev(residual, out_e) : nullptr;
+    launch_winograd_input(d_x, d_v, n, h, w, cin, s);
+    ConvDesc d{};
+    d.src[0] = d_v;
+    d.src_mode = SRC_PLAIN;
+    d.src_bytes = 16 * T * cin * 4;
+    d.wgt = d_u;
+    d.wgt_bytes = u.size() * 4;
+    d.batch = 16;
+    d.N = 1; d.Hin = d.Ho = 1; d.Win = d.Wo = (int)T; d.Cin = cin; d.Cout = cout;
+    d.ks = 1; d.stride = 1; d.pad = 0; d.store_mode = STORE_NHWC; d.out = d_m; d.name = "test_winograd";
+    launch_conv_igemm(d, s);
+    launch_winograd_output(d_m, d_sc, d_bi, d_res, relu, d_y, n, h, w, cout, s);
+    OCR_HIP(hipStreamSynchronize(s));
+    OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
+  });
+}
 int ocr_test_set_conv_tile(int t) {
   ocr::set_conv_tile_override(t);
   return OCR_OK;

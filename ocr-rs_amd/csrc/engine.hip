@@ -109,22 +109,27 @@ ConvW Detector::finish_composed(std::vector<float>&& t, int cout, int cin, int k
 
 // U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]] (f64, rounded once), laid out
 // [16 = 4 i + j][Cout][Cin]: sixteen 1x1-conv weight matrices for conv_igemm's batched mode
-void Detector::add_winograd_weights(ConvW& cw) {
+std::vector<float> winograd_weights(const float* ohwi, int cout, int cin) {
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-  const size_t kc = (size_t)cw.cout * cw.cin;
+  const size_t kc = (size_t)cout * cin;
   std::vector<float> u(16 * kc);
-  for (int o = 0; o < cw.cout; ++o)
-    for (int c = 0; c < cw.cin; ++c) {
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < cin; ++c) {
       double g[3][3];
-      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = cw.host[((size_t)o * 9 + t) * cw.cin + c];
+      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ohwi[((size_t)o * 9 + t) * cin + c];
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
           double acc = 0.0;
           for (int p = 0; p < 3; ++p)
             for (int q = 0; q < 3; ++q) acc += G[i][p] * g[p][q] * G[j][q];
-          u[(size_t)(4 * i + j) * kc + (size_t)o * cw.cin + c] = (float)acc;
+          u[(size_t)(4 * i + j) * kc + (size_t)o * cin + c] = (float)acc;
         }
     }
+  return u;
+}
+
+void Detector::add_winograd_weights(ConvW& cw) {
+  const std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin);
   cw.wino = arena_.upload(u);
   cw.wino_bytes = u.size() * sizeof(float);
 }

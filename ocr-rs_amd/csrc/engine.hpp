@@ -25,6 +25,9 @@ class DeviceArena {  // bump allocator over one hipMalloc (weights)
   size_t cap_ = 0, used_ = 0;
 };
 
+// U = G g G^T of a 3x3 conv given as [Cout][3x3][Cin], laid out [16][Cout][Cin] (winograd.hip)
+std::vector<float> winograd_weights(const float* ohwi, int cout, int cin);
+
 struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
   size_t w_bytes = 0;

@@ -123,3 +123,29 @@ def test_cat4_conv_matches_aten(det, bf16):
     fuse = np.concatenate(ups, axis=3)
     ref, _ = _ref(fuse, wg, 1, scale, bias, None, None, True)
     _check(out, ref, False)
+
+
+WINO_CASES = [
+    # n, h, w, cin, cout, bn, residual, relu
+    (2, 20, 20, 512, 512, True, True, True),     # layer4 conv2 at 640x640
+    (1, 40, 40, 256, 256, True, False, True),    # layer3 conv1
+    (1, 25, 25, 256, 256, True, True, True),     # odd grid (800x800 frames: layer4 is 25x25)
+    (3, 3, 5, 256, 512, False, False, False),    # smaller than a tile row, ragged both ways, Cin != Cout
+    (1, 1, 1, 256, 256, True, True, False),      # a single pixel: every tap but the centre is padding
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_winograd_conv_matches_aten(det, case):
+    """Winograd F(2x2,3x3) path (weight transform, input transform, batched GEMM, output transform with the
+    epilogue) against ATen's direct conv2d on the same operands: relative 2e-5 of the layer's scale."""
+    n, h, w, cin, cout, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:5]) & 0xFFFF)
+    x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)   # post-ReLU-like activations
+    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, h, w, cout), dtype=np.float32) if has_res else None
+    got = det.debug_winograd_conv(x, wg, scale, bias, res, relu)
+    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
+    _check(got, ref, False)
