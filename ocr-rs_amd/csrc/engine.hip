@@ -184,12 +184,14 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
   stream_ = own_stream_;
   {
     const char* e = getenv("OCR_OVERLAP");
-    overlap_ = e && e[0] == '1';
+    if (e) overlap_ = atoi(e);
     if (overlap_) {
       OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
       OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x3_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     }
   }
   arena_.reserve((size_t)224 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
@@ -393,6 +395,8 @@ Detector::~Detector() {
     (void)hipEventDestroy(ev_x2_);
     (void)hipEventDestroy(ev_x3_);
     (void)hipEventDestroy(ev_side_);
+    (void)hipEventDestroy(ev_fork_);
+    (void)hipEventDestroy(ev_join_);
   }
   free_workspace();
   for (void* p : scratch_)
@@ -541,7 +545,19 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   const bool bf = bf16_;
   const size_t es = bf ? 2 : 4;
   hipStream_t cs = stream_;  // stream of the launches below (the side stream while the FPN branch is enqueued)
-  const bool overlap = overlap_ && !prof && fpn_composed_ && !bf16_;
+  const bool overlap = overlap_ >= 2 && !prof && fpn_composed_ && !bf16_;
+  const bool overlap_small = overlap_ >= 1 && !prof;
+  // run `side_work` on the second stream from this point of the main stream on; join() makes the main stream
+  // wait for it
+  auto fork = [&](auto&& side_work) {
+    OCR_HIP(hipEventRecord(ev_fork_, stream_));
+    OCR_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+    cs = side_stream_;
+    side_work();
+    cs = stream_;
+    OCR_HIP(hipEventRecord(ev_join_, side_stream_));
+  };
+  auto join = [&] { OCR_HIP(hipStreamWaitEvent(stream_, ev_join_, 0)); };
   auto conv = [&](const char* name, const ConvW& cw, const void* src, int hin, int win, int stride, void* out,
                   bool relu, const Extra& ex = Extra()) {
     ConvDesc d{};
@@ -679,12 +695,19 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     const int hin = l == 0 ? h4 : (h >> (1 + l)), win = l == 0 ? w4 : (w >> (1 + l));
     const int ho = h >> (2 + l), wo = w >> (2 + l);
     const int stride = l == 0 ? 1 : 2;
-    conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
     Extra sc;
     sc.residual = cur;
-    if (l > 0) {
-      conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
+    if (l > 0 && overlap_small) {
+      fork([&] { conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false); });
+      conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
+      join();
       sc.residual = d_[l];
+    } else {
+      conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
+      if (l > 0) {
+        conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
+        sc.residual = d_[l];
+      }
     }
     conv3x3("layer.conv2", layer_[l][0][1], t_[l], ho, wo, a_[l], sc.residual);
     conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
@@ -705,14 +728,26 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   // up2(in_{k+1}) + in_k that the out_k conv consumes (model.rs:126-137)
   conv("in5", in_[3], x_[3], h >> 5, w >> 5, 1, i_[3], false);
   if (fpn_composed_) {
-    {
-      Extra td;
-      td.up_residual = i_[3];
-      td.out2 = sum_[2];
-      conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
+    if (overlap_small) {
+      fork([&] { conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false); });
+      {
+        Extra td;
+        td.up_residual = i_[3];
+        td.out2 = sum_[2];
+        conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
+      }
+      conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
+      join();
+    } else {
+      {
+        Extra td;
+        td.up_residual = i_[3];
+        td.out2 = sum_[2];
+        conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
+      }
+      conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
+      conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
     }
-    conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
-    conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
     if (overlap) {
       OCR_HIP(hipEventRecord(ev_side_, side_stream_));
       OCR_HIP(hipStreamWaitEvent(stream_, ev_side_, 0));

@@ -72,11 +72,13 @@ class Detector {
 
   int device_;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
-  // OCR_OVERLAP=1: the FPN branch (p2, p3 and their bin_conv1 terms) runs on a second stream next to layer3 /
-  // layer4, filling the ramps and drains of the trunk's launches
-  bool overlap_ = false;
+  // Optional second stream (measured: no gain - the launches are MFMA / power bound).
+  // OCR_OVERLAP=1: the small independent launches side by side (the 1x1 s2 downsample next to its block's
+  // 3x3 s2 conv1, out5 next to in4 / out4); =2: also the FPN branch (p2, p3) next to layer3 / layer4.
+  // forward_profile always runs one stream (clean per-launch timing).
+  int overlap_ = 0;
   hipStream_t side_stream_ = nullptr;
-  hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr;
+  hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena arena_;
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
   ConvW layer_[4][2][2];  // [layer][block][conv1|conv2]
