@@ -26,7 +26,8 @@ def pretty(name: str) -> str:
     ty = "bf16" if "bf16" in a[0] or "__bf16" in a[0] else "f32"
     tile = f"{a[2]}x{a[3]}"
     store = {"0": "", "1": ",SHUFFLE2", "2": ",PHASE"}[a[7]]
-    return f"conv_igemm_{ty}<{tile},k{a[4]},s{a[5]},{'CAT4' if a[6] == '2' else 'PLAIN'}{store}>"
+    src = {"0": "PLAIN", "2": "CAT4", "3": "PYR4"}[a[6]]
+    return f"conv_igemm_{ty}<{tile},k{a[4]},s{a[5]},{src}{store}>"
 
 
 def load(d, counter):
