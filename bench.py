@@ -66,10 +66,10 @@ def pmc_traffic(kernel: str, n: int, s: int):
         t = json.load(open(path))
         if t.get("batch") == n and t.get("size") == s:
             e = t["kernels"].get(kernel)
-            return None if e is None else {"hbm_bytes_per_launch": e["bytes_per_launch"], "source": t["source"]}
+            return (None, None) if e is None else (e["bytes_per_launch"], t["source"])
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def text_like_maps(n: int, s: int, seed: int) -> np.ndarray:
@@ -196,9 +196,10 @@ def main():
         name, (ms, fl, by, cnt) = dom
         achieved = fl / (ms * 1e-3) / 1e12
         executed_gflop = sum(v[1] for v in agg.values()) / reps / 1e9
+        traffic, traffic_source = pmc_traffic(name, n, s)
         roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": pmc_traffic(name, n, s),
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_source,
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
                 "avg_launch_gflop": round(fl / cnt / 1e9, 3),
                 "all_kernels": {k: {"ms_per_step": round(v[0] / reps, 4),

@@ -9,6 +9,12 @@
 //   x8/x4/x2 nearest upsamples (:140) - the 256-channel fuse tensor is never written.
 // Fused into the epilogue: eval-mode batch norm as scale/bias, residual add, ReLU, and the
 //   FPN top-down sum  up2(in_{k+1}) + in_k  (:126-137) as a second output of the lateral conv.
+// Composed forms of the linear part of the graph (engine.hip builds the weights):
+//   STORE_PHASE - a 3x3 conv of a nearest-upsampled tensor as up*up 2x2 phase convs on the low-res grid
+//                 (p2 / p3 with their lateral 1x1 convs folded in);
+//   SRC_PYR4    - bin_conv1 over the upsampled concat per output phase (y mod 8, x mod 8) with p5, p4, p3, p2
+//                 as four sources of one K loop;
+//   batch = 16  - the sixteen GEMMs of a Winograd F(2x2,3x3) conv (winograd.hip) as grid slices of one launch.
 //
 // Data movement: both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds):
 // no staging registers, no ds_write, no per-K-step address arithmetic (the K-step offset is
@@ -100,6 +106,7 @@ struct ConvArgs {
   int nblk_m;   // tiles along M (PHASE: per phase; the grid holds up*up phases)
   int up_shift; // PHASE: log2 of the upsampling factor (1, 2, 3)
   int batch;    // batched GEMM: number of problems (grid slices along M); 1 otherwise
+  int pyr_chunked;  // PYR4 tile order (see the kernel)
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
 };
 
@@ -148,7 +155,24 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // (same for columns) - with that phase's pre-summed weights; the up*up phases are consecutive slices of
   // the grid.
   int ph = 0, pa = 0, pb = 0;
-  if constexpr (STORE == STORE_PHASE) {
+  if constexpr (SRC == SRC_PYR4) {
+    if ((p.nblk_m & 7) == 0 && p.pyr_chunked) {
+      // order (phase row a | chunk of 8 cell blocks | phase column b | block in chunk): an XCD's contiguous run of
+      // tiles is one phase row; the 8 x 8 tiles of a chunk share the source lines they gather (3 MB, L2-sized)
+      // and each weight set is used by 8 consecutive tiles.  Phase-major order fetched 3.5 GB for 280 MB of sources.
+      const int j = tile_m & 7;
+      pb = (tile_m >> 3) & 7;
+      const int rest = tile_m >> 6, nchunk = p.nblk_m >> 3;
+      pa = rest / nchunk;
+      tile_m = (rest - pa * nchunk) * 8 + j;
+      ph = pa * 8 + pb;
+    } else {
+      ph = tile_m / p.nblk_m;
+      tile_m -= ph * p.nblk_m;
+      pa = ph >> 3;
+      pb = ph & 7;
+    }
+  } else if constexpr (STORE == STORE_PHASE) {
     ph = tile_m / p.nblk_m;
     tile_m -= ph * p.nblk_m;
     pa = ph >> p.up_shift;
@@ -537,6 +561,10 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.nblk_m = (a.M + BM - 1) / BM;
   a.up_shift = d.up == 8 ? 3 : d.up == 4 ? 2 : 1;
   a.batch = d.batch > 1 ? d.batch : 1;
+  {
+    static const int chunked = [] { const char* e = getenv("OCR_PYR_ORDER"); return e ? atoi(e) : 1; }();
+    a.pyr_chunked = chunked;
+  }
   a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
