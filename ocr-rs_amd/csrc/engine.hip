@@ -134,6 +134,13 @@ void Detector::add_winograd_weights(ConvW& cw) {
   cw.wino_bytes = u.size() * sizeof(float);
 }
 
+void Detector::add_winograd_fused_weights(ConvW& cw) {
+  if (cw.cin != 64 || cw.cout != 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd is a 64 -> 64 3x3 kernel");
+  std::vector<float> u = winograd_weights(cw.host.data(), 64, 64);
+  for (size_t i = (size_t)12 * 64 * 64; i < u.size(); ++i) u[i] = -u[i];  // row i = 3 enters the output transform negated
+  cw.wino_fused = arena_.upload(u);
+}
+
 // A_k = out_k o in_k
 ConvW Detector::compose_lateral(const ConvW& out, const ConvW& in) {
   const std::vector<double> t = compose_taps(out, in);
@@ -229,6 +236,13 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     const char* e = getenv("OCR_WINOGRAD");
     if (e) winograd_min_cin_ = atoi(e) > 0 ? atoi(e) : (1 << 30);
   }
+  {
+    const char* e = getenv("OCR_WINOGRAD_FUSED");
+    winograd_fused_ = !(e && e[0] == '0');
+  }
+  if (winograd_fused_)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 2; ++c) add_winograd_fused_weights(layer_[0][b][c]);
   for (int l = 0; l < 4; ++l) {
     if ((64 << l) < winograd_min_cin_) continue;
     add_winograd_weights(layer_[l][0][1]);
@@ -244,6 +258,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       fpn_a_[l] = compose_lateral(out_[l], in_[l]);
       fpn_b_[l] = compose_upsampled(out_[l], in_[l + 1]);
     }
+  if (fpn_composed_ && winograd_fused_) add_winograd_fused_weights(fpn_a_[0]);
   bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
   if (fpn_composed_) {
     // slice s of the 256 input channels (p5, p4, p3, p2 = s 0..3), bin_bn1's scale folded in
@@ -625,12 +640,21 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
 
   // 3x3 s1 conv + BN (+ residual) + ReLU of the deep layers as Winograd F(2x2,3x3): input transform, sixteen
   // [tiles x Cin] x [Cin x Cout] GEMMs in one batched launch, output transform with the epilogue (f32 only)
-  auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual) {
+  auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual,
+                     bool relu = true) {
+    if (!bf && cw.wino_fused) {  // 64 -> 64: transforms fused into the GEMM kernel
+      rec.begin();
+      launch_winograd_fused64(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias,
+                              static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cs);
+      const double px = (double)n * hh * ww;
+      rec.end("winograd_fused_64x64", 2.0 * 16.0 * (px / 4.0) * 64 * 64, px * 64 * 4.0 * (residual ? 3.0 : 2.0) + 16.0 * 64 * 64 * 4);
+      return;
+    }
     const size_t th = (hh + 1) / 2, tw = (ww + 1) / 2, T = (size_t)n * th * tw;
     if (bf || !cw.wino || !wino_v_ || 16 * T * std::max(cw.cin, cw.cout) * 4 >= ((size_t)1 << 31)) {
       Extra ex;
       ex.residual = residual;
-      conv(name, cw, src, hh, ww, 1, out, true, ex);
+      conv(name, cw, src, hh, ww, 1, out, relu, ex);
       return;
     }
     rec.begin();
@@ -672,9 +696,13 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     Extra up;
     up.store = STORE_PHASE;
     conv("fpn.upsampled", fpn_b_[lv], x_[lv + 1], h >> (3 + lv), w >> (3 + lv), 1, p_[lv], false, up);
-    Extra lat;
-    lat.residual = p_[lv];
-    conv("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), 1, p_[lv], false, lat);
+    if (fpn_a_[lv].wino_fused && !bf) {
+      conv3x3("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), p_[lv], p_[lv], false);
+    } else {
+      Extra lat;
+      lat.residual = p_[lv];
+      conv("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), 1, p_[lv], false, lat);
+    }
     if (bf || bin_pyr_on_) return;  // bf16 keeps the single gathered bin_conv1; PYR4 takes all four terms at once
     if (lv == 0) {
       Extra first;
@@ -703,7 +731,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
       join();
       sc.residual = d_[l];
     } else {
-      conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
+      if (l == 0) conv3x3("layer.conv1", layer_[l][0][0], cur, hin, win, t_[l], nullptr);  // stride 1 in layer1
+      else conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
       if (l > 0) {
         conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
         sc.residual = d_[l];

@@ -36,6 +36,7 @@ struct ConvW {
   std::vector<float> host_scale;  // folded batch norm scale (empty: none), kept for weight composition
   float* wino = nullptr;   // Winograd F(2x2,3x3) weights U = G g G^T as [16][Cout][Cin] (3x3 s1 convs of the deep layers)
   size_t wino_bytes = 0;
+  float* wino_fused = nullptr;  // 64 -> 64 convs: the same with components 12..15 negated (winograd_fused.hip)
   int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
@@ -106,7 +107,9 @@ class Detector {
   // Winograd for 3x3 s1 trunk convs with Cin >= this (f32 precision only); OCR_WINOGRAD=0 disables, =<cin> overrides
   int winograd_min_cin_ = 256;
   float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [16][T][C] and [16][T][K] scratch of the layer in flight
-  void add_winograd_weights(ConvW& cw);  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
+  void add_winograd_weights(ConvW& cw);
+  void add_winograd_fused_weights(ConvW& cw);
+  bool winograd_fused_ = true;   // OCR_WINOGRAD_FUSED=0: direct convs for the 64 -> 64 layers  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;

@@ -1,0 +1,276 @@
+// Fused Winograd F(2x2, 3x3) for the 64 -> 64 channel 3x3 s1 p1 convs at H/4 (layer1's four convs and the FPN's
+// p2 lateral term, /root/reference/src/text_detection/model.rs:40-55, :126-129): input transform, the sixteen
+// element-wise GEMMs and the output transform in ONE kernel, so that none of the 16-component tensors that make
+// the unfused form (winograd.hip) HBM-bound at this resolution ever leaves the CU.
+//
+// A workgroup owns an 8 x 16 pixel output block = 4 x 8 Winograd tiles (32 rows of the GEMMs) and all 64 output
+// channels.  Its 10 x 18 x 64 input patch is brought into LDS once by LDS-DMA (zero padding = out-of-range
+// lanes).  Wave w owns the Winograd column j = w, i.e. the four components xi = (i, w), i = 0..3:
+//     V_iw = (B^T d B)_iw                         VALU, from the LDS patch into this wave's own operand buffer
+//     M_iw = V_iw [32 x 64] * U_iw [64 x 64]      64 v_mfma_f32_32x32x2_f32, U_iw streamed by LDS-DMA
+//     Z_w[a] = sum_i A^T[a][i] M_iw               i = 0 accumulates into Z_w[0], i = 3 into Z_w[1] (its weights are
+//                                                 stored negated), i = 1, 2 go through a temporary and VALU adds
+// and the column step of the output transform, Y[a][b] = sum_w A^T[b][w] Z_w[a], crosses the waves through LDS,
+// followed by folded BN, residual, ReLU and the store.  16 multiplies per 2x2 outputs instead of 36.
+// The 64 input channels are walked as two halves of 32 (everything above is linear in the channels, z keeps
+// accumulating), which halves every buffer: 22.5 KB patch + 4 x 4 KB V + 4 x 8 KB U = 70.5 KB, two workgroups per
+// CU - one multiplies while the other loads its patch, transforms, or runs its epilogue.
+#include "common.hpp"
+
+namespace ocr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename R>
+__device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
+struct WfArgs {
+  const float* x;         // [N][H][W][64]
+  const float* u;         // [16][64 cout][64 cin], components 12..15 (i = 3) negated
+  const float* scale;     // folded BN, may be null
+  const float* bias;
+  const float* residual;  // [N][H][W][64], may be null
+  float* y;
+  unsigned x_bytes;
+  int H, W, bh, bw;       // block grid: bh x bw blocks of 8 x 16 pixels per image
+  int relu;
+};
+
+constexpr int PH = 10, PWD = 18;                 // patch rows / columns
+constexpr int RAW_BYTES = PH * PWD * 128;        // 23040: one 32-channel half of the patch
+constexpr int V_BYTES = 32 * 128;                // one component, one channel half: 32 tiles x 32 channels
+constexpr int U_BYTES = 64 * 128;                // one component, one channel half: 64 couts x 32 channels
+constexpr int Z_BYTES = 4 * 2 * 32 * 64 * 4;     // output-transform exchange [wave][a][tile][cout]
+constexpr int WORK_BYTES = RAW_BYTES + 4 * V_BYTES + 4 * U_BYTES;   // 72192: two workgroups per CU
+constexpr int LDS_BYTES = WORK_BYTES > Z_BYTES ? WORK_BYTES : Z_BYTES;
+constexpr unsigned OOB = 0x80000000u;
+
+__global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int bx = b % p.bw;
+  b /= p.bw;
+  const int by = b % p.bh;
+  const int n = b / p.bh;
+  const int y0 = 8 * by, x0 = 16 * bx;
+
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, 16 * 64 * 64 * 4, 0x00020000);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)lds;
+  unsigned char* vbuf = lds + RAW_BYTES + wave * V_BYTES;
+  unsigned char* ubuf = lds + RAW_BYTES + 4 * V_BYTES + wave * U_BYTES;
+  const unsigned u_lds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(RAW_BYTES + 4 * V_BYTES + wave * U_BYTES));
+
+  // ---- input patch, channel half hc: 180 pixels x 128 B = 22.5 DMA instructions of 8 pixels, dealt to the waves
+  auto issue_patch = [&](int hc) {
+    const int sub = lane >> 3, chunk = lane & 7;
+    for (int k = wave; k < 23; k += 4) {
+      const int px = 8 * k + sub;
+      const int py = px / PWD, pxx = px - py * PWD;
+      const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+      const bool inside = px < PH * PWD && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const unsigned off = inside ? (unsigned)((((n * p.H + yy) * p.W + xx) * 64 + hc * 32 + chunk * 4) * 4) : OOB;
+      dma16(x_rsrc, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(k * 1024)), off, 0);
+    }
+  };
+  // ---- weights of component (i, wave), channel half hc: 8 DMA instructions of 8 rows x 128 B, swizzled like conv_igemm
+  // (staging them through registers instead, issued a whole step ahead, measured slower: 0.35 vs 0.33 ms)
+  const int urow = lane >> 3, uq = lane & 7;
+  auto issue_u = [&](int step) {  // step = 4 hc + i
+    const int hc = step >> 2, xi = 4 * (step & 3) + wave;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int row = m * 8 + urow;
+      const int gq = uq ^ ((row >> 1) & 7);
+      dma16(u_rsrc, u_lds + (unsigned)(m * 1024), (unsigned)((row * 64 + hc * 32 + gq * 4) * 4), xi * 64 * 64 * 4);
+    }
+  };
+  static_assert(23 * 1024 <= RAW_BYTES + 4 * V_BYTES, "the patch DMA's zero-filled tail stays inside the V buffers it precedes");
+  issue_patch(0);
+  issue_u(0);
+
+  // column pair and sign of B^T row `wave` (the wave's Winograd column), row pair and sign of B^T row i:
+  //   0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
+  const int ca = wave == 0 ? 0 : wave == 2 ? 2 : 1;
+  const int cb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
+  const float cs = wave == 1 ? 1.f : -1.f;
+
+  const int frow = lane & 31, half = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  int xoff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xoff[g] = ((2 * g + half) ^ fsw) * 16;
+
+  f32x16 z0[2], z1[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z0[nt][e] = z1[nt][e] = 0.f;
+
+  auto gemm = [&](f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(vbuf + frow * 128 + xoff[g]);
+      f32x4 bf[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const f32x4*>(ubuf + (nt * 32 + frow) * 128 + xoff[g]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[nt][e], acc[nt], 0, 0, 0);
+    }
+  };
+
+#pragma unroll
+  for (int hc = 0; hc < 2; ++hc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // this channel half of the patch is complete (every wave's share has landed)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // ---- V_iw for 32 tiles x 32 channels: 4 (tile, 4 channels) items per lane
+      constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+      const float rs = i == 1 ? 1.f : -1.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int item = k * 64 + lane;
+        const int tile = item >> 3, c4 = item & 7;
+        const int ty = tile >> 3, tx = tile & 7;
+        const unsigned char* base = lds + ((2 * ty) * PWD + 2 * tx) * 128 + c4 * 16;
+        const f32x4 daa = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + ca) * 128);
+        const f32x4 dab = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + cb) * 128);
+        const f32x4 dba = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + ca) * 128);
+        const f32x4 dbb = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + cb) * 128);
+        const f32x4 v = (daa + cs * dab) + rs * (dba + cs * dbb);
+        *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's U has landed, its V is written
+      if (i == 0) {
+        gemm(z0);
+      } else if (i == 3) {
+        gemm(z1);  // weights negated on the host: z1 -= M_3w
+      } else {
+        f32x16 t[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t[nt][e] = 0.f;
+        gemm(t);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          z0[nt] += t[nt];
+          if (i == 1) z1[nt] += t[nt];
+          else z1[nt] -= t[nt];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of U / V has returned
+      if (4 * hc + i + 1 < 8) issue_u(4 * hc + i + 1);     // the buffer is free: the next step's weights fly
+    }
+    if (hc == 0) {
+      __syncthreads();  // every wave is done reading the first half of the patch
+      issue_patch(1);
+    }
+  }
+
+  // ---- column step of the output transform across the waves, through LDS (patch / V / U are free now)
+  __syncthreads();
+  float* zb = reinterpret_cast<float*>(lds);  // [wave][a][tile 32][cout 64]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int tile = (e & 3) + 8 * (e >> 2) + 4 * half, co = nt * 32 + frow;
+      zb[((wave * 2 + 0) * 32 + tile) * 64 + co] = z0[nt][e];
+      zb[((wave * 2 + 1) * 32 + tile) * 64 + co] = z1[nt][e];
+    }
+  // residual rows of this thread's epilogue items (tile, 4 couts): requested before the barrier, the accumulators
+  // are dead by now
+  f32x4 res[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) res[k][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.residual) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int item = k * 256 + tid;
+      const int tile = item >> 4, c4 = (item & 15) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int yy = y0 + 2 * (tile >> 3) + (q >> 1), xx = x0 + 2 * (tile & 7) + (q & 1);
+        if (yy < p.H && xx < p.W) res[k][q] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)n * p.H + yy) * p.W + xx) * 64 + c4);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = k * 256 + tid;
+    const int tile = item >> 4, c4 = (item & 15) * 4;
+    const int ty = tile >> 3, tx = tile & 7;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + c4);
+    if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + c4);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x4 z[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) z[w] = *reinterpret_cast<const f32x4*>(&zb[((w * 2 + a) * 32 + tile) * 64 + c4]);
+      const f32x4 o0 = z[0] + z[1] + z[2];
+      const f32x4 o1 = z[1] - z[2] - z[3];
+      const int yy = y0 + 2 * ty + a;
+      if (yy >= p.H) continue;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int xx = x0 + 2 * tx + q;
+        if (xx >= p.W) continue;
+        const size_t o = (((size_t)n * p.H + yy) * p.W + xx) * 64 + c4;
+        f32x4 val = (q ? o1 : o0) * sc + bi + res[k][2 * a + q];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.y + o) = val;
+      }
+    }
+  }
+#endif
+}
+
+}  // namespace
+
+void launch_winograd_fused64(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,
+                             int relu, float* y, int N, int H, int W, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0) fail(OCR_ERR_INVALID, "winograd fused: bad shape N=%d H=%d W=%d", N, H, W);
+  const long long bytes = (long long)N * H * W * 64 * 4;
+  if (bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "winograd fused: input of %lld bytes must be < 2^31; split the batch", bytes);
+  WfArgs a{};
+  a.x = x;
+  a.u = u_neg3;
+  a.scale = scale;
+  a.bias = bias;
+  a.residual = residual;
+  a.y = y;
+  a.x_bytes = (unsigned)bytes;
+  a.H = H;
+  a.W = W;
+  a.bh = (H + 7) / 8;
+  a.bw = (W + 15) / 16;
+  a.relu = relu;
+  const long long blocks = (long long)N * a.bh * a.bw;
+  if (blocks >= (1ll << 31)) fail(OCR_ERR_INVALID, "winograd fused: grid too large");
+  hipLaunchKernelGGL(winograd_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  OCR_HIP(hipGetLastError());
+}
+
+}  // namespace ocr

@@ -132,6 +132,11 @@ WINO_CASES = [
     (1, 25, 25, 256, 256, True, True, True),     # odd grid (800x800 frames: layer4 is 25x25)
     (3, 3, 5, 256, 512, False, False, False),    # smaller than a tile row, ragged both ways, Cin != Cout
     (1, 1, 1, 256, 256, True, True, False),      # a single pixel: every tap but the centre is padding
+    # 64 -> 64: the fused-transform kernel (winograd_fused.hip), 8 x 16 pixel blocks
+    (2, 16, 32, 64, 64, True, True, True),       # whole blocks
+    (1, 9, 21, 64, 64, True, False, True),       # ragged blocks, odd sizes
+    (3, 1, 1, 64, 64, False, False, False),      # single pixels
+    (2, 160, 160, 64, 64, True, True, True),     # layer1 grid at 640x640
 ]
 
 
