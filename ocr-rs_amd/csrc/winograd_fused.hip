@@ -45,7 +45,8 @@ struct WfArgs {
 };
 
 constexpr int PH = 10, PWD = 18;                 // patch rows / columns
-constexpr int RAW_BYTES = PH * PWD * 128;        // 23040: one 32-channel half of the patch
+constexpr int RAW_BYTES = 23 * 1024;             // one 32-channel half of the patch: 180 px x 128 B = 23040, rounded up to
+                                                 // whole DMA instructions (the last one zero-fills 512 bytes past the patch)
 constexpr int V_BYTES = 32 * 128;                // one component, one channel half: 32 tiles x 32 channels
 constexpr int U_BYTES = 64 * 128;                // one component, one channel half: 64 couts x 32 channels
 constexpr int Z_BYTES = 4 * 2 * 32 * 64 * 4;     // output-transform exchange [wave][a][tile][cout]
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       dma16(u_rsrc, u_lds + (unsigned)(m * 1024), (unsigned)((row * 64 + hc * 32 + gq * 4) * 4), xi * 64 * 64 * 4);
     }
   };
-  static_assert(23 * 1024 <= RAW_BYTES + 4 * V_BYTES, "the patch DMA's zero-filled tail stays inside the V buffers it precedes");
+  static_assert(23 * 1024 <= RAW_BYTES && PH * PWD * 128 <= RAW_BYTES, "the patch DMA stays inside its buffer");
   issue_patch(0);
   issue_u(0);
 
@@ -155,6 +156,12 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
         *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v;
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's U has landed, its V is written
+      if (hc == 0 && i == 3) {
+        // the last transform of the first channel half is done in every wave: fetch the second half of the patch
+        // now, under the MFMAs of this step
+        __syncthreads();
+        issue_patch(1);
+      }
       if (i == 0) {
         gemm(z0);
       } else if (i == 3) {
@@ -175,10 +182,6 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of U / V has returned
       if (4 * hc + i + 1 < 8) issue_u(4 * hc + i + 1);     // the buffer is free: the next step's weights fly
-    }
-    if (hc == 0) {
-      __syncthreads();  // every wave is done reading the first half of the patch
-      issue_patch(1);
     }
   }
 
