@@ -142,17 +142,23 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       // ---- V_iw for 32 tiles x 32 channels: 4 (tile, 4 channels) items per lane
       constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
       const float rs = i == 1 ? 1.f : -1.f;
+      f32x4 d[4][4];  // all sixteen reads first: one LDS round trip per step instead of one per item
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int item = k * 64 + lane;
         const int tile = item >> 3, c4 = item & 7;
-        const int ty = tile >> 3, tx = tile & 7;
-        const unsigned char* base = lds + ((2 * ty) * PWD + 2 * tx) * 128 + c4 * 16;
-        const f32x4 daa = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + ca) * 128);
-        const f32x4 dab = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + cb) * 128);
-        const f32x4 dba = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + ca) * 128);
-        const f32x4 dbb = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + cb) * 128);
-        const f32x4 v = (daa + cs * dab) + rs * (dba + cs * dbb);
+        const unsigned char* base = lds + ((2 * (tile >> 3)) * PWD + 2 * (tile & 7)) * 128 + c4 * 16;
+        d[k][0] = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + ca) * 128);
+        d[k][1] = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + cb) * 128);
+        d[k][2] = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + ca) * 128);
+        d[k][3] = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + cb) * 128);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int item = k * 64 + lane;
+        const int tile = item >> 3, c4 = item & 7;
+        const f32x4 v = (d[k][0] + cs * d[k][1]) + rs * (d[k][2] + cs * d[k][3]);
         *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v;
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's U has landed, its V is written
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 
   // ---- column step of the output transform across the waves, through LDS (patch / V / U are free now)
   __syncthreads();
+
   float* zb = reinterpret_cast<float*>(lds);  // [wave][a][tile 32][cout 64]
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
