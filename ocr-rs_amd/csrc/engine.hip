@@ -135,9 +135,9 @@ void Detector::add_winograd_weights(ConvW& cw) {
 }
 
 void Detector::add_winograd_fused_weights(ConvW& cw) {
-  if (cw.cin != 64 || cw.cout != 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd is a 64 -> 64 3x3 kernel");
-  std::vector<float> u = winograd_weights(cw.host.data(), 64, 64);
-  for (size_t i = (size_t)12 * 64 * 64; i < u.size(); ++i) u[i] = -u[i];  // row i = 3 enters the output transform negated
+  if ((cw.cin != 64 && cw.cin != 128) || cw.cout % 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd: unsupported conv shape");
+  std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin);
+  for (size_t i = (size_t)12 * cw.cout * cw.cin; i < u.size(); ++i) u[i] = -u[i];  // row i = 3 enters the output transform negated
   cw.wino_fused = arena_.upload(u);
 }
 
@@ -240,9 +240,14 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     const char* e = getenv("OCR_WINOGRAD_FUSED");
     winograd_fused_ = !(e && e[0] == '0');
   }
-  if (winograd_fused_)
+  if (winograd_fused_) {
     for (int b = 0; b < 2; ++b)
       for (int c = 0; c < 2; ++c) add_winograd_fused_weights(layer_[0][b][c]);
+    // layer2's stride-1 convs (128 -> 128 at H/8)
+    add_winograd_fused_weights(layer_[1][0][1]);
+    add_winograd_fused_weights(layer_[1][1][0]);
+    add_winograd_fused_weights(layer_[1][1][1]);
+  }
   for (int l = 0; l < 4; ++l) {
     if ((64 << l) < winograd_min_cin_) continue;
     add_winograd_weights(layer_[l][0][1]);
@@ -258,7 +263,10 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       fpn_a_[l] = compose_lateral(out_[l], in_[l]);
       fpn_b_[l] = compose_upsampled(out_[l], in_[l + 1]);
     }
-  if (fpn_composed_ && winograd_fused_) add_winograd_fused_weights(fpn_a_[0]);
+  if (fpn_composed_ && winograd_fused_) {
+    add_winograd_fused_weights(fpn_a_[0]);  // p2 lateral term, 64 -> 64 at H/4
+    add_winograd_fused_weights(fpn_a_[1]);  // p3 lateral term, 128 -> 64 at H/8
+  }
   bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
   if (fpn_composed_) {
     // slice s of the 256 input channels (p5, p4, p3, p2 = s 0..3), bin_bn1's scale folded in
@@ -644,10 +652,11 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
                      bool relu = true) {
     if (!bf && cw.wino_fused) {  // 64 -> 64: transforms fused into the GEMM kernel
       rec.begin();
-      launch_winograd_fused64(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias,
-                              static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cs);
+      launch_winograd_fused(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
+                            relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, cs);
       const double px = (double)n * hh * ww;
-      rec.end("winograd_fused_64x64", 2.0 * 16.0 * (px / 4.0) * 64 * 64, px * 64 * 4.0 * (residual ? 3.0 : 2.0) + 16.0 * 64 * 64 * 4);
+      rec.end(cw.cin == 64 ? "winograd_fused<c64>" : "winograd_fused<c128>", 2.0 * 16.0 * (px / 4.0) * cw.cin * cw.cout,
+              px * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 16.0 * cw.cin * cw.cout * 4);
       return;
     }
     const size_t th = (hh + 1) / 2, tw = (ww + 1) / 2, T = (size_t)n * th * tw;

@@ -1,5 +1,6 @@
-// Fused Winograd F(2x2, 3x3) for the 64 -> 64 channel 3x3 s1 p1 convs at H/4 (layer1's four convs and the FPN's
-// p2 lateral term, /root/reference/src/text_detection/model.rs:40-55, :126-129): input transform, the sixteen
+// Fused Winograd F(2x2, 3x3) for the 3x3 s1 p1 convs of the large grids: 64 -> 64 at H/4 (layer1's four convs and
+// the FPN's p2 lateral term) and 128 -> 128 / 128 -> 64 at H/8 (layer2, the p3 lateral term),
+// /root/reference/src/text_detection/model.rs:40-55, :126-133: input transform, the sixteen
 // element-wise GEMMs and the output transform in ONE kernel, so that none of the 16-component tensors that make
 // the unfused form (winograd.hip) HBM-bound at this resolution ever leaves the CU.
 //
@@ -33,18 +34,19 @@ __device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, 
 }
 
 struct WfArgs {
-  const float* x;         // [N][H][W][64]
-  const float* u;         // [16][64 cout][64 cin], components 12..15 (i = 3) negated
+  const float* x;         // [N][H][W][C]
+  const float* u;         // [16][K cout][C cin], components 12..15 (i = 3) negated
   const float* scale;     // folded BN, may be null
   const float* bias;
-  const float* residual;  // [N][H][W][64], may be null
-  float* y;
-  unsigned x_bytes;
+  const float* residual;  // [N][H][W][K], may be null
+  float* y;               // [N][H][W][K]
+  unsigned x_bytes, u_bytes;
   int H, W, bh, bw;       // block grid: bh x bw blocks of 8 x 16 pixels per image
+  int C, K, kblocks;      // channels in / out, K / 64
   int relu;
 };
 
-constexpr int PH = 10, PWD = 18;                 // patch rows / columns
+[[maybe_unused]] constexpr int PH = 10, PWD = 18;                 // patch rows / columns
 constexpr int RAW_BYTES = 23 * 1024;             // one 32-channel half of the patch: 180 px x 128 B = 23040, rounded up to
                                                  // whole DMA instructions (the last one zero-fills 512 bytes past the patch)
 constexpr int V_BYTES = 32 * 128;                // one component, one channel half: 32 tiles x 32 channels
@@ -54,12 +56,16 @@ constexpr int WORK_BYTES = RAW_BYTES + 4 * V_BYTES + 4 * U_BYTES;   // 72192: tw
 constexpr int LDS_BYTES = WORK_BYTES > Z_BYTES ? WORK_BYTES : Z_BYTES;
 constexpr unsigned OOB = 0x80000000u;
 
+// NCH = C / 32: the input channels are walked in chunks of 32; a workgroup produces 64 of the K output channels
+template <int NCH>
 __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
+  const int kb = b % p.kblocks;  // innermost: the K / 64 workgroups of a pixel block share its patch in L2
+  b /= p.kblocks;
   const int bx = b % p.bw;
   b /= p.bw;
   const int by = b % p.bh;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
   const int y0 = 8 * by, x0 = 16 * bx;
 
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, 16 * 64 * 64 * 4, 0x00020000);
+  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
   const unsigned lds0 = (unsigned)(size_t)(lds_void*)lds;
   unsigned char* vbuf = lds + RAW_BYTES + wave * V_BYTES;
   unsigned char* ubuf = lds + RAW_BYTES + 4 * V_BYTES + wave * U_BYTES;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       const int py = px / PWD, pxx = px - py * PWD;
       const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
       const bool inside = px < PH * PWD && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const unsigned off = inside ? (unsigned)((((n * p.H + yy) * p.W + xx) * 64 + hc * 32 + chunk * 4) * 4) : OOB;
+      const unsigned off = inside ? (unsigned)((((n * p.H + yy) * p.W + xx) * p.C + hc * 32 + chunk * 4) * 4) : OOB;
       dma16(x_rsrc, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(k * 1024)), off, 0);
     }
   };
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     for (int m = 0; m < 8; ++m) {
       const int row = m * 8 + urow;
       const int gq = uq ^ ((row >> 1) & 7);
-      dma16(u_rsrc, u_lds + (unsigned)(m * 1024), (unsigned)((row * 64 + hc * 32 + gq * 4) * 4), xi * 64 * 64 * 4);
+      dma16(u_rsrc, u_lds + (unsigned)(m * 1024), (unsigned)((row * p.C + hc * 32 + gq * 4) * 4), (xi * p.K + kb * 64) * p.C * 4);
     }
   };
   static_assert(23 * 1024 <= RAW_BYTES && PH * PWD * 128 <= RAW_BYTES, "the patch DMA stays inside its buffer");
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
   };
 
 #pragma unroll
-  for (int hc = 0; hc < 2; ++hc) {
+  for (int hc = 0; hc < NCH; ++hc) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // this channel half of the patch is complete (every wave's share has landed)
 #pragma unroll
@@ -162,11 +168,11 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
         *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v;
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's U has landed, its V is written
-      if (hc == 0 && i == 3) {
-        // the last transform of the first channel half is done in every wave: fetch the second half of the patch
-        // now, under the MFMAs of this step
+      if (hc + 1 < NCH && i == 3) {
+        // the last transform of this channel chunk is done in every wave: fetch the next chunk of the patch now,
+        // under the MFMAs of this step
         __syncthreads();
-        issue_patch(1);
+        issue_patch(hc + 1);
       }
       if (i == 0) {
         gemm(z0);
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of U / V has returned
-      if (4 * hc + i + 1 < 8) issue_u(4 * hc + i + 1);     // the buffer is free: the next step's weights fly
+      if (4 * hc + i + 1 < 4 * NCH) issue_u(4 * hc + i + 1);  // the buffer is free: the next step's weights fly
     }
   }
 
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int yy = y0 + 2 * (tile >> 3) + (q >> 1), xx = x0 + 2 * (tile & 7) + (q & 1);
-        if (yy < p.H && xx < p.W) res[k][q] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)n * p.H + yy) * p.W + xx) * 64 + c4);
+        if (yy < p.H && xx < p.W)
+          res[k][q] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4);
       }
     }
   }
@@ -229,8 +236,8 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     const int tile = item >> 4, c4 = (item & 15) * 4;
     const int ty = tile >> 3, tx = tile & 7;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + c4);
-    if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + c4);
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
+    if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + kb * 64 + c4);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       f32x4 z[4];
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       for (int q = 0; q < 2; ++q) {
         const int xx = x0 + 2 * tx + q;
         if (xx >= p.W) continue;
-        const size_t o = (((size_t)n * p.H + yy) * p.W + xx) * 64 + c4;
+        const size_t o = (((size_t)n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4;
         f32x4 val = (q ? o1 : o0) * sc + bi + res[k][2 * a + q];
         if (p.relu) {
 #pragma unroll
@@ -259,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 
 }  // namespace
 
-void launch_winograd_fused64(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,
-                             int relu, float* y, int N, int H, int W, hipStream_t s) {
-  if (N <= 0 || H <= 0 || W <= 0) fail(OCR_ERR_INVALID, "winograd fused: bad shape N=%d H=%d W=%d", N, H, W);
-  const long long bytes = (long long)N * H * W * 64 * 4;
+void launch_winograd_fused(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,
+                           int relu, float* y, int N, int H, int W, int C, int K, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || (C != 64 && C != 128) || K % 64 || K <= 0)
+    fail(OCR_ERR_INVALID, "winograd fused: bad shape N=%d H=%d W=%d C=%d K=%d", N, H, W, C, K);
+  const long long bytes = (long long)N * H * W * C * 4;
   if (bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "winograd fused: input of %lld bytes must be < 2^31; split the batch", bytes);
+  if ((long long)N * H * W * K * 4 >= (1ll << 40)) fail(OCR_ERR_INVALID, "winograd fused: output too large");
   WfArgs a{};
   a.x = x;
   a.u = u_neg3;
@@ -272,14 +281,19 @@ void launch_winograd_fused64(const float* x, const float* u_neg3, const float* s
   a.residual = residual;
   a.y = y;
   a.x_bytes = (unsigned)bytes;
+  a.u_bytes = (unsigned)(16ll * K * C * 4);
   a.H = H;
   a.W = W;
   a.bh = (H + 7) / 8;
   a.bw = (W + 15) / 16;
+  a.C = C;
+  a.K = K;
+  a.kblocks = K / 64;
   a.relu = relu;
-  const long long blocks = (long long)N * a.bh * a.bw;
+  const long long blocks = (long long)N * a.bh * a.bw * a.kblocks;
   if (blocks >= (1ll << 31)) fail(OCR_ERR_INVALID, "winograd fused: grid too large");
-  hipLaunchKernelGGL(winograd_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  if (C == 64) hipLaunchKernelGGL(winograd_fused_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(winograd_fused_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
 

@@ -137,6 +137,9 @@ WINO_CASES = [
     (1, 9, 21, 64, 64, True, False, True),       # ragged blocks, odd sizes
     (3, 1, 1, 64, 64, False, False, False),      # single pixels
     (2, 160, 160, 64, 64, True, True, True),     # layer1 grid at 640x640
+    (2, 80, 80, 128, 128, True, True, True),     # layer2 conv2: four channel chunks, two output-channel blocks
+    (1, 13, 37, 128, 64, False, True, False),    # p3 lateral term (128 -> 64), ragged blocks
+    (1, 8, 16, 64, 128, True, False, True),      # 64 -> 128
 ]
 
 
