@@ -51,7 +51,9 @@ constexpr int RAW_BYTES = 23 * 1024;             // one 32-channel half of the p
                                                  // whole DMA instructions (the last one zero-fills 512 bytes past the patch)
 constexpr int V_BYTES = 32 * 128;                // one component, one channel half: 32 tiles x 32 channels
 constexpr int U_BYTES = 64 * 128;                // one component, one channel half: 64 couts x 32 channels
-constexpr int Z_BYTES = 4 * 2 * 32 * 64 * 4;     // output-transform exchange [wave][a][tile][cout]
+constexpr int ZROW = 68;                         // exchange row of 64 couts, padded: the two lane halves of a C-layout store
+                                                 // sit 4 rows apart and would otherwise hit the same banks
+constexpr int Z_BYTES = 4 * 2 * 32 * ZROW * 4;   // output-transform exchange [wave][a][tile][cout]
 constexpr int WORK_BYTES = RAW_BYTES + 4 * V_BYTES + 4 * U_BYTES;   // 72192: two workgroups per CU
 constexpr int LDS_BYTES = WORK_BYTES > Z_BYTES ? WORK_BYTES : Z_BYTES;
 constexpr unsigned OOB = 0x80000000u;
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int tile = (e & 3) + 8 * (e >> 2) + 4 * half, co = nt * 32 + frow;
-      zb[((wave * 2 + 0) * 32 + tile) * 64 + co] = z0[nt][e];
-      zb[((wave * 2 + 1) * 32 + tile) * 64 + co] = z1[nt][e];
+      zb[((wave * 2 + 0) * 32 + tile) * ZROW + co] = z0[nt][e];
+      zb[((wave * 2 + 1) * 32 + tile) * ZROW + co] = z1[nt][e];
     }
   // residual rows of this thread's epilogue items (tile, 4 couts): requested before the barrier, the accumulators
   // are dead by now
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     for (int a = 0; a < 2; ++a) {
       f32x4 z[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) z[w] = *reinterpret_cast<const f32x4*>(&zb[((w * 2 + a) * 32 + tile) * 64 + c4]);
+      for (int w = 0; w < 4; ++w) z[w] = *reinterpret_cast<const f32x4*>(&zb[((w * 2 + a) * 32 + tile) * ZROW + c4]);
       const f32x4 o0 = z[0] + z[1] + z[2];
       const f32x4 o1 = z[1] - z[2] - z[3];
       const int yy = y0 + 2 * ty + a;

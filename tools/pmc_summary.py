@@ -13,7 +13,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             if "ocr::" not in r["Kernel_Name"]:
                 continue
-            name = r["Kernel_Name"].split("(")[0].replace("void ocr::igemm::", "").replace("ocr::(anonymous namespace)::", "")
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ocr::igemm::", "").replace("ocr::", "")
             c = r["Counter_Name"]
             if c not in counters:
                 counters.append(c)
