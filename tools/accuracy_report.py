@@ -25,12 +25,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
 
 n = sys.argv[1] if len(sys.argv) > 1 else "2"
 s = sys.argv[2] if len(sys.argv) > 2 else "256"
-for label, env in (("default (composed FPN + Winograd layer3/4)", {}),
-                   ("OCR_WINOGRAD=0", {"OCR_WINOGRAD": "0"}),
+for label, env in (("default (composed FPN, fused Winograd layer1/2, Winograd layer3/4)", {}),
+                   ("OCR_WINOGRAD_FUSED=0", {"OCR_WINOGRAD_FUSED": "0"}),
+                   ("OCR_WINOGRAD=0 OCR_WINOGRAD_FUSED=0 (direct convs, composed FPN)", {"OCR_WINOGRAD": "0", "OCR_WINOGRAD_FUSED": "0"}),
                    ("OCR_FPN_UNFUSED=1", {"OCR_FPN_UNFUSED": "1"}),
-                   ("OCR_WINOGRAD=0 OCR_FPN_UNFUSED=1 (layer-by-layer direct convs)", {"OCR_WINOGRAD": "0", "OCR_FPN_UNFUSED": "1"}),
-                   ("OCR_WINOGRAD=64 (every 3x3 s1 trunk conv)", {"OCR_WINOGRAD": "64"})):
+                   ("OCR_WINOGRAD=0 OCR_WINOGRAD_FUSED=0 OCR_FPN_UNFUSED=1 (layer-by-layer direct convs)",
+                    {"OCR_WINOGRAD": "0", "OCR_WINOGRAD_FUSED": "0", "OCR_FPN_UNFUSED": "1"})):
     e = dict(os.environ)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", n, s], env=e, capture_output=True, text=True)
-    print(f"{label:66s} {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr.strip()[-200:]}")
+    print(f"{label:88s} {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr.strip()[-200:]}")

@@ -20,6 +20,8 @@ def pretty(name: str) -> str:
         return "stem_conv7x7_bn_relu_maxpool" if "stem_kernel" in name else \
                "convt2x2_sigmoid" if "convt2_sigmoid" in name else \
                "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else \
+               "winograd_fused<c64>" if "winograd_fused_kernel<2>" in name else \
+               "winograd_fused<c128>" if "winograd_fused_kernel<4>" in name else \
                "winograd_input_transform" if "winograd_input" in name else \
                "winograd_output_transform" if "winograd_output" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
