@@ -16,6 +16,8 @@
 // The 64 input channels are walked as two halves of 32 (everything above is linear in the channels, z keeps
 // accumulating), which halves every buffer: 22.5 KB patch + 4 x 4 KB V + 4 x 8 KB U = 70.5 KB, two workgroups per
 // CU - one multiplies while the other loads its patch, transforms, or runs its epilogue.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ocr {
@@ -145,29 +147,46 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
   for (int hc = 0; hc < NCH; ++hc) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // this channel half of the patch is complete (every wave's share has landed)
+    f32x4 c1[4], c2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      // ---- V_iw for 32 tiles x 32 channels: 4 (tile, 4 channels) items per lane
-      constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
-      const float rs = i == 1 ? 1.f : -1.f;
-      f32x4 d[4][4];  // all sixteen reads first: one LDS round trip per step instead of one per item
+      // ---- V_iw for 32 tiles x 32 channels: 4 (tile, 4 channels) items per lane.  The column step of the transform
+      // (patch row r -> c[r] = d[r][ca] + cs d[r][cb]) is shared by the components: rows 1 and 2 stay in registers
+      // from i = 0 / 1 on, so a chunk costs 32 LDS reads per lane instead of 64.
+      auto col = [&](int r, f32x4 (&c)[4]) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int item = k * 64 + lane;
-        const int tile = item >> 3, c4 = item & 7;
-        const unsigned char* base = lds + ((2 * (tile >> 3)) * PWD + 2 * (tile & 7)) * 128 + c4 * 16;
-        d[k][0] = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + ca) * 128);
-        d[k][1] = *reinterpret_cast<const f32x4*>(base + (RA[i] * PWD + cb) * 128);
-        d[k][2] = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + ca) * 128);
-        d[k][3] = *reinterpret_cast<const f32x4*>(base + (RB[i] * PWD + cb) * 128);
+        for (int k = 0; k < 4; ++k) {
+          const int item = k * 64 + lane;
+          const int tile = item >> 3, c4 = item & 7;
+          const unsigned char* base = lds + ((2 * (tile >> 3) + r) * PWD + 2 * (tile & 7)) * 128 + c4 * 16;
+          c[k] = *reinterpret_cast<const f32x4*>(base + ca * 128) + cs * *reinterpret_cast<const f32x4*>(base + cb * 128);
+        }
+      };
+      f32x4 v[4];
+      if (i == 0) {        // d0 - d2
+        f32x4 c0[4];
+        col(0, c0);
+        col(2, c2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = c0[k] - c2[k];
+      } else if (i == 1) { // d1 + d2
+        col(1, c1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = c1[k] + c2[k];
+      } else if (i == 2) { // d2 - d1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = c2[k] - c1[k];
+      } else {             // d1 - d3
+        f32x4 c3[4];
+        col(3, c3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = c1[k] - c3[k];
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int item = k * 64 + lane;
         const int tile = item >> 3, c4 = item & 7;
-        const f32x4 v = (d[k][0] + cs * d[k][1]) + rs * (d[k][2] + cs * d[k][3]);
-        *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v;
+        *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v[k];
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's U has landed, its V is written
       if (hc + 1 < NCH && i == 3) {
@@ -294,8 +313,9 @@ void launch_winograd_fused(const float* x, const float* u_neg3, const float* sca
   a.relu = relu;
   const long long blocks = (long long)N * a.bh * a.bw * a.kblocks;
   if (blocks >= (1ll << 31)) fail(OCR_ERR_INVALID, "winograd fused: grid too large");
-  if (C == 64) hipLaunchKernelGGL(winograd_fused_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(winograd_fused_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  static const int extra_lds = getenv("OCR_WF_EXTRA_LDS") ? atoi(getenv("OCR_WF_EXTRA_LDS")) : 0;  // tuning knob: caps residency
+  if (C == 64) hipLaunchKernelGGL(winograd_fused_kernel<2>, dim3((unsigned)blocks), dim3(256), extra_lds, s, a);
+  else hipLaunchKernelGGL(winograd_fused_kernel<4>, dim3((unsigned)blocks), dim3(256), extra_lds, s, a);
   OCR_HIP(hipGetLastError());
 }
 
