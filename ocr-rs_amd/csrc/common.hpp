@@ -64,6 +64,7 @@ struct ConvDesc {
   // shape, problem b reading src + b * M*Cin, wgt + b * Cout*Cin and writing out + b * M*Cout (elements);
   // src_bytes / wgt_bytes cover all of them.  0 or 1 = a single problem.
   int batch;
+  int pyr_nsrc;           // SRC_PYR4: 0 / 4 = all four sources, 3 = p5, p4, p3 only (p2's term is computed elsewhere)
   const void* wgt;
   const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32
   const float* bias;

@@ -107,6 +107,7 @@ struct ConvArgs {
   int up_shift; // PHASE: log2 of the upsampling factor (1, 2, 3)
   int batch;    // batched GEMM: number of problems (grid slices along M); 1 otherwise
   int pyr_chunked;  // PYR4 tile order (see the kernel)
+  int pyr_nsrc;     // PYR4: 4 = p5, p4, p3, p2; 3 = without p2
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
 };
 
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 
   // One pass = all channel chunks of one source (PLAIN: the only one; CAT4: four passes of 2 chunks).
   constexpr bool MULTI = SRC == SRC_CAT4 || SRC == SRC_PYR4;
-  constexpr int NSRC = MULTI ? 4 : 1;
+  const int NSRC = SRC == SRC_PYR4 ? p.pyr_nsrc : MULTI ? 4 : 1;  // PYR4 may leave p2 (its last source) to another kernel
   const int pass_chunks = MULTI ? 64 / BK : csteps;
   int par = 0;  // LDS stage holding the K-step about to be multiplied
   issue_plain(0, avoff[0], 0, 0, 0);
@@ -564,6 +565,7 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   {
     static const int chunked = [] { const char* e = getenv("OCR_PYR_ORDER"); return e ? atoi(e) : 1; }();
     a.pyr_chunked = chunked;
+    a.pyr_nsrc = d.pyr_nsrc == 3 ? 3 : 4;
   }
   a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);

@@ -319,6 +319,11 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       bin_pyr_ = finish_composed(std::move(w), 64, 64, 3);
       bin_pyr_.up = 8;
       bin_pyr_.bias = bin1_.bias;
+      if (winograd_fused_) {
+        // p2's 3x3 term leaves the phase launch and runs as a fused Winograd conv on top of it (bias + ReLU there)
+        add_winograd_fused_weights(bin_p2_);
+        bin_p2_.bias = bin1_.bias;
+      }
     }
   }
   {  // bin_conv_tr1 [Cin=64][Cout=64][2][2] + bias, then bin_bn2:
@@ -562,6 +567,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     void* out2 = nullptr;
     bool cat4 = false;
     bool pyr4 = false;      // SRC_PYR4: the four pyramid levels as sources of one phase-conv launch
+    int pyr_nsrc = 4;       // ... or only the three upsampled ones (3)
     bool f32_out = false;   // bf16 precision: keep this conv's result (and residual) in f32
     int store = STORE_NHWC;
   };
@@ -588,6 +594,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     const bool in_bf = bf && ex.store != STORE_SHUFFLE2;
     d.in_bf16 = in_bf ? 1 : 0;
     d.out_bf16 = (in_bf && !ex.cat4 && !ex.f32_out) ? 1 : 0;
+    d.pyr_nsrc = ex.pyr_nsrc;
     d.up = cw.up;
     const size_t ies = in_bf ? 2 : 4;
     d.src[0] = src;
@@ -629,7 +636,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     const double reps = ex.store == STORE_PHASE ? (double)(cw.up * cw.up) : 1.0;  // phase convs per low-res pixel
     // taps executed per low-res pixel over all phases: (up + 2)^2 (edge phases 2, inner phases 1 per direction)
     // PYR4 per cell: (8+2)^2 + 4 (4+2)^2 + 16 (2+2)^2 tap-phases of the upsampled levels + 64 * 9 of p2
-    const double K = ex.pyr4 ? 64.0 * (100 + 144 + 256 + 576)
+    const double K = ex.pyr4 ? 64.0 * (100 + 144 + 256 + (ex.pyr_nsrc == 4 ? 576 : 0))
                              : ex.store == STORE_PHASE ? (double)cw.cin * (cw.up + 2) * (cw.up + 2) : (double)cw.ks * cw.ks * cw.cin;
     double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
     if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
@@ -811,7 +818,16 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     py.pyr4 = true;
     py.store = STORE_PHASE;
     py.f32_out = true;
-    conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+    if (bin_p2_.wino_fused) {
+      // the three upsampled sources in the phase launch, p2's 3x3 term on top as a fused Winograd conv (+ bias, ReLU)
+      py.pyr_nsrc = 3;
+      ConvW up3 = bin_pyr_;
+      up3.bias = nullptr;
+      conv("bin_conv1.pyramid", up3, p_[3], h >> 5, w >> 5, 1, b1_, false, py);
+      conv3x3("bin_conv1.p2", bin_p2_, p_[0], h4, w4, b1_, b1_, true);
+    } else {
+      conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+    }
   } else if (fpn_composed_ && !bf) {
     // the p2 quarter as a plain 3x3 conv and the three upsampled quarters as phase convs on their own grids;
     // partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more
