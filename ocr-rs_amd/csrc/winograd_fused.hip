@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     }
   };
   // ---- weights of component (i, wave), channel half hc: 8 DMA instructions of 8 rows x 128 B, swizzled like conv_igemm
-  // (staging them through registers instead, issued a whole step ahead, measured slower: 0.35 vs 0.33 ms)
+  // (measured slower: staging them through registers a whole step ahead, 0.35 vs 0.33 ms; and feeding the MFMA B
+  // operand straight from global memory in a lane-contiguous K order with no U in LDS at all, 0.32 vs 0.31 ms -
+  // both push the kernel to the 256-VGPR cap of two waves per SIMD)
   const int urow = lane >> 3, uq = lane & 7;
   auto issue_u = [&](int step) {  // step = 4 hc + i
     const int hc = step >> 2, xi = 4 * (step & 3) + wave;
