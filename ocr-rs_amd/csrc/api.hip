@@ -647,7 +647,7 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     const float* d_sc = scale ? dev(scale, cout) : nullptr;
     const float* d_bi = bias ? dev(bias, cout) : nullptr;
     const float* d_res = residual ? dev(residual, out_e) : nullptr;
-    if ((cin == 64 || cin == 128) && cout % 64 == 0 && getenv("OCR_TEST_WINOGRAD_UNFUSED") == nullptr) {  // the fused kernel
+    if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && getenv("OCR_TEST_WINOGRAD_UNFUSED") == nullptr) {  // the fused kernel
       std::vector<float> un = u;
       for (size_t i = (size_t)12 * cout * cin; i < un.size(); ++i) un[i] = -un[i];
       float* d_un = dev(un.data(), un.size());

@@ -143,6 +143,7 @@ WINO_CASES = [
 ]
 
 
+
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
 def test_winograd_conv_matches_aten(det, case):
     """Winograd F(2x2,3x3) path (weight transform, input transform, batched GEMM, output transform with the
