@@ -58,8 +58,8 @@ constexpr int ZROW = 68;                         // exchange row of 64 couts, pa
                                                  // sit 4 rows apart and would otherwise hit the same banks
 constexpr int Z_BYTES = 4 * 2 * 32 * ZROW * 4;   // output-transform exchange [wave][a][tile][cout]
 constexpr int WORK_BYTES = RAW_BYTES + 4 * V_BYTES + 4 * U_BYTES;   // 72192: two workgroups per CU
-constexpr int LDS_BYTES = WORK_BYTES > Z_BYTES ? WORK_BYTES : Z_BYTES;
-constexpr unsigned OOB = 0x80000000u;
+[[maybe_unused]] constexpr int LDS_BYTES = WORK_BYTES > Z_BYTES ? WORK_BYTES : Z_BYTES;
+[[maybe_unused]] constexpr unsigned OOB = 0x80000000u;
 
 // NCH = C / 32: the input channels are walked in chunks of 32; a workgroup produces 64 of the K output channels
 template <int NCH>
