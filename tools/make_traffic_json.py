@@ -22,6 +22,7 @@ def pretty(name: str) -> str:
                "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else \
                "winograd_fused<c64>" if "winograd_fused_kernel<2>" in name else \
                "winograd_fused<c128>" if "winograd_fused_kernel<4>" in name else \
+               "winograd_fused<c256>" if "winograd_fused_kernel<8>" in name else \
                "winograd_input_transform" if "winograd_input" in name else \
                "winograd_output_transform" if "winograd_output" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
