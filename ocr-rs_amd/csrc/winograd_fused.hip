@@ -56,9 +56,9 @@ constexpr int V_BYTES = 32 * 128;                // one component, one channel h
 constexpr int U_BYTES = 64 * 128;                // one component, one channel half: 64 couts x 32 channels
 constexpr int ZROW = 68;                         // exchange row of 64 couts, padded: the two lane halves of a C-layout store
                                                  // sit 4 rows apart and would otherwise hit the same banks
-constexpr int Z_BYTES = 4 * 2 * 32 * ZROW * 4;   // output-transform exchange [wave][a][tile][cout]
+constexpr int Z_BYTES = 4 * 32 * ZROW * 4;       // output-transform exchange of one output row a: [wave][tile][cout]
 constexpr int WORK_BYTES = RAW_BYTES + 4 * V_BYTES + 4 * U_BYTES;   // 72192: two workgroups per CU
-[[maybe_unused]] constexpr int LDS_BYTES = WORK_BYTES > Z_BYTES ? WORK_BYTES : Z_BYTES;
+[[maybe_unused]] constexpr int LDS_BYTES = WORK_BYTES > RAW_BYTES + Z_BYTES ? WORK_BYTES : RAW_BYTES + Z_BYTES;
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;
 
 // NCH = C / 32: the input channels are walked in chunks of 32; a workgroup produces 64 of the K output channels
@@ -72,15 +72,20 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
   // start of every second one to de-phase the pairs did not help.  A variant with 16-channel chunks (44 KB of LDS,
   // a second V buffer per wave so that the next transform overlaps the MFMAs, three workgroups per CU at 168
   // VGPRs) was 25 % slower: twice the steps, half the MFMA burst per step, register spills.
+  bool patch_in_flight = false;  // chunk 0 of this block's patch was requested during the previous block
   for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
-  int b = blk;
-  const int kb = b % p.kblocks;  // innermost: the K / 64 workgroups of a pixel block share its patch in L2
-  b /= p.kblocks;
-  const int bx = b % p.bw;
-  b /= p.bw;
-  const int by = b % p.bh;
-  const int n = b / p.bh;
-  const int y0 = 8 * by, x0 = 16 * bx;
+  // block -> (image, pixel block, output-channel block); innermost kb: the K / 64 workgroups of a pixel block share
+  // its patch in L2
+  auto coords = [&](int bb, int& n_, int& y0_, int& x0_, int& kb_) {
+    kb_ = bb % p.kblocks;
+    bb /= p.kblocks;
+    x0_ = 16 * (bb % p.bw);
+    bb /= p.bw;
+    y0_ = 8 * (bb % p.bh);
+    n_ = bb / p.bh;
+  };
+  int n, y0, x0, kb;
+  coords(blk, n, y0, x0, kb);
 
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
@@ -90,14 +95,14 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
   const unsigned u_lds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(RAW_BYTES + 4 * V_BYTES + wave * U_BYTES));
 
   // ---- input patch, channel half hc: 180 pixels x 128 B = 22.5 DMA instructions of 8 pixels, dealt to the waves
-  auto issue_patch = [&](int hc) {
+  auto issue_patch_at = [&](int pn, int py0, int px0, int hc) {
     const int sub = lane >> 3, chunk = lane & 7;
     for (int k = wave; k < 23; k += 4) {
       const int px = 8 * k + sub;
       const int py = px / PWD, pxx = px - py * PWD;
-      const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+      const int yy = py0 - 1 + py, xx = px0 - 1 + pxx;
       const bool inside = px < PH * PWD && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const unsigned off = inside ? (unsigned)((((n * p.H + yy) * p.W + xx) * p.C + hc * 32 + chunk * 4) * 4) : OOB;
+      const unsigned off = inside ? (unsigned)((((pn * p.H + yy) * p.W + xx) * p.C + hc * 32 + chunk * 4) * 4) : OOB;
       dma16(x_rsrc, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(k * 1024)), off, 0);
     }
   };
@@ -116,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     }
   };
   static_assert(23 * 1024 <= RAW_BYTES && PH * PWD * 128 <= RAW_BYTES, "the patch DMA stays inside its buffer");
-  issue_patch(0);
+  auto issue_patch = [&](int hc) { issue_patch_at(n, y0, x0, hc); };
+  if (!patch_in_flight) issue_patch(0);
+  patch_in_flight = false;
   issue_u(0);
 
   // column pair and sign of B^T row `wave` (the wave's Winograd column), row pair and sign of B^T row i:
@@ -197,11 +204,20 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
         *reinterpret_cast<f32x4*>(vbuf + tile * 128 + ((c4 ^ ((tile >> 1) & 7)) * 16)) = v[k];
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's U has landed, its V is written
-      if (hc + 1 < NCH && i == 3) {
-        // the last transform of this channel chunk is done in every wave: fetch the next chunk of the patch now,
-        // under the MFMAs of this step
-        __syncthreads();
-        issue_patch(hc + 1);
+      if (i == 3) {
+        // the last transform of this channel chunk is done in every wave: fetch the next chunk of the patch - or
+        // the first chunk of the NEXT block's patch (the exchange buffer of the epilogue lies behind the patch
+        // buffer) - now, under the MFMAs of this step
+        if (hc + 1 < NCH) {
+          __syncthreads();
+          issue_patch(hc + 1);
+        } else if (blk + (int)gridDim.x < p.nblocks) {
+          __syncthreads();
+          int nn, ny0, nx0, nkb;
+          coords(blk + (int)gridDim.x, nn, ny0, nx0, nkb);
+          issue_patch_at(nn, ny0, nx0, 0);
+          patch_in_flight = true;
+        }
       }
       if (i == 0) {
         gemm(z0);
@@ -226,52 +242,50 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     }
   }
 
-  // ---- column step of the output transform across the waves, through LDS (patch / V / U are free now)
-  __syncthreads();
-
-  float* zb = reinterpret_cast<float*>(lds);  // [wave][a][tile 32][cout 64]
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int tile = (e & 3) + 8 * (e >> 2) + 4 * half, co = nt * 32 + frow;
-      zb[((wave * 2 + 0) * 32 + tile) * ZROW + co] = z0[nt][e];
-      zb[((wave * 2 + 1) * 32 + tile) * ZROW + co] = z1[nt][e];
-    }
-  // residual rows of this thread's epilogue items (tile, 4 couts): requested before the barrier, the accumulators
-  // are dead by now
+  // ---- column step of the output transform across the waves, through LDS, one output row a at a time: the
+  // exchange buffer [wave][tile 32][ZROW] lies behind the patch buffer (over the V / U buffers, free now)
+  float* zb = reinterpret_cast<float*>(lds + RAW_BYTES);
   f32x4 res[2][4];
 #pragma unroll
   for (int k = 0; k < 2; ++k)
 #pragma unroll
     for (int q = 0; q < 4; ++q) res[k][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (p.residual) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    __syncthreads();  // a = 0: every wave is done with V / U;  a = 1: row 0 has been combined
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tile = (e & 3) + 8 * (e >> 2) + 4 * half, co = nt * 32 + frow;
+        zb[(wave * 32 + tile) * ZROW + co] = a == 0 ? z0[nt][e] : z1[nt][e];
+      }
+    if (a == 0 && p.residual) {
+      // residual rows of this thread's epilogue items (tile, 4 couts): in flight during the exchange
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int item = k * 256 + tid;
+        const int tile = item >> 4, c4 = (item & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int yy = y0 + 2 * (tile >> 3) + (q >> 1), xx = x0 + 2 * (tile & 7) + (q & 1);
+          if (yy < p.H && xx < p.W)
+            res[k][q] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4);
+        }
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int item = k * 256 + tid;
       const int tile = item >> 4, c4 = (item & 15) * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int yy = y0 + 2 * (tile >> 3) + (q >> 1), xx = x0 + 2 * (tile & 7) + (q & 1);
-        if (yy < p.H && xx < p.W)
-          res[k][q] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4);
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int item = k * 256 + tid;
-    const int tile = item >> 4, c4 = (item & 15) * 4;
-    const int ty = tile >> 3, tx = tile & 7;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
-    if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + kb * 64 + c4);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
+      const int ty = tile >> 3, tx = tile & 7;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
+      if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + kb * 64 + c4);
       f32x4 z[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) z[w] = *reinterpret_cast<const f32x4*>(&zb[((w * 2 + a) * 32 + tile) * ZROW + c4]);
+      for (int w = 0; w < 4; ++w) z[w] = *reinterpret_cast<const f32x4*>(&zb[(w * 32 + tile) * ZROW + c4]);
       const f32x4 o0 = z[0] + z[1] + z[2];
       const f32x4 o1 = z[1] - z[2] - z[3];
       const int yy = y0 + 2 * ty + a;
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       }
     }
   }
-  __syncthreads();  // the exchange buffer has been read: the next block's patch may land
+  __syncthreads();  // the exchange buffer has been read: the next block's V / U may be written
   }  // blk
 #endif
 }
