@@ -271,6 +271,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
   if (fpn_composed_ && winograd_fused_) {
     add_winograd_fused_weights(fpn_a_[0]);  // p2 lateral term, 64 -> 64 at H/4
     add_winograd_fused_weights(fpn_a_[1]);  // p3 lateral term, 128 -> 64 at H/8
+    add_winograd_fused_weights(out_[2]);    // out4, 256 -> 64 at H/16
   }
   bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
   if (fpn_composed_) {
@@ -786,7 +787,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
         td.out2 = sum_[2];
         conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
       }
-      conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
+      conv3x3("out", out_[2], sum_[2], h >> 4, w >> 4, p_[2], nullptr, false);
       join();
     } else {
       {
@@ -795,7 +796,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
         td.out2 = sum_[2];
         conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
       }
-      conv("out", out_[2], sum_[2], h >> 4, w >> 4, 1, p_[2], false);
+      conv3x3("out", out_[2], sum_[2], h >> 4, w >> 4, p_[2], nullptr, false);
       conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
     }
     if (overlap) {
