@@ -318,3 +318,29 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     assert d < 1e-5
     with pytest.raises(capi.OcrError):
         det.debug_stage(5, (n, h // 4, w // 4, 256))
+
+
+@pytest.mark.parametrize("env", [
+    {"OCR_WINOGRAD_FUSED": "0"},                                   # direct convs on the large grids, unfused Winograd layer3/4
+    {"OCR_WINOGRAD": "0", "OCR_WINOGRAD_FUSED": "0"},             # no Winograd at all
+    {"OCR_BIN_PYR": "0"},                                         # bin_conv1 as four launches
+    {"OCR_FPN_UNFUSED": "1"},                                     # layer-by-layer FPN
+    {"OCR_FPN_UNFUSED": "1", "OCR_WINOGRAD": "0", "OCR_WINOGRAD_FUSED": "0", "OCR_TAIL_UNFUSED": "1"},  # the plain graph
+    {"OCR_OVERLAP": "1"}, {"OCR_OVERLAP": "2"},                   # second-stream schedules
+], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
+def test_engine_modes_agree(det, det_w, monkeypatch, env):
+    """Every graph-level option of the engine computes the same map: within 1e-5 of the
+    default engine and within TOL of the oracle.  The options are read when a detector is created."""
+    n, h, w = 2, 96, 160
+    x = W.synth_image_batch(33, n, h, w)
+    base = det.forward_host(x)
+    ref = T.det_forward(det_w, x)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = capi.Detector(W.pack_blob(det_w), 0)
+    try:
+        got = other.forward_host(x)
+    finally:
+        other.close()
+    assert np.abs(got - base).max() < 1e-5
+    assert np.abs(got - ref).max() < TOL
