@@ -101,6 +101,13 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   float o[4][4];  // [tap][u] of this lane's pixel
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // bin_conv_tr2's weights of this lane's 32 channels (co = 32 ct + (e&3) + 8 (e>>2) + 4 half) do not depend on the
+  // tap: into registers once.  Read from LDS inside the tap loop they were 32 more dependent round trips per tap.
+  f32x4 w2r[2][16];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) w2r[ct][e] = *reinterpret_cast<const f32x4*>(&tab_w2[(32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half) * 4]);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t + 1 < 4) issue_w(t + 1, (t + 1) & 1);
@@ -126,15 +133,22 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
       }
     // acc[ct][e] = Z_t^T[co][pixel = lane&31] with co = 32 ct + (e&3) + 8 (e>>2) + 4 half
     float part[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sv[2][4], bv[2][4];  // folded bias / bin_bn2 of this tap: all sixteen reads first, then the arithmetic
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co0 = t * 64 + 32 * ct + 8 * q + 4 * half;
+        sv[ct][q] = *reinterpret_cast<const f32x4*>(&tab_s[co0]);
+        bv[ct][q] = *reinterpret_cast<const f32x4*>(&tab_b[co0]);
+      }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int co = 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const float z = fmaxf(acc[ct][e] * tab_s[t * 64 + co] + tab_b[t * 64 + co], 0.f);  // + bias, bin_bn2, ReLU
-        const f32x4 w2 = *reinterpret_cast<const f32x4*>(&tab_w2[co * 4]);
+        const float z = fmaxf(acc[ct][e] * sv[ct][e >> 2][e & 3] + bv[ct][e >> 2][e & 3], 0.f);  // + bias, bin_bn2, ReLU
 #pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2[u], part[u]);
+        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2r[ct][e][u], part[u]);
       }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
