@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, c
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
                                                    TO* __restrict__ out, int H, int W) {
   __shared__ __attribute__((aligned(16))) float in_s[2 * PLANE];
-  __shared__ __attribute__((aligned(16))) float conv_s[NPIX][64];
+  __shared__ __attribute__((aligned(16))) float conv_s[32 * MTILES][64];  // padded to whole MFMA tiles: stores need no guard
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.z;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, c
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
-      if (p < NPIX) {
+      {
         const int qr = p / CC, qc = p - qr * CC;
         // conv positions outside the conv grid are max-pool padding: they never win against the
         // always-valid window centre because ReLU output is >= 0.
