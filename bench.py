@@ -9,18 +9,32 @@ one batch of 32 synthetic 640x640 frames that are already resident in HBM, per G
 weights; there is no data-path collective - results are gathered once, after the
 timed region, to show the exchange step).  Prints ONE JSON line on rank 0.
 
+`python bench.py --gpus N` is a complete command for any N: when it is not already running
+under torch.distributed.run (no RANK in the environment) and N > 1, this process only LAUNCHES -
+before it has made any GPU call it starts N child ranks of itself (subprocess, one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's JSON line and
+exits non-zero if any rank failed.  Under `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` the ranks exist already and it just runs as one of them.
+
 Extra objects in that line:
   roofline      dominant kernel (largest summed time), measured live with HIP events
-                on the launch stream: algorithmic FLOPs of its launches / their time,
-                against the 157.3 TF/s dense f32 MFMA peak of MI355X.
-  cpu_baseline  the same graph on the host cores through ATen-CPU (oracle/torch_ref.py,
-                the operator library the reference reaches through tch), bounded sample.
+                on the launch stream: the MFMA FLOPs its launches EXECUTE / their time,
+                against the 157.3 TF/s dense f32 MFMA peak of MI355X (frac <= 1 by construction;
+                `algorithmic_tflops` is the reference graph's direct-conv work / the same time).
+  roofline_rec  the recogniser kernel, same definition, at B = 256 (configs[2]) and B = 65536.
+  cpu_baseline  the same graphs on the host cores through ATen-CPU (oracle/torch_ref.py,
+                the operator library the reference reaches through tch), bounded samples:
+                detector at all cores (headline) and one thread, recogniser, post-processing.
+  N > 1 only    rccl_ranks, all_gather_results_ms, detect_postprocess_gather_images_per_s (forward +
+                get_boxes_and_box_scores + the result all-gather inside the timed loop).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,63 +42,137 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import ocr_rs_amd  # noqa: E402,F401
-from ocr_rs_amd import capi  # noqa: E402
-from ocr_rs_amd import weights as W  # noqa: E402
-
-F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the headline vendor figure includes 2:1 sparsity)
+# /opt/skills/guides/MI355X_MICROARCH.md, "Chip-level parameters": Peak FP32 (matrix) 157.3 TFLOPS (spec; 155 measured),
+# Peak BF16/FP16 MFMA ~2.5 PF dense (the 5 PF vendor figure includes 2:1 sparsity), HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_640_IMAGE = 48.365568  # SURVEY.md section 8(d) / BASELINE.md section 2
+MFLOP_PER_CROP = 8.587264
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline detector leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip recognition / post-processing side numbers")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control flow only, no GPU: the ranks rendezvous on gloo, all-gather fake polygon lists and rank 0 "
+                         "prints a line marked dry_run (used by the CPU test of the launcher path; never a measurement)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the reference's arithmetic (BASELINE configs[1], the headline); bf16 = the opt-in "
-                         "OCR_PRECISION_BF16 trunk/FPN (configs[4]), reported as its own line")
-    return ap.parse_args()
+                         "OCR_PRECISION_BF16 detector (configs[4]), reported as its own line")
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no RANK in the environment.  Makes NO GPU call and imports
+# neither torch nor the library; the ranks are child processes (never a re-exec of this one).
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    import tempfile
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting in a rendezvous or a collective: end them (these exact
+        # children, by PID) as soon as one has failed
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                failed = True
+                time.sleep(2.0)
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+        codes = [p.wait() for p in procs]
+        out0.seek(0)
+        text = out0.read()
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if failed or any(codes):
+        sys.stderr.write(f"bench.py: ranks failed, exit codes by rank: {codes}\n")
+        return 1
+    if not any(line.startswith("{") for line in text.splitlines()):
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------
 def pmc_traffic(kernel: str, n: int, s: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md);
-    None when no extract for this workload is committed.  Not measured live: PMC needs rocprofv3."""
+    None when no extract for this workload is committed.  Not measured live: PMC needs rocprofv3.
+    The extract carries the git hash of the tree it was taken on (`git_head`), so a stale file shows."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
         if t.get("batch") == n and t.get("size") == s:
             e = t["kernels"].get(kernel)
-            return (None, None) if e is None else (e["bytes_per_launch"], t["source"])
+            src = t["source"] + (f" @ {t['git_head']}" if t.get("git_head") else "")
+            return (None, None) if e is None else (e["bytes_per_launch"], src)
     except Exception:
         pass
     return None, None
 
 
-def text_like_maps(n: int, s: int, seed: int) -> np.ndarray:
+def text_like_maps(n: int, s: int, seed: int):
     """Probability maps with text-like blobs (the reference's gt_shrinked fixtures, cropped to s x s and
     jittered): random-weight network outputs are noise, which is not what post-processing sees in use."""
+    import numpy as np
     from PIL import Image
     rng = np.random.RandomState(seed)
     names = ["gt_shrinked_img55.png", "gt_shrinked_img224.png", "gt_shrinked_img494.png", "gt_shrinked_img545.png"]
+    base = [np.array(Image.open(os.path.join(ROOT, "tests", "golden", nm)).convert("L")) for nm in names]
     out = []
     for i in range(n):
-        g = np.array(Image.open(os.path.join(ROOT, "tests", "golden", names[i % 4])).convert("L"))
+        g = base[i % 4]
         o = (800 - s) // 2
         g = g[o:o + s, o:o + s] if s <= 800 else np.pad(g, ((0, s - 800), (0, s - 800)))
         out.append(np.where(g > 127, 0.8 + 0.2 * rng.rand(s, s), 0.1 * rng.rand(s, s)).astype(np.float32))
     return np.ascontiguousarray(np.stack(out)[:, None])
+
+
+def dense_text_maps(n: int, s: int, seed: int):
+    """Post-processing stress maps: a grid of word-sized slanted boxes (about 50 per 640 x 640 frame)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    out = np.empty((n, 1, s, s), np.float32)
+    yy, xx = np.mgrid[0:s, 0:s]
+    for i in range(n):
+        m = np.zeros((s, s), bool)
+        for gy in range(20, s - 40, 64):
+            for gx in range(16, s - 90, 104):
+                w, h = 60 + rng.randint(0, 30), 18 + rng.randint(0, 14)
+                sl = rng.uniform(-0.15, 0.15)
+                x0, y0 = gx + rng.randint(0, 8), gy + rng.randint(0, 8)
+                m |= (xx >= x0) & (xx < x0 + w) & (yy >= y0 + sl * (xx - x0)) & (yy < y0 + h + sl * (xx - x0))
+        out[i, 0] = np.where(m, 0.8 + 0.2 * rng.rand(s, s), 0.1 * rng.rand(s, s))
+    return out
 
 
 def host_cores() -> int:
@@ -99,33 +187,100 @@ def host_cores() -> int:
     return min(n, 16) if n > 64 else n
 
 
-def cpu_baseline(det_w, size: int, budget_s: float):
-    """Reference stand-in on the host cores: same graph through ATen CPU kernels."""
+def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
+    """Reference stand-in on the host cores: the same graphs through ATen CPU kernels
+    (oracle/torch_ref.py), and the post-processing restatement (oracle/postproc_oracle.py).  Bounded samples."""
+    import numpy as np
+    import torch
+    from oracle import postproc_oracle as PO
     from oracle import torch_ref as T
+    from ocr_rs_amd import weights as W
     cores = host_cores()
+
+    def det_rate(threads, batch, max_frames, budget):
+        torch.set_num_threads(threads)
+        x = W.synth_image_batch(1, batch, size, size)
+        T.det_forward(det_w, x[:1])  # warm the thread pool / allocator
+        done, t0 = 0, time.perf_counter()
+        while True:
+            T.det_forward(det_w, x)
+            done += x.shape[0]
+            el = time.perf_counter() - t0
+            if el > budget or done >= max_frames:
+                return done, el
+
+    done, el = det_rate(cores, 2, 64, budget_s)
+    out = {"value": round(done / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{done} frames of {size}x{size} f32 in batches of 2 through oracle/torch_ref.py "
+                     f"(ATen CPU, {cores} threads), {el:.1f} s"}
+    d1, e1 = det_rate(1, 1, 2, 4.0)
+    out["one_thread"] = {"value": round(d1 / e1, 3), "unit": "images/s", "cores": 1, "sample": f"{d1} frames, {e1:.1f} s"}
     torch.set_num_threads(cores)
-    x = W.synth_image_batch(1, 2, size, size)
-    T.det_forward(det_w, x[:1])  # warm the thread pool / allocator
-    done, t0 = 0, time.perf_counter()
-    while True:
-        T.det_forward(det_w, x)
-        done += x.shape[0]
-        el = time.perf_counter() - t0
-        if el > budget_s or done >= 64:
-            break
-    return {"value": round(done / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{done} frames of {size}x{size} f32 in batches of 2 through oracle/torch_ref.py "
-                      f"(ATen CPU, {cores} threads), {el:.1f} s"}
+    crops = W.synth_crops(2, 4096)
+    T.rec_forward(rec_w, crops[:256])
+    t0, it = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 3.0:
+        T.rec_classify(T.rec_forward(rec_w, crops))
+        it += 1
+    el = time.perf_counter() - t0
+    out["recognition"] = {"value": round(it * 4096 / el, 1), "unit": "crops/s", "cores": cores, "kind": "port",
+                          "sample": f"{it} x 4096 crops of 28x28 through oracle/torch_ref.py (forward + softmax f64 + top-1), {el:.1f} s"}
+    maps = text_like_maps(4, size, 7)
+    t0, it = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 3.0:
+        PO.get_boxes_and_box_scores(maps, np.ones((4, 2)))
+        it += 1
+    el = time.perf_counter() - t0
+    out["postprocess"] = {"value": round(it * 4 / el, 2), "unit": "images/s", "cores": 1, "kind": "port",
+                          "sample": f"{it} x 4 text-like {size}x{size} maps through oracle/postproc_oracle.py "
+                                    f"(numpy/pure-Python restatement, one thread), {el:.1f} s"}
+    return out
+
+
+def dry_run(a) -> None:
+    """The multi-rank control flow without a GPU (gloo): rendezvous, result all-gather, one line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    import ocr_rs_amd  # noqa: F401
+    from ocr_rs_amd import parallel as P
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("OCR_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(3)  # test hook: a rank that dies must fail the launcher
+    images = 0
+    if world > 1:
+        dist.init_process_group("gloo")
+        polys = [[[(rank, i), (rank + 1, i), (rank + 1, i + 1), (rank, i + 1)]] * (i % 3) for i in range(a.batch)]
+        scores = [[0.9] * (i % 3) for i in range(a.batch)]
+        all_p, _ = P.all_gather_results(polys, scores, torch.device("cpu"))
+        images = len(all_p)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "all_gather_results": {"images": images}}), flush=True)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if a.dry_run:
+        return dry_run(a)
+
+    import numpy as np
+    import torch
+
+    import ocr_rs_amd  # noqa: F401
+    from ocr_rs_amd import capi
+    from ocr_rs_amd import weights as W
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # one rank per GPU; OCR_BENCH_BACKEND=gloo (+ fewer GPUs than ranks) only exists to rehearse the
@@ -143,6 +298,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+    comm_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
 
     n, s = a.batch, a.size
     det_w = W.make_det_weights(0)
@@ -165,6 +321,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v: float) -> float:
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     with torch.cuda.stream(stream):
         for _ in range(a.warmup):
             step()
@@ -174,10 +337,7 @@ def main():
             step()
         fence()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=x.device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream
     roof = None
@@ -194,75 +354,125 @@ def main():
                 e[3] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (ms, fl, by, cnt) = dom
+        # the engine reports the MFMA FLOPs a launch EXECUTES: `achieved` / `frac` are matrix-core utilisation.
+        # A fused Winograd F(2x2,3x3) launch is a 3x3 conv whose direct-algorithm work (2 M N 9C, what SURVEY 8d
+        # counts for the reference graph) is 36/16 of that; it is reported beside, never as the fraction.
         executed = fl / (ms * 1e-3) / 1e12
-        # the engine reports the FLOPs a kernel executes.  A fused Winograd F(2x2,3x3) launch is a 3x3 conv whose
-        # algorithmic work (2 M N 9C, what SURVEY 8d counts) is 36/16 of the multiplies it executes; `achieved`
-        # is algorithmic work / time as the contract defines it (so it can exceed the MFMA peak of the direct
-        # algorithm), `executed` is what the matrix cores actually do.
         alg_factor = 36.0 / 16.0 if name.startswith("winograd_fused") else 1.0
-        achieved = executed * alg_factor
         executed_gflop = sum(v[1] for v in agg.values()) / reps / 1e9
         traffic, traffic_source = pmc_traffic(name, n, s)
-        roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "executed": {"tflops": round(executed, 2), "frac": round(executed / peak, 4),
-                             "note": "MFMA FLOPs the kernel executes / time" + (
-                                 "; Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36" if alg_factor > 1 else "")},
+        roof = {"kernel": name, "bound": "mfma", "achieved": round(executed, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(executed / peak, 4),
+                "definition": "MFMA FLOPs the kernel executes per launch / average launch duration (HIP events on the launch stream)",
+                "algorithmic_tflops": round(executed * alg_factor, 2), "algorithmic_speedup": round(alg_factor, 3),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_source,
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
-                "avg_launch_gflop": round(fl * alg_factor / cnt / 1e9, 3),
+                "avg_launch_gflop_executed": round(fl / cnt / 1e9, 3),
                 "all_kernels": {k: {"ms_per_step": round(v[0] / reps, 4),
                                     "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None,
                                     "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
 
-    # ---- the exchange step of the sharded path (outside the timed region): every rank post-processes
-    # text-like maps of its shard (get_boxes_and_box_scores) and the variable-length polygon blocks
-    # are all-gathered - RCCL over xGMI when the backend is nccl (ocr-rs_amd/parallel.py)
-    gathered = None
+    # ---- post-processing and the exchange step of the sharded path: every rank post-processes text-like maps
+    # of its shard (get_boxes_and_box_scores) and the variable-length polygon blocks are all-gathered -
+    # RCCL over xGMI when the backend is nccl (ocr-rs_amd/parallel.py)
     post = {}
+    polys = scores = pm = adj = params = None
     try:
-        maps = text_like_maps(min(n, 8), s, seed=rank)
-        pm = torch.from_numpy(maps).to(x.device)
-        torch.cuda.synchronize()
         params = capi.default_params(skip_degenerate=True)
-        adj = np.ones((maps.shape[0], 2))
-        polys, scores = det.postprocess(pm, maps.shape[0], s, s, adj, capi.MEM_DEVICE, params)
-        t1 = time.perf_counter()
+        maps = text_like_maps(n, s, seed=rank)
+        pm = torch.from_numpy(maps).to(x.device)
+        adj = np.ones((n, 2))
+        torch.cuda.synchronize()
+        polys, scores = det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
         reps = 3
+        t1 = time.perf_counter()
         for _ in range(reps):
-            det.postprocess(pm, maps.shape[0], s, s, adj, capi.MEM_DEVICE, params)
-        post = {"postprocess_images_per_s": round(maps.shape[0] * reps / (time.perf_counter() - t1), 1),
-                "postprocess_polygons_per_image": round(sum(len(p) for p in polys) / maps.shape[0], 2)}
-        if dist is not None:
-            from ocr_rs_amd import parallel as P
-            all_p, all_s = P.all_gather_results(polys, scores, x.device if backend == "nccl" else torch.device("cpu"))
-            gathered = {"images": len(all_p), "polygons": sum(len(p) for p in all_p)}
+            det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
+        post = {"postprocess_images_per_s": round(n * reps / (time.perf_counter() - t1), 1),
+                "postprocess_polygons_per_image": round(sum(len(p) for p in polys) / n, 2)}
+        if rank == 0 and not a.no_extras:
+            dm = torch.from_numpy(dense_text_maps(n, s, 5)).to(x.device)
+            dp, _ = det.postprocess(dm, n, s, s, adj, capi.MEM_DEVICE, params)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                det.postprocess(dm, n, s, s, adj, capi.MEM_DEVICE, params)
+            post["postprocess_dense_images_per_s"] = round(n * reps / (time.perf_counter() - t1), 1)
+            post["postprocess_dense_polygons_per_image"] = round(sum(len(p) for p in dp) / n, 2)
     except Exception as e:  # side numbers never hide the headline
-        post = {"postprocess_error": str(e)}
+        post["postprocess_error"] = f"{type(e).__name__}: {e}"
+        polys = None
+    if dist is not None:
+        # the collective section runs only when EVERY rank has results (a rank that failed above must not leave
+        # the others waiting in an all-gather)
+        ok = torch.tensor([0.0 if polys is None else 1.0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            from ocr_rs_amd import parallel as P
+            all_p, all_s = P.all_gather_results(polys, scores, comm_dev)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                P.all_gather_results(polys, scores, comm_dev)
+            gather_ms = max_over_ranks((time.perf_counter() - t1) / 10 * 1e3)
+            # configs[3] as a pipeline: forward + get_boxes_and_box_scores + all-gather of the polygon lists per step
+            with torch.cuda.stream(stream):
+                fence()
+                k = max(3, a.steps // 4)
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    step()
+                    pl, sc = det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
+                    P.all_gather_results(pl, sc, comm_dev)
+                fence()
+                e2e = max_over_ranks(time.perf_counter() - t1)
+            post.update({"rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                         "collective_backend": backend + (f" (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})" if backend == "nccl" else ""),
+                         "all_gather_results_ms": round(gather_ms, 3),
+                         "all_gather_results": {"images": len(all_p), "polygons": sum(len(p) for p in all_p)},
+                         "detect_postprocess_gather_images_per_s": round(n * world * k / e2e, 1),
+                         "detect_postprocess_gather_note": "per step and rank: forward of its 32 frames, get_boxes_and_box_scores over 32 "
+                                                           "text-like maps, all-gather of the polygon lists; sequential on one stream"})
 
     extras = {}
+    rec_w = W.make_rec_weights(0)
     if rank == 0 and not a.no_extras:
         try:
-            rec_w = W.make_rec_weights(0)
             rec = capi.Recognizer(W.pack_blob(rec_w), local)
             rec.set_stream(stream.cuda_stream)
-            nc = 256
-            crops = torch.from_numpy(W.synth_crops(2, nc)).to(x.device)
-            labels = torch.empty(nc, dtype=torch.int32, device=x.device)
-            probs = torch.empty(nc, dtype=torch.float64, device=x.device)
-            with torch.cuda.stream(stream):
-                for _ in range(3):
-                    rec.classify_device(crops.data_ptr(), nc, 0, labels.data_ptr(), probs.data_ptr())
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                it = 50
-                for _ in range(it):
-                    rec.classify_device(crops.data_ptr(), nc, 0, labels.data_ptr(), probs.data_ptr())
-                torch.cuda.synchronize()
-                extras["rec_crops_per_s_b256"] = round(nc * it / (time.perf_counter() - t1), 1)
+            roof_rec = {"kernel": "rec_forward", "bound": "mfma", "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "definition": "8.587264 MFLOP per crop (SURVEY Appendix C; the kernel executes exactly the reference "
+                                      "graph's multiplies) x crops per launch / average launch duration (HIP events on the launch stream)"}
+            for nc in (256, 65536):
+                crops = torch.from_numpy(W.synth_crops(2, nc)).to(x.device)
+                labels = torch.empty(nc, dtype=torch.int32, device=x.device)
+                probs = torch.empty(nc, dtype=torch.float64, device=x.device)
+                it = 50 if nc == 256 else 5
+                with torch.cuda.stream(stream):
+                    for _ in range(3):
+                        rec.classify_device(crops.data_ptr(), nc, 0, labels.data_ptr(), probs.data_ptr())
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    e0.record(stream)
+                    for _ in range(it):
+                        rec.classify_device(crops.data_ptr(), nc, 0, labels.data_ptr(), probs.data_ptr())
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    wall = time.perf_counter() - t1
+                ms = e0.elapsed_time(e1) / it
+                tf = MFLOP_PER_CROP * 1e6 * nc / (ms * 1e-3) / 1e12
+                extras[f"rec_crops_per_s_b{nc}"] = round(nc * it / wall, 1)
+                roof_rec[f"b{nc}"] = {"avg_launch_ms": round(ms, 4), "achieved": round(tf, 2),
+                                      "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                      "crops_per_s_device": round(nc / (ms * 1e-3), 1)}
+                del crops, labels, probs
+            roof_rec["achieved"] = roof_rec["b65536"]["achieved"]
+            roof_rec["frac"] = roof_rec["b65536"]["frac"]
+            extras["roofline_rec"] = roof_rec
+            rec.close()
         except Exception as e:  # side numbers never hide the headline
-            extras["rec_error"] = str(e)
+            extras["rec_error"] = f"{type(e).__name__}: {e}"
 
     total_images = n * world * a.steps
     if rank == 0:
@@ -280,12 +490,13 @@ def main():
             "tflops_executed": None if executed_gflop is None else round(executed_gflop * a.steps * world / elapsed / 1e3, 2),
             "roofline": roof,
         }
-        if gathered is not None:
-            line["all_gather_results"] = gathered
         line.update(post)
         line.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(det_w, s, a.cpu_seconds)
+            try:
+                line["cpu_baseline"] = cpu_baseline(det_w, rec_w, s, a.cpu_seconds)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     det.close()
     if dist is not None:

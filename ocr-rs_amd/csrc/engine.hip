@@ -460,7 +460,10 @@ void* Detector::scratch(int slot, size_t bytes) {
 }
 
 void Detector::ensure_workspace(int n, int h, int w) {
-  if (n == ws_n_ && h == ws_h_ && w == ws_w_ && ws_bf16_ == bf16_) return;
+  // sized for the largest batch seen at this frame size: a smaller batch (the remainder chunk of a split batch,
+  // a caller alternating batch sizes) reuses it - every launch takes its extents from the call's own n
+  last_n_ = n;
+  if (n <= ws_n_ && h == ws_h_ && w == ws_w_ && ws_bf16_ == bf16_) return;
   OCR_HIP(hipStreamSynchronize(stream_));
   free_workspace();
   const size_t es = bf16_ ? 2 : 4;  // bytes per activation element
@@ -515,31 +518,37 @@ void Detector::ensure_workspace(int n, int h, int w) {
 }
 
 namespace {
+// hipEvent pairs around every launch of ONE forward_chunk; entries are appended to the shared `prof` vector,
+// so a batch that runs in several chunks keeps every chunk's launches (base = first entry of this chunk).
 struct Recorder {
   std::vector<ProfileEntry>* prof;
   hipStream_t s;
   std::vector<hipEvent_t> ev;
-  void begin() {
-    if (!prof) return;
+  size_t base;
+  Recorder(std::vector<ProfileEntry>* p, hipStream_t st) : prof(p), s(st), base(p ? p->size() : 0) {}
+  Recorder(const Recorder&) = delete;
+  ~Recorder() {  // also on the exceptional path: no event outlives its chunk
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+  void mark() {
     hipEvent_t e;
     OCR_HIP(hipEventCreate(&e));
-    OCR_HIP(hipEventRecord(e, s));
     ev.push_back(e);
+    OCR_HIP(hipEventRecord(e, s));
+  }
+  void begin() {
+    if (prof) mark();
   }
   void end(const char* name, double flops, double bytes) {
     if (!prof) return;
-    hipEvent_t e;
-    OCR_HIP(hipEventCreate(&e));
-    OCR_HIP(hipEventRecord(e, s));
-    ev.push_back(e);
+    mark();
     prof->push_back({name, 0.f, flops, bytes});
   }
   void finish() {
     if (!prof) return;
     OCR_HIP(hipStreamSynchronize(s));
-    for (size_t i = 0; i < prof->size(); ++i) OCR_HIP(hipEventElapsedTime(&(*prof)[i].ms, ev[2 * i], ev[2 * i + 1]));
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    ev.clear();
+    for (size_t i = base; i < prof->size(); ++i)
+      OCR_HIP(hipEventElapsedTime(&(*prof)[i].ms, ev[2 * (i - base)], ev[2 * (i - base) + 1]));
   }
 };
 }  // namespace
@@ -565,7 +574,7 @@ void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t
 void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                              std::vector<ProfileEntry>* prof) {
   ensure_workspace(n, h, w);
-  Recorder rec{prof, stream_, {}};
+  Recorder rec(prof, stream_);
 
   struct Extra {
     const void* residual = nullptr;
@@ -705,8 +714,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     rec.end(conv_igemm_kernel_name(d), 2.0 * 16.0 * T * cw.cin * cw.cout,
             16.0 * 4.0 * ((double)T * cw.cin + (double)T * cw.cout + (double)cw.cin * cw.cout));
     rec.begin();
-    launch_winograd_output(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), 1, static_cast<float*>(out), n, hh,
-                           ww, cw.cout, stream_);
+    launch_winograd_output(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(out),
+                           n, hh, ww, cw.cout, stream_);
     rec.end("winograd_output_transform", 0.0,
             16.0 * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
   };
@@ -874,10 +883,10 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
 }
 
 const float* Detector::stage(int id, size_t* elems) const {
-  if (ws_n_ == 0) fail(OCR_ERR_INVALID, "no forward has run yet");
+  if (ws_n_ == 0 || last_n_ == 0) fail(OCR_ERR_INVALID, "no forward has run yet");
   if (ws_bf16_ && id != 13) fail(OCR_ERR_INVALID, "stage read-back is f32 only (bf16 precision is active)");
   auto f = [](const char* p) { return reinterpret_cast<const float*>(p); };
-  const size_t N = (size_t)ws_n_;
+  const size_t N = (size_t)last_n_;
   auto px = [&](int shift) { return N * (ws_h_ >> shift) * (ws_w_ >> shift); };
   if (id == 0) { *elems = px(2) * 64; return f(s_); }
   if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return f(x_[id - 1]); }

@@ -118,7 +118,8 @@ class Detector {
   float tr2_bias_ = 0.f;
 
   bool bf16_ = false;
-  int ws_n_ = 0, ws_h_ = 0, ws_w_ = 0;
+  int ws_n_ = 0, ws_h_ = 0, ws_w_ = 0;  // workspace capacity (frames) and frame size
+  int last_n_ = 0;                      // frames of the most recent forward_chunk (stage read-back)
   bool ws_bf16_ = false;
   std::vector<void*> ws_allocs_;
   // activations are f32 or bf16 depending on the precision (b1_, tr1buf_ are always f32)

@@ -52,8 +52,20 @@ class FuncT:
             raise capi.OcrError(1, "expected a contiguous CUDA f32 tensor N x 1 x H x W")
         n, _, h, w = xs.shape
         out = torch.empty_like(xs)
-        self._det.set_stream(torch.cuda.current_stream().cuda_stream)
-        self._det.forward_device(xs.data_ptr(), n, h, w, out.data_ptr())
+        cur = torch.cuda.current_stream(xs.device)
+        if cur.cuda_stream:
+            # a real stream: the forward is enqueued on it, ordered after whatever produced xs and before
+            # whatever the caller enqueues next on the same stream (torch semantics)
+            self._det.set_stream(cur.cuda_stream)
+            self._det.forward_device(xs.data_ptr(), n, h, w, out.data_ptr())
+        else:
+            # torch's default stream is the legacy null stream (handle 0), which the C ABI reads as "the handle's
+            # own stream" - a hipStreamNonBlocking one that the null stream does not order against.  Make the
+            # call blocking on both sides instead: pending producers of xs first, the forward before returning.
+            cur.synchronize()
+            self._det.set_stream(None)
+            self._det.forward_device(xs.data_ptr(), n, h, w, out.data_ptr())
+            self._det.synchronize()
         return out
 
     def close(self):

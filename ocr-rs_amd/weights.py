@@ -181,6 +181,29 @@ def unpack_blob(blob: bytes) -> Dict[str, np.ndarray]:
     return out
 
 
+def rename_tch_rec(named: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The recogniser's real VarStore names.  `Net::new` creates conv1, conv2, fc1 and fc2 on the SAME
+    `nn::Path` (/root/reference/src/char_recognition/model.rs:13-24), so every layer asks for the names
+    "weight" and "bias"; tch 0.3.0's `Path::add` de-duplicates a taken name as `{name}__{n}` with n = the
+    number of variables registered so far: weight, bias, weight__2, bias__3, ..., bias__7 (or with bias
+    first inside a layer - the order tch's conv / linear constructors register them in).  The eight
+    shapes are all different, so each tensor is identified by its shape, whatever the order was.
+    A dict that already uses conv1.weight ... fc2.bias (this library's own blobs) passes through."""
+    specs = rec_param_specs()
+    if all(n in named for n, _ in specs):
+        return named
+    by_shape = {tuple(shape): name for name, shape in specs}
+    out: Dict[str, np.ndarray] = {}
+    for name, t in named.items():
+        base = name.split("__")[0]
+        want = by_shape.get(tuple(t.shape))
+        if base in ("weight", "bias") and want is not None and want.endswith("." + base) and want not in out:
+            out[want] = t
+        else:
+            out[name] = t
+    return out
+
+
 def load_varstore(path: str, kind: str | None = None) -> Dict[str, np.ndarray]:
     """Named tensors of a tch `VarStore::save` file (what `vs.load(file)` reads back,
     /root/reference/src/text_detection/mod.rs:41-44, char_recognition/mod.rs:46, utils.rs:55-63).
@@ -201,6 +224,8 @@ def load_varstore(path: str, kind: str | None = None) -> Dict[str, np.ndarray]:
     out: Dict[str, np.ndarray] = {}
     for name, t in list(module.named_parameters()) + list(module.named_buffers()):
         out[name] = np.ascontiguousarray(t.detach().to(torch.float32).cpu().numpy())
+    if kind == "rec":
+        out = rename_tch_rec(out)
     if kind is not None:
         specs = {"det": det_param_specs, "rec": rec_param_specs}[kind]()
         problems = []

@@ -1,0 +1,50 @@
+"""`python bench.py --gpus N` as a bare command: the parent must start N ranks as child processes (before any
+GPU call), relay rank 0's JSON line and fail when a rank fails.  CPU-only: --dry-run swaps the GPU work for a
+gloo rendezvous + the result all-gather, the launcher code is the one the GPU run uses."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_bare_command_launches_its_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--batch", "7", "--steps", "4", "--warmup", "1"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                      # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1
+    assert line["all_gather_results"]["images"] == 14   # both shards arrived, in rank order
+
+
+def test_failing_rank_fails_the_launcher():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=_env(OCR_BENCH_FAIL_RANK="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr
+
+
+def test_runs_as_a_rank_under_an_external_launcher():
+    # the shape torch.distributed.run gives: RANK / WORLD_SIZE already set -> no second level of children
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run"], env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_launcher_makes_no_gpu_call():
+    """The parent must not import torch or the library before it forks: nothing that could initialise HIP."""
+    src = open(BENCH).read()
+    head = src[:src.index("def main():")]
+    top_level = [ln for ln in head.splitlines() if ln.startswith(("import ", "from "))]
+    assert not any("torch" in ln or "ocr_rs_amd" in ln or "numpy" in ln for ln in top_level), top_level

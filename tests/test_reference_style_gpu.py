@@ -67,10 +67,17 @@ def test_forward_t_device_tensor_and_train_flag(net):
     import torch
     from oracle import torch_ref as T
     x = W.synth_image_batch(3, 1, 64, 64)
+    ref = T.det_forward(W.make_det_weights(0), x)
+    # the contract of a torch op: no manual synchronisation around the call, on the default stream ...
     y = net.forward_t(torch.from_numpy(x).cuda())
-    torch.cuda.synchronize()
-    net.handle.synchronize()
-    assert np.abs(y.cpu().numpy() - T.det_forward(W.make_det_weights(0), x)).max() < 1e-4
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-4
+    # ... and on a side stream, where producer (the copy), forward and consumer are ordered by the stream alone
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xs = torch.from_numpy(x).pin_memory().cuda(non_blocking=True)
+        y2 = net.forward_t(xs)
+        host = y2.to("cpu", non_blocking=False)
+    assert np.abs(host.numpy() - ref).max() < 1e-4
     with pytest.raises(capi.OcrError):
         net.forward_t(x, train=True)
 

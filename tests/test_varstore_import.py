@@ -37,3 +37,20 @@ def test_imported_tensors_pack_into_the_blob_the_abi_takes(golden_dir):
     got = W.load_varstore(os.path.join(golden_dir, "varstore_small.ot"))
     back = W.unpack_blob(W.pack_blob(got))
     assert set(back) == set(got) and all(np.array_equal(back[k], got[k]) for k in got)
+
+
+def test_recogniser_names_as_tch_writes_them():
+    """Net::new puts all four layers on one nn::Path (char_recognition/model.rs:13-24): tch de-duplicates the
+    colliding names with __N suffixes.  Both registration orders map onto conv1 / conv2 / fc1 / fc2 by shape."""
+    want = W.make_rec_weights(3)
+    weight_first = ["weight", "bias", "weight__2", "bias__3", "weight__4", "bias__5", "weight__6", "bias__7"]
+    bias_first_convs = ["bias", "weight", "bias__2", "weight__3", "weight__4", "bias__5", "weight__6", "bias__7"]
+    for names in (weight_first, bias_first_convs):
+        leafs = {}
+        for (name, _), layer in zip(W.rec_param_specs(), [0, 0, 1, 1, 2, 2, 3, 3]):
+            leaf = name.split(".")[1]
+            tch_name = next(n for n in names[2 * layer:2 * layer + 2] if n.split("__")[0] == leaf)
+            leafs[tch_name] = want[name]
+        got = W.rename_tch_rec(leafs)
+        assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
+    assert W.rename_tch_rec(want) is want          # this library's own dotted names pass through
