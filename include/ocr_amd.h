@@ -189,6 +189,11 @@ int ocr_rec_forward(ocr_rec_t* rec, const float* crops, int n, float* logits, in
  * its probability.  logits may be NULL.  Device pointers; enqueues and returns. */
 int ocr_rec_classify_async(ocr_rec_t* rec, const float* crops_dev, int n, float* logits_dev,
                            int32_t* labels_dev, double* probs_dev);
+/* Per-kernel timing of one classify pass over n device-resident crops (hipEvents on the handle's stream around
+ * every launch; same conventions as ocr_det_forward_profile: flops = MFMA FLOPs the launch executes). */
+int ocr_rec_classify_profile(ocr_rec_t* rec, const float* crops_dev, int n, int32_t* labels_dev, double* probs_dev,
+                             int max_entries, const char** names, float* ms, double* flops, double* bytes,
+                             int* n_entries);
 /* Blocking convenience over either memory kind. */
 int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels, double* probs,
                      int mem_kind);

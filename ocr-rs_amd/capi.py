@@ -26,7 +26,7 @@ EXPORTS = [
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
-    "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify", "ocr_rec_alphabet",
+    "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet",
 ]
 
 
@@ -101,6 +101,9 @@ def lib() -> C.CDLL:
         L.ocr_rec_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.ocr_rec_classify_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ocr_rec_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ocr_rec_classify_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
         # host-geometry test hooks
         L.ocr_test_contour_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int, C.POINTER(C.c_int)]
@@ -350,6 +353,18 @@ class Recognizer:
         probs = np.empty(n, np.float64)
         check(lib().ocr_rec_classify(self._h, _ptr(crops), n, _ptr(labels), _ptr(probs), MEM_HOST))
         return labels, probs
+
+    def classify_profile(self, crops_ptr: int, n: int, labels_ptr: int = 0, probs_ptr: int = 0):
+        """[(kernel, ms, executed flops, bytes)] of one classify pass (device pointers)."""
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        by = (C.c_double * cap)()
+        cnt = C.c_int(0)
+        check(lib().ocr_rec_classify_profile(self._h, crops_ptr, n, labels_ptr or None, probs_ptr or None, cap, names, ms,
+                                             fl, by, C.byref(cnt)))
+        return [(names[i].decode(), float(ms[i]), float(fl[i]), float(by[i])) for i in range(cnt.value)]
 
     def classify_device(self, crops_ptr: int, n: int, logits_ptr: int, labels_ptr: int, probs_ptr: int) -> None:
         check(lib().ocr_rec_classify_async(self._h, crops_ptr, n, logits_ptr or None, labels_ptr or None,

@@ -421,6 +421,22 @@ int ocr_rec_classify_async(ocr_rec_t* rec, const float* crops, int n, float* log
     rec->impl.classify(crops, n, logits, labels, probs);
   });
 }
+int ocr_rec_classify_profile(ocr_rec_t* rec, const float* crops, int n, int32_t* labels, double* probs, int max_entries,
+                             const char** names, float* ms, double* flops, double* bytes, int* n_entries) {
+  return guard([&] {
+    if (!rec || !n_entries) ocr::fail(OCR_ERR_INVALID, "null argument");
+    std::vector<ocr::ProfileEntry> prof;
+    rec->impl.classify(crops, n, nullptr, labels, probs, &prof);
+    const int k = std::min<int>(max_entries, (int)prof.size());
+    for (int i = 0; i < k; ++i) {
+      if (names) names[i] = prof[i].name;
+      if (ms) ms[i] = prof[i].ms;
+      if (flops) flops[i] = prof[i].flops;
+      if (bytes) bytes[i] = prof[i].bytes;
+    }
+    *n_entries = k;
+  });
+}
 int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels, double* probs, int mem_kind) {
   return guard([&] {
     if (!rec || !crops) ocr::fail(OCR_ERR_INVALID, "null argument");

@@ -117,12 +117,20 @@ struct CropBox {
 };
 void launch_crops(const float* frames_dev, int H, int W, const CropBox* boxes_dev, int n_boxes, float* crops_dev, hipStream_t s);
 
-// recognition net, fused
+// recognition net (rec_net.hip): conv1 + pool + conv2 + pool on the matrix cores -> feat [n][1024]; fc1 runs as a
+// conv_igemm 1x1 GEMM over the whole batch; fc2 + softmax(f64) + top-1 in one kernel
 struct RecWeights {
-  const float *c1w, *c1b, *c2w, *c2b, *f1w, *f1b, *f2w, *f2b;
+  const float *c1f, *c1b;   // conv1 as MFMA fragments [13][64], bias [32]
+  const float *c2f, *c2b;   // conv2 as MFMA fragments [25][2][4][64][4], bias [64]
+  const float *f1w, *f1b;   // fc1 [512][1024], bias [512]
+  const float *f2f, *f2b;   // fc2 as MFMA fragments [2][64][64][4] (rows 62, 63 zero), bias [64]
 };
-void launch_rec_forward(const RecWeights& w, const float* crops, int n, float* logits,
-                        int32_t* labels, double* probs, hipStream_t s);
+std::vector<float> rec_conv1_fragments(const float* w_32x25);
+std::vector<float> rec_conv2_fragments(const float* w_64x32x25);
+int rec_crops_per_block(int n);
+void launch_rec_conv(const RecWeights& w, const float* crops, int n, float* feat, hipStream_t s);
+std::vector<float> rec_fc2_fragments(const float* w_62x512);
+void launch_rec_fc2_softmax(const RecWeights& w, const float* hid, int n, float* logits62, int32_t* labels, double* probs, hipStream_t s);
 
 // box score: masked mean of prob over rasterised polygons (metrics.rs:150-184)
 struct BoxScoreJob {

@@ -927,24 +927,28 @@ Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(dev
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
   arena_.reserve((size_t)4 << 20);
-  auto up = [&](const char* name, std::initializer_list<int> shape) {
+  auto vec = [&](const char* name, std::initializer_list<int> shape) {
     const TensorView& t = wb.get(name, shape);
-    return arena_.upload(std::vector<float>(t.data, t.data + t.count));
+    return std::vector<float>(t.data, t.data + t.count);
   };
-  w_.c1w = up("conv1.weight", {32, 1, 5, 5});
-  w_.c1b = up("conv1.bias", {32});
-  w_.c2w = up("conv2.weight", {64, 32, 5, 5});
-  w_.c2b = up("conv2.bias", {64});
-  w_.f1w = up("fc1.weight", {512, 1024});
-  w_.f1b = up("fc1.bias", {512});
-  w_.f2w = up("fc2.weight", {62, 512});
-  w_.f2b = up("fc2.bias", {62});
+  // char_recognition/model.rs:13-24; the two convs re-laid out as MFMA operand fragments (rec_net.hip)
+  w_.c1f = arena_.upload(rec_conv1_fragments(vec("conv1.weight", {32, 1, 5, 5}).data()));
+  w_.c1b = arena_.upload(vec("conv1.bias", {32}));
+  w_.c2f = arena_.upload(rec_conv2_fragments(vec("conv2.weight", {64, 32, 5, 5}).data()));
+  w_.c2b = arena_.upload(vec("conv2.bias", {64}));
+  w_.f1w = arena_.upload(vec("fc1.weight", {512, 1024}));
+  w_.f1b = arena_.upload(vec("fc1.bias", {512}));
+  std::vector<float> b2 = vec("fc2.bias", {62});
+  b2.resize(64, 0.f);  // two padding columns: the kernel works on 32-column MFMA tiles
+  w_.f2f = arena_.upload(rec_fc2_fragments(vec("fc2.weight", {62, 512}).data()));
+  w_.f2b = arena_.upload(b2);
 }
 
 Recognizer::~Recognizer() {
   (void)hipSetDevice(device_);
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   if (stage_) (void)hipFree(stage_);
+  if (feat_) (void)hipFree(feat_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -953,10 +957,62 @@ void Recognizer::synchronize() {
   OCR_HIP(hipStreamSynchronize(stream_));
 }
 
-void Recognizer::classify(const float* crops, int n, float* logits, int32_t* labels, double* probs) {
+void Recognizer::ensure_workspace(int n) {
+  if (n <= ws_cap_) return;
+  OCR_HIP(hipStreamSynchronize(stream_));
+  if (feat_) OCR_HIP(hipFree(feat_));
+  feat_ = hid_ = nullptr;
+  ws_cap_ = 0;
+  const int cap = std::min(kChunk, std::max(n, 256));
+  OCR_HIP(hipMalloc(reinterpret_cast<void**>(&feat_), (size_t)cap * (1024 + 512) * sizeof(float)));
+  hid_ = feat_ + (size_t)cap * 1024;
+  ws_cap_ = cap;
+}
+
+void Recognizer::classify(const float* crops, int n, float* logits, int32_t* labels, double* probs,
+                          std::vector<ProfileEntry>* prof) {
   if (!crops || n < 0) fail(OCR_ERR_INVALID, "rec: null crops or negative count");
   OCR_HIP(hipSetDevice(device_));
-  launch_rec_forward(w_, crops, n, logits, labels, probs, stream_);
+  for (int b = 0; b < n; b += kChunk) {
+    const int nb = std::min(kChunk, n - b);
+    ensure_workspace(nb);
+    Recorder rec(prof, stream_);
+    rec.begin();
+    launch_rec_conv(w_, crops + (size_t)b * 784, nb, feat_, stream_);
+    rec.end(rec_crops_per_block(nb) == 1 ? "rec_conv<1>" : rec_crops_per_block(nb) == 2 ? "rec_conv<2>" : "rec_conv<4>",
+            2.0 * nb * (576.0 * 32 * 26 + 64.0 * 64 * 800), (double)nb * (784 + 1024) * 4 + 13 * 64 * 4 + 25 * 2048 * 4);
+    // fc1 + bias + ReLU as a plain GEMM over the batch: M = crops, K = Cin, N = Cout
+    auto fc = [&](const char* name, const float* in, const float* wgt, const float* bias, int cin, int cout, bool relu, float* out) {
+      ConvDesc d{};
+      d.src[0] = in;
+      d.src_mode = SRC_PLAIN;
+      d.src_bytes = (size_t)nb * cin * 4;
+      d.wgt = wgt;
+      d.wgt_bytes = (size_t)cout * cin * 4;
+      d.N = 1;
+      d.Hin = d.Ho = 1;
+      d.Win = d.Wo = nb;
+      d.Cin = cin;
+      d.Cout = cout;
+      d.ks = 1;
+      d.stride = 1;
+      d.pad = 0;
+      d.bias = bias;
+      d.relu = relu ? 1 : 0;
+      d.store_mode = STORE_NHWC;
+      d.out = out;
+      d.name = name;
+      rec.begin();
+      launch_conv_igemm(d, stream_);
+      rec.end(name, 2.0 * nb * cin * cout, 4.0 * ((double)nb * (cin + cout) + (double)cin * cout));
+    };
+    fc("rec_fc1", feat_, w_.f1w, w_.f1b, 1024, 512, true, hid_);
+    rec.begin();
+    launch_rec_fc2_softmax(w_, hid_, nb, logits ? logits + (size_t)b * 62 : nullptr, labels ? labels + b : nullptr,
+                           probs ? probs + b : nullptr, stream_);
+    rec.end("rec_fc2_softmax_top1", 2.0 * nb * 512 * 64, (double)nb * (512 * 4 + 12) + 64 * 512 * 4);
+    rec.finish();
+  }
 }
 
 void Recognizer::forward_host(const float* crops, int n, float* logits, int32_t* labels, double* probs) {

@@ -142,9 +142,12 @@ class Recognizer {
   ~Recognizer();
   void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
   void synchronize();
-  void classify(const float* crops_dev, int n, float* logits_dev, int32_t* labels_dev, double* probs_dev);
+  // device pointers; enqueues on the stream.  prof != null -> per-launch events (as Detector::forward)
+  void classify(const float* crops_dev, int n, float* logits_dev, int32_t* labels_dev, double* probs_dev,
+                std::vector<ProfileEntry>* prof = nullptr);
   void forward_host(const float* crops, int n, float* logits, int32_t* labels, double* probs);
   int device() const { return device_; }
+  static constexpr int kChunk = 65536;  // crops per pass: bounds the feat / hidden workspace (6144 bytes per crop)
 
  private:
   int device_;
@@ -153,6 +156,9 @@ class Recognizer {
   RecWeights w_{};
   void* stage_ = nullptr;
   size_t stage_bytes_ = 0;
+  void ensure_workspace(int n);
+  float *feat_ = nullptr, *hid_ = nullptr;  // [cap][1024], [cap][512]
+  int ws_cap_ = 0;
 };
 
 void check_device(int device);

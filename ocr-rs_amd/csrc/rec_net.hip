@@ -1,169 +1,326 @@
-// Recognition network, one fused launch: one 1024-thread workgroup per 28x28 crop.
+// Recognition network on the matrix cores, weights shared across crops.
 //   /root/reference/src/char_recognition/model.rs:27-39
 //     view[-1,1,28,28] -> conv5x5(1->32)+b -> maxpool2 -> conv5x5(32->64)+b -> maxpool2
 //     -> view[-1,1024] -> fc1(1024->512)+b -> ReLU -> (dropout: identity in eval) -> fc2(512->62)+b
 //   /root/reference/src/char_recognition/mod.rs:53-56 + utils.rs:28-43
 //     softmax(-1, Kind::Double) and top-1 (label index into "A-Za-z0-9").
-// All intermediates stay in LDS; weights (2.4 MB) are served from L2 / Infinity Cache.
+//
+// Three stages, every multiply on v_mfma_f32_32x32x2_f32 (exact f32 FMA chains):
+//   rec_conv_kernel<T>   conv1 + pool + conv2 + pool of T crops per workgroup, intermediates in LDS, -> feat [B][1024]
+//                        conv1: M = 576 pixels, N = 32, K = 25 (+1 zero) - weights live in 13 registers per lane;
+//                        conv2: implicit GEMM M = 64 T pixels, N = 64, K = 800 (25 taps x 32 channels) - the weights of
+//                        a tap (16 registers per lane, host-arranged in MFMA fragment order so that a wave's load is
+//                        1 KiB contiguous) are fetched from L2 once per tap and serve T row tiles.
+//                        Rows of an MFMA tile are (pool window, position in window): the 2x2 max pool is a max over
+//                        the four accumulator registers of a lane, and the pooled pixels a lane holds are contiguous.
+//   fc1                  the batched GEMM [B x 1024] x [1024 x 512] (+b, ReLU) through conv_igemm's 1x1 form - LDS-DMA
+//                        staged, weights shared by the 64 / 128 crops of a tile
+//   rec_fc2_softmax_kernel  [B x 512] x [512 x 64] (+b; 62 real columns), softmax over the 62 logits in f64, top-1
 #include "common.hpp"
 
 namespace ocr {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float wave_sum(float v) {
+constexpr int IMG = 784;            // 28 x 28 input pixels
+constexpr int P1_PIX = 144;         // 12 x 12 pooled pixels after conv1
+constexpr int P1_ROW = 32;          // channels per pooled pixel (one 128-byte LDS row)
+
+// float index of channel c of pooled pixel `pix` in a crop's [144][32] LDS image: the 16-byte chunk c / 4 sits in
+// slot (c / 4) ^ ((pix >> 1) & 7), which spreads the 32 pixel rows a wave reads over the LDS banks
+__device__ __forceinline__ int p1_index(int pix, int c) { return pix * P1_ROW + ((((c >> 2) ^ ((pix >> 1) & 7)) << 2) | (c & 3)); }
+
+// T = crops per workgroup.  256 threads = 4 waves; 80 000 bytes of LDS at T = 4: two workgroups per CU.
+template <int T>
+__global__ __launch_bounds__(256, 2) void rec_conv_kernel(const float* __restrict__ crops, int n, const float* __restrict__ w1f,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2f,
+                                                          const float* __restrict__ b2, float* __restrict__ feat) {
+  constexpr int NIMG = T < 2 ? T : 2;  // crops staged at a time (conv1 runs over the crops two by two)
+  __shared__ __attribute__((aligned(16))) float p1[T * P1_PIX * P1_ROW];
+  __shared__ __attribute__((aligned(16))) float img[NIMG * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int crop0 = blockIdx.x * T;
+
+  // conv1 weights as MFMA B fragments: step s multiplies taps k = 2 s + h (k = 25 is the zero pad)
+  float w1r[13];
 #pragma unroll
-  for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k, 64);
-  return v;
+  for (int s = 0; s < 13; ++s) w1r[s] = w1f[s * 64 + lane];
+  const float bias1 = b1[j];
+
+  // ---- staging: crop c of the batch -> img slot; crops past the end of the batch re-read the last one (never stored)
+  auto load_pair = [&](int first, f32x4 (&r)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;  // float4 index inside the NIMG * 196 float4 of the pair
+      if (idx < NIMG * (IMG / 4)) {
+        const int c = idx / (IMG / 4), o = idx - c * (IMG / 4);
+        const int g = min(crop0 + first + c, n - 1);
+        r[u] = *reinterpret_cast<const f32x4*>(crops + (size_t)g * IMG + o * 4);
+      }
+    }
+  };
+  auto store_pair = [&](const f32x4 (&r)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < NIMG * (IMG / 4)) *reinterpret_cast<f32x4*>(img + idx * 4) = r[u];
+    }
+  };
+
+  // ---- conv1 (valid 5x5, 1 -> 32) + bias + 2x2 max pool of one 8-window tile: rows i = 4 * window slot + (dy, dx)
+  auto conv1_tile = [&](int slot_img, int crop_local, int tile) {
+    const int i = lane & 31;
+    const int wi = tile * 8 + (i >> 2);            // pooled pixel (window) 0..143
+    const int qy = wi / 12, qx = wi - qy * 12;
+    const int base = (2 * qy + ((i >> 1) & 1)) * 28 + 2 * qx + (i & 1);
+    const float* im = img + slot_img * IMG + base;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      const int k0 = 2 * s, k1 = 2 * s + 1;
+      const int o0 = (k0 / 5) * 28 + k0 % 5;
+      const int o1 = k1 < 25 ? (k1 / 5) * 28 + k1 % 5 : 0;  // pad tap: weight 0, any in-range pixel
+      const float a = im[h ? o1 : o0];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1r[s], acc, 0, 0, 0);
+    }
+    // C/D map: column = lane & 31 (channel), rows 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3 = window slot 2 g + h
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float m = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias1;
+      p1[crop_local * (P1_PIX * P1_ROW) + p1_index(tile * 8 + 2 * g + h, j)] = m;
+    }
+  };
+
+  f32x4 stage[2];
+  load_pair(0, stage);
+  store_pair(stage);
+  if constexpr (T > 2) load_pair(2, stage);  // in flight during conv1 of the first pair
+  __syncthreads();
+  if constexpr (T == 1) {
+    for (int t = wave; t < 18; t += 4) conv1_tile(0, 0, t);
+  } else {
+#pragma unroll 1
+    for (int pr = 0; pr < T / 2; ++pr) {
+      if (pr > 0) {
+        __syncthreads();  // every wave is done reading the previous pair
+        store_pair(stage);
+        if (2 * pr + 2 < T) load_pair(2 * pr + 2, stage);
+        __syncthreads();
+      }
+      const int c = wave >> 1;  // this wave's crop of the pair, half of its 18 tiles
+#pragma unroll 1
+      for (int t = 9 * (wave & 1); t < 9 * (wave & 1) + 9; ++t) conv1_tile(c, 2 * pr + c, t);
+    }
+  }
+  __syncthreads();
+
+  // ---- conv2 (valid 5x5, 32 -> 64) + bias + 2x2 max pool.  Wave w: output channels 32 (w & 1) .. + 31 and T of the 2 T
+  // row tiles (a crop's 8 x 8 outputs = 16 windows = 2 tiles of 8 windows).  Row i of tile t' = window slot i >> 2
+  // -> pooled pixel p = 8 t' + 4 (slot & 1) + (slot >> 1), so that after the pool lane half h holds p = 8 t' + 4 h + g.
+  const int ct = wave & 1;
+  int pix0[T], crow[T];
+#pragma unroll
+  for (int r = 0; r < T; ++r) {
+    const int rt = (wave >> 1) * T + r;
+    const int crop_local = rt >> 1, tp = rt & 1;
+    const int i = lane & 31, slot = i >> 2;
+    const int p = 8 * tp + 4 * (slot & 1) + (slot >> 1);
+    const int y = 2 * (p >> 2) + ((i >> 1) & 1), x = 2 * (p & 3) + (i & 1);
+    pix0[r] = y * 12 + x;
+    crow[r] = crop_local * (P1_PIX * P1_ROW);
+  }
+  f32x16 acc[T];
+#pragma unroll
+  for (int r = 0; r < T; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+  const f32x4* wf = reinterpret_cast<const f32x4*>(w2f) + ct * 4 * 64 + lane;  // [tap][ct][g][lane] float4
+  f32x4 bcur[4], bnext[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bcur[g] = wf[g * 64];
+#pragma unroll 1
+  for (int tap = 0; tap < 25; ++tap) {
+    const int tn = tap + 1 < 25 ? tap + 1 : tap;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bnext[g] = wf[(tn * 2 * 4 + g) * 64];  // next tap's weights fly during this tap's MFMAs
+    const int ky = tap / 5, kx = tap - ky * 5;
+    const int toff = ky * 12 + kx;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[T];
+#pragma unroll
+      for (int r = 0; r < T; ++r) {
+        const int pix = pix0[r] + toff;
+        a[r] = *reinterpret_cast<const f32x4*>(p1 + crow[r] + pix * P1_ROW + (((2 * g + h) ^ ((pix >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < T; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][e], bcur[g][e], acc[r], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
+  }
+
+  // pooled + bias -> feat[crop][co * 16 + p] (the C,H,W flatten of view[-1,1024]): a lane's four p are contiguous
+  const float bias2 = b2[32 * ct + j];
+#pragma unroll
+  for (int r = 0; r < T; ++r) {
+    const int rt = (wave >> 1) * T + r;
+    const int crop = crop0 + (rt >> 1), tp = rt & 1;
+    f32x4 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      v[g] = fmaxf(fmaxf(acc[r][4 * g], acc[r][4 * g + 1]), fmaxf(acc[r][4 * g + 2], acc[r][4 * g + 3])) + bias2;
+    if (crop < n) *reinterpret_cast<f32x4*>(feat + (size_t)crop * 1024 + (32 * ct + j) * 16 + 8 * tp + 4 * h) = v;
+  }
 }
 
-constexpr int REC_THREADS = 1024;  // 16 waves per crop: at 256 crops every CU holds one crop
-
-__global__ __launch_bounds__(REC_THREADS) void rec_forward_kernel(RecWeights w, const float* __restrict__ crops,
-                                                                  float* __restrict__ logits_out,
-                                                                  int32_t* __restrict__ labels, double* __restrict__ probs) {
-  __shared__ __attribute__((aligned(16))) float img[28 * 28];
-  __shared__ __attribute__((aligned(16))) float w1[32 * 25];
-  __shared__ __attribute__((aligned(16))) float p1[32][12][12];   // after conv1 + pool
-  __shared__ __attribute__((aligned(16))) float feat[1024];       // [c][h][w] flatten (view[-1,1024])
-  __shared__ __attribute__((aligned(16))) float hid[512];
-  __shared__ float lg[64];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int crop = blockIdx.x;
-  const float* src = crops + (size_t)crop * 784;
-  if (tid < 784) img[tid] = src[tid];
-  if (tid < 800) w1[tid] = w.c1w[tid];
-  // conv2 weights of this thread's output channel, first input channel: requested now,
-  // consumed after conv1 (their L2 latency hides behind it)
-  const int co2 = tid >> 4;                   // conv2: thread = (output channel, pooled position)
-  const int pp = tid & 15, py = pp >> 2, px = pp & 3;
-  const float* wc = w.c2w + (size_t)co2 * 800;
-  float wcur[25];
-#pragma unroll
-  for (int k = 0; k < 25; ++k) wcur[k] = wc[k];
-  __syncthreads();
-
-  // conv1 (valid 5x5) fused with 2x2 max pool: 32 x 12 x 12 pooled outputs
-  for (int o = tid; o < 32 * 144; o += REC_THREADS) {
-    const int co = o / 144, rem = o - co * 144, qy = rem / 12, qx = rem - qy * 12;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-    for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
-        const float wv = w1[co * 25 + kh * 5 + kw];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx)
-            acc[dy][dx] = fmaf(img[(2 * qy + dy + kh) * 28 + 2 * qx + dx + kw], wv, acc[dy][dx]);
-      }
-    const float b = w.c1b[co];
-    p1[co][qy][qx] = fmaxf(fmaxf(acc[0][0] + b, acc[0][1] + b), fmaxf(acc[1][0] + b, acc[1][1] + b));
-  }
-  __syncthreads();
-
-  // conv2 (valid 5x5, 32->64) fused with its 2x2 max pool: the thread owns the 2x2 conv outputs
-  // under one pooled pixel; per input channel it reads a 6x6 patch and does 100 FMAs while the
-  // next channel's 25 weights are in flight.
+// fc2 (512 -> 62, as 64 columns with two zero ones) + bias, then softmax(-1, f64) and its top-1: 64 crops per
+// 1024-thread workgroup.  Wave w multiplies the 32 x 32 tile (crops 32 ((w >> 1) & 1) .., columns 32 (w & 1) ..) over
+// the K quarter w >> 2 (16 waves: the dependent MFMA chain is 64 long instead of 256 - this kernel is latency-bound at
+// every batch size); the four partial tiles are added in a fixed order ((q0 + q1) + (q2 + q3)) + bias, so a crop's
+// logits do not depend on the batch around it.  Both operands come straight from global memory: the hidden rows as
+// 16-byte pieces, the weights host-arranged in fragment order (1 KiB contiguous per wave load).  Tail: 16 lanes per
+// crop, 4 columns each: first index of the maximum, exp in f64 (mod.rs:55 softmax(-1, Kind::Double), utils.rs:28-43).
+__global__ __launch_bounds__(1024) void rec_fc2_softmax_kernel(const float* __restrict__ hid, int n, const float* __restrict__ w2f,
+                                                               const float* __restrict__ b2, float* __restrict__ logits_out,
+                                                               int32_t* __restrict__ labels, double* __restrict__ probs) {
+  __shared__ __attribute__((aligned(16))) float part[4][64][68];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int kq = wave >> 2, rt = (wave >> 1) & 1, ct = wave & 1;
+  const int m0 = blockIdx.x * 64;
   {
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int ci = 0; ci < 32; ++ci) {
-      float wnext[25];
-      const float* wn = wc + (ci + 1 < 32 ? ci + 1 : ci) * 25;
+    const int row = min(m0 + 32 * rt + j, n - 1);  // rows past the batch re-read the last crop (never stored)
+    const f32x4* ap = reinterpret_cast<const f32x4*>(hid + (size_t)row * 512 + 128 * kq + 4 * h);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(w2f) + ((size_t)ct * 64 + 16 * kq) * 64 + lane;  // [ct][g][lane] float4
+    f32x16 acc;
 #pragma unroll
-      for (int k = 0; k < 25; ++k) wnext[k] = wn[k];
-      float patch[6][6];
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
+    for (int g0 = 0; g0 < 16; g0 += 8) {
+      f32x4 a[8], b[8];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) patch[a][b] = p1[ci][2 * py + a][2 * px + b];
-#pragma unroll
-      for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 5; ++kw) {
-          const float wv = wcur[kh * 5 + kw];
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = fmaf(patch[dy + kh][dx + kw], wv, acc[dy][dx]);
-        }
-#pragma unroll
-      for (int k = 0; k < 25; ++k) wcur[k] = wnext[k];
-    }
-    const float bb = w.c2b[co2];
-    feat[co2 * 16 + pp] = fmaxf(fmaxf(acc[0][0] + bb, acc[0][1] + bb), fmaxf(acc[1][0] + bb, acc[1][1] + bb));
-  }
-  __syncthreads();
-
-  // fc1 + ReLU: one wave per output row (coalesced 4 KB weight rows), four rows in flight
-  f32x4 fv[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) fv[k] = *reinterpret_cast<const f32x4*>(feat + k * 256 + lane * 4);
-  for (int o0 = wave * 4; o0 < 512; o0 += 64) {
-    f32x4 a[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a[u][k] = *reinterpret_cast<const f32x4*>(w.f1w + (size_t)(o0 + u) * 1024 + k * 256 + lane * 4);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) s += a[u][k][0] * fv[k][0] + a[u][k][1] * fv[k][1] + a[u][k][2] * fv[k][2] + a[u][k][3] * fv[k][3];
-      s = wave_sum(s);
-      if (lane == 0) hid[o0 + u] = fmaxf(s + w.f1b[o0 + u], 0.f);
-    }
-  }
-  __syncthreads();
-  for (int o = wave; o < 62; o += 16) {
-    const float* wr = w.f2w + (size_t)o * 512;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(wr + k * 256 + lane * 4);
-      const f32x4 f = *reinterpret_cast<const f32x4*>(hid + k * 256 + lane * 4);
-      s += a[0] * f[0] + a[1] * f[1] + a[2] * f[2] + a[3] * f[3];
-    }
-    s = wave_sum(s);
-    if (lane == 0) lg[o] = s + w.f2b[o];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const float v = lane < 62 ? lg[lane] : -INFINITY;
-    if (logits_out && lane < 62) logits_out[(size_t)crop * 62 + lane] = v;
-    if (labels || probs) {
-      // top-1 of softmax(-1, f64): first index of the maximum
-      float mx = v;
-      int arg = lane;
-#pragma unroll
-      for (int k = 32; k >= 1; k >>= 1) {
-        const float ov = __shfl_xor(mx, k, 64);
-        const int oa = __shfl_xor(arg, k, 64);
-        if (ov > mx || (ov == mx && oa < arg)) {
-          mx = ov;
-          arg = oa;
-        }
+      for (int u = 0; u < 8; ++u) {
+        a[u] = ap[2 * (g0 + u)];
+        b[u] = bp[(g0 + u) * 64];
       }
-      double e = lane < 62 ? exp((double)v - (double)mx) : 0.0;
 #pragma unroll
-      for (int k = 32; k >= 1; k >>= 1) e += __shfl_xor(e, k, 64);
-      if (lane == 0) {
-        if (labels) labels[crop] = arg;
-        if (probs) probs[crop] = 1.0 / e;
-      }
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[kq][32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h][32 * ct + j] = acc[e];
+  }
+  __syncthreads();
+  const int r = tid >> 4, l16 = tid & 15;  // crop row of the tile, its columns 4 l16 .. 4 l16 + 3
+  const int crop = m0 + r;
+  f32x4 v = (*reinterpret_cast<const f32x4*>(&part[0][r][4 * l16]) + *reinterpret_cast<const f32x4*>(&part[1][r][4 * l16])) +
+            (*reinterpret_cast<const f32x4*>(&part[2][r][4 * l16]) + *reinterpret_cast<const f32x4*>(&part[3][r][4 * l16]));
+  v += *reinterpret_cast<const f32x4*>(b2 + 4 * l16);
+  if (l16 == 15) v[2] = v[3] = -INFINITY;  // columns 62, 63 are padding
+  if (crop < n && logits_out) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * l16 + e < 62) logits_out[(size_t)crop * 62 + 4 * l16 + e] = v[e];
+  }
+  if (!labels && !probs) return;
+  float mx = v[0];  // first index of the maximum
+  int arg = 4 * l16;
+#pragma unroll
+  for (int e = 1; e < 4; ++e)
+    if (v[e] > mx) {
+      mx = v[e];
+      arg = 4 * l16 + e;
+    }
+#pragma unroll
+  for (int k = 1; k <= 8; k <<= 1) {
+    const float ov = __shfl_xor(mx, k, 64);
+    const int oa = __shfl_xor(arg, k, 64);
+    if (ov > mx || (ov == mx && oa < arg)) {
+      mx = ov;
+      arg = oa;
+    }
+  }
+  double e = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) e += exp((double)v[c] - (double)mx);  // exp(-inf) = 0 for the padding
+#pragma unroll
+  for (int k = 1; k <= 8; k <<= 1) e += __shfl_xor(e, k, 64);
+  if (l16 == 0 && crop < n) {
+    if (labels) labels[crop] = arg;
+    if (probs) probs[crop] = 1.0 / e;
   }
 }
 
 }  // namespace
 
-void launch_rec_forward(const RecWeights& w, const float* crops, int n, float* logits, int32_t* labels,
-                        double* probs, hipStream_t s) {
+// conv1 [32][1][5][5] -> [13 steps][64 lanes]: lane (j = l & 31, h = l >> 5) of step s holds w[j][k = 2 s + h] (0 for k = 25)
+std::vector<float> rec_conv1_fragments(const float* w) {
+  std::vector<float> f(13 * 64, 0.f);
+  for (int s = 0; s < 13; ++s)
+    for (int l = 0; l < 64; ++l) {
+      const int k = 2 * s + (l >> 5);
+      if (k < 25) f[s * 64 + l] = w[(l & 31) * 25 + k];
+    }
+  return f;
+}
+
+// conv2 [64][32][5][5] -> [25 taps][2 column tiles][4 g][64 lanes][4]: element e of lane (j, h) is
+// w[co = 32 ct + j][ci = 8 g + 4 h + e][tap] - the B operand of the e-th of four MFMAs of K group g
+std::vector<float> rec_conv2_fragments(const float* w) {
+  std::vector<float> f((size_t)25 * 2 * 4 * 64 * 4);
+  for (int tap = 0; tap < 25; ++tap)
+    for (int ct = 0; ct < 2; ++ct)
+      for (int g = 0; g < 4; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 4; ++e) {
+            const int co = 32 * ct + (l & 31), ci = 8 * g + 4 * (l >> 5) + e;
+            f[((((size_t)tap * 2 + ct) * 4 + g) * 64 + l) * 4 + e] = w[((size_t)co * 32 + ci) * 25 + tap];
+          }
+  return f;
+}
+
+int rec_crops_per_block(int n) { return n <= 768 ? 1 : n <= 3072 ? 2 : 4; }
+
+void launch_rec_conv(const RecWeights& w, const float* crops, int n, float* feat, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(rec_forward_kernel, dim3(n), dim3(REC_THREADS), 0, s, w, crops, logits, labels, probs);
+  // few crops: one per workgroup so that every CU gets work; many: four, so that a tap's weights serve four row tiles
+  const int t = rec_crops_per_block(n);
+  const dim3 grid((n + t - 1) / t), block(256);
+  if (t == 1) hipLaunchKernelGGL(rec_conv_kernel<1>, grid, block, 0, s, crops, n, w.c1f, w.c1b, w.c2f, w.c2b, feat);
+  else if (t == 2) hipLaunchKernelGGL(rec_conv_kernel<2>, grid, block, 0, s, crops, n, w.c1f, w.c1b, w.c2f, w.c2b, feat);
+  else hipLaunchKernelGGL(rec_conv_kernel<4>, grid, block, 0, s, crops, n, w.c1f, w.c1b, w.c2f, w.c2b, feat);
+  OCR_HIP(hipGetLastError());
+}
+
+// fc2 [62][512] -> [2 column tiles][64 g][64 lanes][4]: element e of lane (j, h) is w[32 ct + j][8 g + 4 h + e] (0 for rows 62, 63)
+std::vector<float> rec_fc2_fragments(const float* w) {
+  std::vector<float> f((size_t)2 * 64 * 64 * 4, 0.f);
+  for (int ct = 0; ct < 2; ++ct)
+    for (int g = 0; g < 64; ++g)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 4; ++e) {
+          const int o = 32 * ct + (l & 31), k = 8 * g + 4 * (l >> 5) + e;
+          if (o < 62) f[(((size_t)ct * 64 + g) * 64 + l) * 4 + e] = w[(size_t)o * 512 + k];
+        }
+  return f;
+}
+
+void launch_rec_fc2_softmax(const RecWeights& w, const float* hid, int n, float* logits, int32_t* labels, double* probs, hipStream_t s) {
+  if (n <= 0 || (!logits && !labels && !probs)) return;
+  hipLaunchKernelGGL(rec_fc2_softmax_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, hid, n, w.f2f, w.f2b, logits, labels, probs);
   OCR_HIP(hipGetLastError());
 }
 

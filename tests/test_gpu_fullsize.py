@@ -98,3 +98,32 @@ def test_config2_recognition_4096_crops():
     assert l2[0] == labels[100] and p2[0] == probs[100]
     assert np.array_equal(np.argmax(logits, axis=1).astype(np.int32), labels)
     rec.close()
+
+
+def test_recognition_large_batch_chunks_and_batch_independence():
+    """65 536 + 19 crops: two passes of the recogniser's workspace (Recognizer::kChunk), the last one ragged.
+    Size-independent property: a crop's label and probability do not depend on the batch around it (every dot
+    product is one k-ordered f32 FMA chain whatever the tile shape) - checked at the chunk seam and the tail."""
+    import torch
+    rw = W.make_rec_weights(0)
+    rec = capi.Recognizer(W.pack_blob(rw), 0)
+    n = 65536 + 19
+    crops = W.synth_crops(9, n)
+    d = torch.from_numpy(crops).cuda()
+    labels = torch.empty(n, dtype=torch.int32, device="cuda")
+    probs = torch.empty(n, dtype=torch.float64, device="cuda")
+    logits = torch.empty((n, 62), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rec.classify_device(d.data_ptr(), n, logits.data_ptr(), labels.data_ptr(), probs.data_ptr())
+    rec.synchronize()
+    labels, probs, logits = labels.cpu().numpy(), probs.cpu().numpy(), logits.cpu().numpy()
+    assert np.array_equal(np.argmax(logits, axis=1).astype(np.int32), labels)
+    assert np.all((probs > 1.0 / 62 - 1e-12) & (probs <= 1.0))
+    for i in (0, 65535, 65536, 65537, n - 1):
+        l1, p1 = rec.classify_host(crops[i:i + 1])
+        assert l1[0] == labels[i] and p1[0] == probs[i]
+    sub = np.r_[np.arange(0, n, 997), np.arange(65530, 65545)]
+    ref = T.rec_forward(rw, crops[sub])
+    assert np.abs(logits[sub] - ref).max() < TOL
+    rec.close()
+

@@ -286,6 +286,40 @@ def test_rec_single_crop_and_empty(rec, rec_w):
     assert labels.shape == (0,)
 
 
+@pytest.mark.parametrize("n", [2, 3, 5, 768, 769, 3075])
+def test_rec_ragged_batches_cover_every_kernel_variant(rec, rec_w, n):
+    """The conv stage takes 1, 2 or 4 crops per workgroup depending on the batch (rec_net.hip) and the last
+    workgroup / GEMM tile is partial for these sizes: every crop against the oracle, none written past the end."""
+    crops = W.synth_crops(11 + n, n)
+    ref = T.rec_forward(rec_w, crops)
+    logits = rec.forward_host(crops)
+    assert logits.shape == (n, 62) and np.abs(logits - ref).max() < TOL
+    labels, probs = rec.classify_host(crops)
+    rl, rp = T.rec_classify(ref)
+    srt = np.sort(ref, axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 1e-3
+    assert (labels[decided] == rl[decided]).all() and np.abs(probs - rp).max() < 1e-5
+
+
+def test_rec_device_path_guards_and_profile(rec, rec_w):
+    import torch
+    n = 1001
+    crops = W.synth_crops(5, n)
+    d = torch.from_numpy(crops).cuda()
+    labels = torch.full((n + 8,), -7, dtype=torch.int32, device="cuda")     # canaries behind the last crop
+    probs = torch.full((n + 8,), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    prof = rec.classify_profile(d.data_ptr(), n, labels.data_ptr(), probs.data_ptr())
+    rec.synchronize()
+    names = [p[0] for p in prof]
+    assert names[0].startswith("rec_conv<") and names[1] == "rec_fc1" and names[2] == "rec_fc2_softmax_top1"
+    assert all(ms > 0 for _, ms, _, _ in prof)
+    assert abs(sum(fl for _, _, fl, _ in prof) / n / 8.587264e6 - 1.0) < 0.05   # executes the reference graph's work (+ K / N padding)
+    rl, _ = T.rec_classify(T.rec_forward(rec_w, crops))
+    assert labels[:n].cpu().tolist() == rl.tolist()
+    assert (labels[n:] == -7).all() and (probs[n:] == -7.0).all()
+
+
 def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     """The default engine folds in2/in3 into out2/out3 (lateral conv + phase convs on the low-res grid) and
     splits bin_conv1 over the concat into phase convs (DESIGN.md section 3).  Exact in real arithmetic;
