@@ -230,6 +230,25 @@ class Detector:
         finally:
             lib().ocr_polygons_free(out)
 
+    def postprocess_and_crops_device(self, prob_ptr: int, frames_ptr: int, n: int, h: int, w: int, adjust_values,
+                                     alloc_crops, params: Optional[PostprocParams] = None):
+        """The same on device-resident tensors: prob / frames are device pointers (N x 1 x H x W f32),
+        `alloc_crops(P)` returns the device pointer of a P x 784 f32 buffer once the polygon count P is known.
+        Returns (polygons, scores, P)."""
+        adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+        adj_p = adj.ctypes.data_as(C.POINTER(C.c_double))
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_postprocess(self._h, prob_ptr, n, h, w, MEM_DEVICE, adj_p,
+                                        C.byref(params) if params is not None else None, C.byref(out)))
+        try:
+            npoly = out.contents.n_polygons
+            if npoly:
+                check(lib().ocr_extract_crops(self._h, frames_ptr, n, h, w, MEM_DEVICE, out, adj_p, alloc_crops(npoly)))
+            polys, scores = polygons_to_python(out)
+            return polys, scores, npoly
+        finally:
+            lib().ocr_polygons_free(out)
+
     def debug_stage(self, stage_id: int, shape_nhwc) -> np.ndarray:
         """Test hook: NHWC intermediate of the last forward, returned as NCHW."""
         n = C.c_size_t(0)

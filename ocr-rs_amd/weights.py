@@ -132,6 +132,65 @@ def make_det_weights(seed: int = 0) -> Dict[str, np.ndarray]:
     return out
 
 
+def make_det_weights_text(gain: float = 0.06, tau: float = 120.0, noise: float = 0.02, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic detector weights whose probability map FOLLOWS THE INK of the page: a hand-built signal path
+    through the reference graph (model.rs:107-151) plus the random weights of make_det_weights scaled by `noise`,
+    so that every channel carries data but bright word boxes on a dark page come out as text-like blobs.  No
+    trained weights exist (.gitignore:16); random ones give noise maps, on which polygon lists of two precisions
+    cannot be compared - this set is what the end-to-end tests of BASELINE configs[4] run on.
+
+    Signal path (channel 0 everywhere): conv1 = 7x7 box mean -> bn1 identity -> ReLU -> maxpool; the residual
+    blocks pass it through (block convs ~ 0, shortcut identity or the 1x1 s2 downsample picking channel 0);
+    in2 / out2 / bin_conv1 pick it (centre taps), both transposed convs replicate it, the last one maps it to
+    sigmoid(gain * (v - tau)).  Batch norms are identities (gamma 1, beta 0, mean 0, var 1)."""
+    rnd = make_det_weights(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in det_param_specs():
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "running_var" or (leaf == "weight" and len(shape) == 1):
+            out[name] = np.ones(shape, np.float32)
+        elif len(shape) == 1:
+            out[name] = np.zeros(shape, np.float32)
+        else:
+            out[name] = (rnd[name] * np.float32(noise)).astype(np.float32)
+    out["conv1.weight"][0, 0] = np.float32(1.0 / 49.0)
+    for li in (2, 3, 4):
+        out[f"layer{li}.0.downsample.0.weight"][0, 0, 0, 0] = 1.0
+    out["in2.weight"][0, 0, 0, 0] = 1.0
+    out["out2.weight"][0, 0, 1, 1] = 1.0
+    out["bin_conv1.weight"][0, 192, 1, 1] = 1.0          # channel 0 of p2 = channel 192 of cat[p5, p4, p3, p2]
+    out["bin_conv_tr1.weight"][0, 0] = 1.0
+    out["bin_conv_tr2.weight"][:] = 0.0
+    out["bin_conv_tr2.weight"][0, 0] = np.float32(gain)
+    out["bin_conv_tr2.bias"][0] = np.float32(-gain * tau)
+    return out
+
+
+def synth_text_pages(seed: int, n: int, h: int, w: int):
+    """Synthetic pages for the end-to-end path: dark noisy paper (10..50) with a jittered grid of slanted word
+    boxes (190..250), as f32 N x 1 x H x W.  Returns (frames, boxes) with boxes[i] = [(x0, y0, x1, y1), ...]."""
+    rng = np.random.RandomState(seed)
+    frames = np.empty((n, 1, h, w), np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    boxes = []
+    for i in range(n):
+        page = rng.randint(10, 51, (h, w)).astype(np.float32)
+        bl = []
+        for gy in range(24, h - 64, 80):
+            for gx in range(24, w - 150, 168):
+                if rng.rand() < 0.15:
+                    continue
+                bw, bh = 72 + rng.randint(0, 48), 24 + rng.randint(0, 16)
+                x0, y0 = gx + rng.randint(0, 16), gy + rng.randint(0, 12)
+                sl = rng.uniform(-0.08, 0.08)
+                m = (xx >= x0) & (xx < x0 + bw) & (yy >= y0 + sl * (xx - x0)) & (yy < y0 + bh + sl * (xx - x0))
+                page[m] = rng.randint(190, 251, int(m.sum())).astype(np.float32)
+                bl.append((x0, y0, x0 + bw, y0 + bh))
+        frames[i, 0] = page
+        boxes.append(bl)
+    return frames, boxes
+
+
 def make_rec_weights(seed: int = 0) -> Dict[str, np.ndarray]:
     out: Dict[str, np.ndarray] = {}
     for ti, (name, shape) in enumerate(rec_param_specs()):
