@@ -59,12 +59,13 @@ void ocr_det_destroy(ocr_det_t* det);
  * of a torch.cuda.Stream).  NULL restores the handle's own stream. */
 int ocr_det_set_stream(ocr_det_t* det, void* hip_stream);
 
-/* Arithmetic of the detector's trunk and FPN (the reference runs f32 only; BASELINE config 5 names
- * bf16 as the optional reduced precision).  OCR_PRECISION_F32 (default): everything f32, the parity
- * configuration.  OCR_PRECISION_BF16: layer1..4, in2..5, out2..5 and bin_conv1 take bf16 activations
- * and weights with f32 accumulation and f32 folded batch norm; the stem's convolution, the
- * probability head (bin_conv_tr1, bin_bn2, bin_conv_tr2, sigmoid) and all of the post-processing
- * stay f32.  Inputs and outputs of every entry point keep their f32 layout. */
+/* Arithmetic of the detector (the reference runs f32 only; BASELINE config 5 names bf16 as the optional
+ * reduced precision).  OCR_PRECISION_F32 (default): everything f32, the parity configuration.
+ * OCR_PRECISION_BF16: every convolution of the graph - conv1, layer1..4, in2..5, out2..5, bin_conv1 and
+ * bin_conv_tr1 - takes bf16 activations and weights on the bf16 matrix cores with f32 accumulation; folded
+ * batch norm, residual adds, ReLU are f32 on the accumulators and the stored activations are bf16.  The last
+ * transposed conv (64 -> 1), the sigmoid and all of the post-processing stay f32.  Inputs and outputs of every
+ * entry point keep their f32 layout (raw 0..255 luma is exact in bf16). */
 #define OCR_PRECISION_F32 0
 #define OCR_PRECISION_BF16 1
 int ocr_det_set_precision(ocr_det_t* det, int precision);

@@ -86,6 +86,10 @@ void set_conv_tile_override(int t);  // tuning aid: 0 = automatic
 // stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
 void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,
                  void* out, int out_bf16, int N, int H, int W, hipStream_t s);
+// bf16 precision: the same stem with conv1 on v_mfma_f32_32x32x16_bf16 (weights as fragments from stem_bf16_fragments)
+std::vector<uint16_t> stem_bf16_fragments(const float* w64x49);
+void launch_stem_bf16(const float* x, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
+                      hipStream_t s);
 // Winograd F(2x2, 3x3) transforms around a batched 16-problem GEMM (winograd.hip): 3x3 s1 p1 convs of the deep,
 // small-grid layers.  x: [N][H][W][C] f32 -> v: [16][T][C], T = N * ceil(H/2) * ceil(W/2) tiles (zero padding
 // and odd sizes handled here); m: [16][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.
@@ -100,7 +104,8 @@ void launch_winograd_fused(const float* x, const float* u_neg3, const float* sca
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);
 // fused head: convT1 + bias + BN + ReLU + convT2 + bias + sigmoid (+ binarize), tail_fused.hip
-void launch_tail_fused(const float* y, const float* wt1, const float* s4, const float* b4, const float* w2t, float bias2,
+// y [M][64] and wt1 [4][64][64] are f32, or bf16 when bf16 != 0 (bf16 MFMA, f32 accumulate and f32 epilogue)
+void launch_tail_fused(const void* y, const void* wt1, int bf16, const float* s4, const float* b4, const float* w2t, float bias2,
                        float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s);
 void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n, hipStream_t s);
 

@@ -705,7 +705,8 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
     if (d.store_mode == STORE_PHASE && !d.out_bf16) return launch_tiles<__bf16, float, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
     if (d.store_mode == STORE_PHASE) return launch_tiles<__bf16, __bf16, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
     if (d.ks == 3 && d.stride == 1 && !d.out_bf16 && d.src_mode == SRC_PLAIN) return launch_tiles<__bf16, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
-    if (d.src_mode == SRC_CAT4) return launch_tiles<__bf16, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
+    if (d.src_mode == SRC_CAT4 && !d.out_bf16) return launch_tiles<__bf16, float, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
+    if (d.src_mode == SRC_CAT4) return launch_tiles<__bf16, __bf16, 3, 1, SRC_CAT4, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 1) return launch_tiles<__bf16, __bf16, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 2) return launch_tiles<__bf16, __bf16, 3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.ks == 1 && d.stride == 1) return launch_tiles<__bf16, __bf16, 1, 1, SRC_PLAIN, STORE_NHWC>(d, s);

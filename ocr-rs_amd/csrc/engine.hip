@@ -209,6 +209,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     for (int c = 0; c < 64; ++c)
       for (int k = 0; k < 49; ++k) t[k * 64 + c] = w[c * 49 + k];
     stem_w_ = arena_.upload(t);
+    stem_w_host_.assign(w, w + 64 * 49);
     std::vector<float> s, b;
     fold_bn(wb, "bn1", 64, s, b);
     stem_scale_ = arena_.upload(s);
@@ -348,6 +349,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       }
     tr1_.w = arena_.upload(t);
     tr1_.w_bytes = t.size() * sizeof(float);
+    tr1_.host = t;  // kept for the bf16 copy (set_precision)
     tr1_.scale = arena_.upload(s4);
     tr1_.bias = arena_.upload(b4);
     tr1_.cin = 64;
@@ -403,6 +405,18 @@ void Detector::set_precision(int precision) {
   if (precision != 0 && precision != 1) fail(OCR_ERR_INVALID, "precision %d (0 = f32, 1 = bf16)", precision);
   OCR_HIP(hipSetDevice(device_));
   if (precision == 1) {
+    auto upload_bf16 = [&](const uint16_t* h, size_t count) {
+      std::vector<float> packed((count + 1) / 2);
+      std::memcpy(packed.data(), h, count * 2);
+      return static_cast<void*>(arena_.upload(packed));
+    };
+    if (!stem_wb_) {  // conv1 as bf16 MFMA fragments, bin_conv_tr1 as a bf16 GEMM operand
+      const std::vector<uint16_t> fr = stem_bf16_fragments(stem_w_host_.data());
+      stem_wb_ = upload_bf16(fr.data(), fr.size());
+      std::vector<uint16_t> t1(tr1_.host.size());
+      for (size_t i = 0; i < t1.size(); ++i) t1[i] = f32_to_bf16(tr1_.host[i]);
+      tr1_.w_bf16 = upload_bf16(t1.data(), t1.size());
+    }
     for (ConvW* cw : all_convs_) {
       if (cw->w_bf16) continue;
       std::vector<float> packed((cw->host.size() + 1) / 2);
@@ -608,7 +622,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     // the probability head (bin_conv_tr1 as a GEMM) always runs in f32; bin_conv1 reads bf16 and writes f32
     const bool in_bf = bf && ex.store != STORE_SHUFFLE2;
     d.in_bf16 = in_bf ? 1 : 0;
-    d.out_bf16 = (in_bf && !ex.cat4 && !ex.f32_out) ? 1 : 0;
+    // bin_conv1 (the gathered CAT4 conv) feeds the fused head in its own element type: bf16 in the bf16 precision
+    d.out_bf16 = (in_bf && !(ex.cat4 && !fused_tail_) && !ex.f32_out) ? 1 : 0;
     d.pyr_nsrc = ex.pyr_nsrc;
     d.up = cw.up;
     const size_t ies = in_bf ? 2 : 4;
@@ -664,7 +679,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
 
   const int h4 = h / 4, w4 = w / 4;
   rec.begin();
-  launch_stem(x, stem_w_, stem_scale_, stem_bias_, s_, bf ? 1 : 0, n, h, w, stream_);
+  if (bf) launch_stem_bf16(x, stem_wb_, stem_scale_, stem_bias_, s_, n, h, w, stream_);
+  else launch_stem(x, stem_w_, stem_scale_, stem_bias_, s_, 0, n, h, w, stream_);
   rec.end("stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
           (double)n * h * w * 4 + (double)n * h4 * w4 * 64 * (double)es);
 
@@ -863,9 +879,10 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     // bin_conv_tr1 + bias + bin_bn2 + relu + bin_conv_tr2 + bias + sigmoid (+ binarize) in one kernel:
     // the 64-channel H/2 x W/2 intermediate never reaches HBM.  model.rs:146-150
     rec.begin();
-    launch_tail_fused(b1_, tr1_.w, tr1_.scale, tr1_.bias, tr2_wt_, tr2_bias_, prob, bitmap, thresh, n, h4, w4, stream_);
+    launch_tail_fused(b1_, bf ? tr1_.w_bf16 : static_cast<const void*>(tr1_.w), bf ? 1 : 0, tr1_.scale, tr1_.bias, tr2_wt_, tr2_bias_,
+                      prob, bitmap, thresh, n, h4, w4, stream_);
     rec.end("tail_convt1_bn_relu_convt2_sigmoid", 2.0 * n * h4 * w4 * 64.0 * 256 + 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
-            (double)n * h4 * w4 * 64 * 4 + (double)n * h * w * 4);
+            (double)n * h4 * w4 * 64 * (double)es + (double)n * h * w * 4);
   } else {
     // bin_conv_tr1 + bias + bin_bn2 + relu, model.rs:146-148
     {
@@ -884,7 +901,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
 
 const float* Detector::stage(int id, size_t* elems) const {
   if (ws_n_ == 0 || last_n_ == 0) fail(OCR_ERR_INVALID, "no forward has run yet");
-  if (ws_bf16_ && id != 13) fail(OCR_ERR_INVALID, "stage read-back is f32 only (bf16 precision is active)");
+  if (ws_bf16_) fail(OCR_ERR_INVALID, "stage read-back is f32 only (bf16 precision is active)");
   auto f = [](const char* p) { return reinterpret_cast<const float*>(p); };
   const size_t N = (size_t)last_n_;
   auto px = [&](int shift) { return N * (ws_h_ >> shift) * (ws_w_ >> shift); };

@@ -82,6 +82,8 @@ class Detector {
   hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena arena_;
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
+  std::vector<float> stem_w_host_;  // conv1 [64][49], kept for the bf16 fragments
+  void* stem_wb_ = nullptr;         // conv1 as bf16 MFMA fragments (stem_bf16_fragments), filled by set_precision
   ConvW layer_[4][2][2];  // [layer][block][conv1|conv2]
   ConvW down_[4];         // [layer] (layer 0 unused)
   ConvW in_[4];           // in2..in5

@@ -3,6 +3,8 @@
 //          /root/reference/src/text_detection/model.rs:108-112
 //   tail : bin_conv_tr2 convT 2x2 s2 (64->1) + bias + sigmoid, optional fused
 //          binarize(pred, thresh)      model.rs:149-150, metrics.rs:129-131
+#include <cstring>
+
 #include "common.hpp"
 
 namespace ocr {
@@ -143,6 +145,105 @@ __global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, c
   }  // tl
 }
 
+// The same stem with its convolution on the bf16 matrix cores (OCR_PRECISION_BF16; f32 accumulate, f32 batch norm,
+// bf16 output).  K = 8 kh + kw over an 8 x 8 window whose last row and column carry zero weights: one
+// v_mfma_f32_32x32x16_bf16 step covers window rows 2 s and 2 s + 1, a lane's eight operands are eight consecutive
+// pixels of ONE input row - four 4-byte LDS reads from a plain row-major bf16 image of the input tile (raw 0..255
+// luma is exact in bf16).  8 MFMAs per wave and tile instead of 56: the kernel is bound by its staging / pooling
+// phases and by HBM, not by the matrix cores.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int IRB = IR + 1;      // one more row: window row 7 of the last conv row (zero weight, must be finite)
+constexpr int PWB = 36;          // bf16 per image row (72 bytes): 32 used
+__global__ __launch_bounds__(NT) void stem_bf16_kernel(const float* __restrict__ x, const u32x4* __restrict__ wfrag,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias,
+                                                       __bf16* __restrict__ out, int H, int W) {
+  __shared__ __attribute__((aligned(16))) unsigned in_s[IRB * PWB / 2];   // two bf16 per word
+  __shared__ __attribute__((aligned(16))) float conv_s[32 * MTILES][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.z;
+  const int ph0 = blockIdx.y * TPH;
+  const int Hc = H >> 1, Wc = W >> 1, Hp = H >> 2, Wp = W >> 2;
+  const int cr0 = 2 * ph0 - 1;
+  const int ir0 = 2 * cr0 - 3;
+  const float* xin = x + (size_t)n * H * W;
+  const int half = lane >> 5, l31 = lane & 31;
+  // B operand of step s, channel tile ct: weights of window row 2 s + half, columns 0..7, channel 32 ct + (lane & 31)
+  bf16x8 wreg[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wreg[ct][s] = __builtin_bit_cast(bf16x8, wfrag[(ct * 4 + s) * 64 + lane]);
+  const float sc0 = scale[l31], bi0 = bias[l31], sc1 = scale[32 + l31], bi1 = bias[32 + l31];
+  for (int i = tid; i < PWB / 2; i += NT) in_s[(IRB - 1) * (PWB / 2) + i] = 0u;  // the extra row
+  for (int tl = 0; tl < TL; ++tl) {
+    const int pw0 = (blockIdx.x * TL + tl) * TPW;
+    if (pw0 >= Wp) break;
+    const int cc0 = 2 * pw0 - 1;
+    const int ic0 = 2 * cc0 - 3;
+    for (int i = tid; i < IR * (ICP / 2); i += NT) {   // one word = two neighbouring pixels
+      const int rr = i / (ICP / 2), cp = i - rr * (ICP / 2);
+      const int ih = ir0 + rr, iw = ic0 + 2 * cp;
+      float v0 = 0.f, v1 = 0.f;  // zero padding of conv1
+      if ((unsigned)ih < (unsigned)H) {
+        if ((unsigned)iw < (unsigned)W) v0 = xin[(size_t)ih * W + iw];
+        if ((unsigned)(iw + 1) < (unsigned)W) v1 = xin[(size_t)ih * W + iw + 1];
+      }
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const bf16x2 pk = {(__bf16)v0, (__bf16)v1};
+      in_s[rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pk);
+    }
+    __syncthreads();
+    {
+      const int mt = wv;
+      const int pix = min(32 * mt + l31, NPIX - 1);
+      const int pr = pix / CC, pc = pix - pr * CC;
+      const unsigned* row = in_s + (2 * pr + half) * (PWB / 2) + pc;  // window row `half`, first pixel pair
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x4 a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = row[2 * s * (PWB / 2) + k];
+        const bf16x8 af = __builtin_bit_cast(bf16x8, a);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[1][s], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int qr = p / CC, qc = p - qr * CC;
+        const bool valid = (unsigned)(cr0 + qr) < (unsigned)Hc && (unsigned)(cc0 + qc) < (unsigned)Wc;
+        conv_s[p][l31] = valid ? fmaxf(acc0[e] * sc0 + bi0, 0.f) : 0.f;
+        conv_s[p][32 + l31] = valid ? fmaxf(acc1[e] * sc1 + bi1, 0.f) : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int o = tid; o < TPH * TPW * 16; o += NT) {
+      const int c4 = (o & 15) * 4, pp = o >> 4;
+      const int py = pp / TPW, px = pp - py * TPW;
+      const int ph = ph0 + py, pw = pw0 + px;
+      if (ph < Hp && pw < Wp) {
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&conv_s[(2 * py + dy) * CC + 2 * px + dx][c4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+          }
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 hv = {(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+        *reinterpret_cast<bf16x4*>(out + (((size_t)n * Hp + ph) * Wp + pw) * 64 + c4) = hv;
+      }
+    }
+  }  // tl
+}
+
 // 16 lanes per input pixel (64 channels as 16 x float4, coalesced), xor-reduce, 4 taps out.
 __global__ __launch_bounds__(256) void convt2_sigmoid_kernel(const float* __restrict__ in, const float* __restrict__ w4x64,
                                                              float bias, float* __restrict__ prob,
@@ -191,6 +292,35 @@ void launch_stem(const float* x, const float* w49x64, const float* scale, const 
   dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
   if (out_bf16) hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(NT), 0, s, x, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
   else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(NT), 0, s, x, w49x64, scale, bias, static_cast<float*>(out), H, W);
+  OCR_HIP(hipGetLastError());
+}
+
+// conv1 [64][1][7][7] (f32) -> bf16 MFMA B fragments [2 channel tiles][4 steps][64 lanes][8]: element j of lane
+// (co = 32 ct + (l & 31), half = l >> 5) is w[co][kh = 2 s + half][kw = j], zero for kh = 7 or kw = 7
+std::vector<uint16_t> stem_bf16_fragments(const float* w64x49) {
+  auto bf = [](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // finite weights: round to nearest even
+  };
+  std::vector<uint16_t> fr((size_t)2 * 4 * 64 * 8, 0);
+  for (int ct = 0; ct < 2; ++ct)
+    for (int s = 0; s < 4; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int co = 32 * ct + (l & 31), kh = 2 * s + (l >> 5);
+          if (kh < 7 && j < 7) fr[(((size_t)ct * 4 + s) * 64 + l) * 8 + j] = bf(w64x49[co * 49 + kh * 7 + j]);
+        }
+  return fr;
+}
+
+void launch_stem_bf16(const float* x, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
+                      hipStream_t s) {
+  if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
+  const int Hp = H / 4, Wp = W / 4;
+  dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
+  hipLaunchKernelGGL(stem_bf16_kernel, grid, dim3(NT), 0, s, x, static_cast<const u32x4*>(wfrag), scale, bias,
+                     static_cast<__bf16*>(out), H, W);
   OCR_HIP(hipGetLastError());
 }
 

@@ -32,8 +32,8 @@ __device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, 
 }
 
 struct TailArgs {
-  const float* y;      // bin_conv1 output, NHWC [M][64]
-  const float* wt1;    // [4 taps][64 co][64 ci]
+  const void* y;       // bin_conv1 output, NHWC [M][64]            (f32, or bf16 in the bf16 precision)
+  const void* wt1;     // [4 taps][64 co][64 ci]                    (same element type as y)
   const float* s4;     // [256] folded bin_bn2 scale, index t*64+co
   const float* b4;     // [256] folded bias (conv bias and BN)
   const float* w2t;    // [64 co][4 u] bin_conv_tr2 weights, u = c'*2+d'
@@ -52,11 +52,20 @@ __device__ __forceinline__ int fdiv(int x, unsigned magic, unsigned shift) {
 }
 
 constexpr int TP = 128;                  // pixels per workgroup
-[[maybe_unused]] constexpr int A_FLOATS = 2 * TP * 32;    // two 32-channel chunks of the pixel rows
-[[maybe_unused]] constexpr int W_FLOATS = 2 * 64 * 32;    // one tap: two chunks of 64 output-channel rows
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// TI = float: v_mfma_f32_32x32x2_f32, a pixel's 64 channels are two 128-byte LDS rows (KC = 2 chunks of 32);
+// TI = __bf16 (OCR_PRECISION_BF16): v_mfma_f32_32x32x16_bf16, one 128-byte row holds all 64 channels (KC = 1) and a
+// 16-byte fragment is one MFMA operand.  Everything after the accumulators (bias, bin_bn2, ReLU, the second transposed
+// conv, sigmoid) is f32 in both.
+template <typename TI>
 __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool BF = sizeof(TI) == 2;
+  constexpr int KC = BF ? 1 : 2;                 // 128-byte chunks per pixel row
+  constexpr int EB = sizeof(TI);
+  constexpr int A_FLOATS = KC * TP * 32;         // LDS words: KC chunks of the pixel rows
+  constexpr int W_FLOATS = KC * 64 * 32;         // one tap: KC chunks of 64 output-channel rows
   __shared__ __attribute__((aligned(1024))) float lds[A_FLOATS + 2 * W_FLOATS];
   __shared__ __attribute__((aligned(16))) float tab_s[256], tab_b[256], tab_w2[256];
   float* As = lds;
@@ -64,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * TP;
-  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.y), 0, p.y_bytes, 0x00020000);
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt1), 0, 4 * 64 * 64 * 4, 0x00020000);
+  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.y), 0, p.y_bytes, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt1), 0, 4 * 64 * 64 * EB, 0x00020000);
   tab_s[tid] = p.s4[tid];
   tab_b[tid] = p.b4[tid];
   tab_w2[tid] = p.w2t[tid];
@@ -75,20 +84,20 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   const int r = tid >> 3, q = tid & 7;
   const int gq = q ^ ((r >> 1) & 7);
 #pragma unroll
-  for (int kc = 0; kc < 2; ++kc)
+  for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
     for (int i = 0; i < TP / 32; ++i) {
       const int m = m0 + r + 32 * i;
-      const unsigned off = m < p.M ? (unsigned)((m * 64 + kc * 32 + gq * 4) * 4) : 0x80000000u;  // rows past M read as zeros
+      const unsigned off = m < p.M ? (unsigned)(m * 64 * EB + kc * 128 + gq * 16) : 0x80000000u;  // rows past M read as zeros
       dma16(y_rsrc, __builtin_amdgcn_readfirstlane(lds_a + (unsigned)((kc * TP * 32 + (32 * i + 8 * wave) * 32) * 4)), off, 0);
     }
   auto issue_w = [&](int t, int buf) {
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
+    for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         dma16(w_rsrc, __builtin_amdgcn_readfirstlane(lds_w + (unsigned)((buf * W_FLOATS + kc * 64 * 32 + (32 * i + 8 * wave) * 32) * 4)),
-              (unsigned)(((r + 32 * i) * 64 + kc * 32 + gq * 4) * 4), t * 64 * 64 * 4);
+              (unsigned)((r + 32 * i) * 64 * EB + kc * 128 + gq * 16), t * 64 * 64 * EB);
   };
   issue_w(0, 0);
 
@@ -118,18 +127,24 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
     const float* wb = Ws + (t & 1) * W_FLOATS;
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
+    for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 px = *reinterpret_cast<const f32x4*>(As + kc * TP * 32 + (32 * wave + frow) * 32 + xoff[g]);
         f32x4 wf[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) wf[ct] = *reinterpret_cast<const f32x4*>(wb + kc * 64 * 32 + (32 * ct + frow) * 32 + xoff[g]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+        if constexpr (BF) {  // the 16-byte fragment is 8 bf16 of K = 16 g + 8 half + j: one MFMA
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][e], px[e], acc[ct], 0, 0, 0);  // rows = co, cols = pixels
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ct]), __builtin_bit_cast(bf16x8, px), acc[ct], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][e], px[e], acc[ct], 0, 0, 0);  // rows = co, cols = pixels
+        }
       }
     // acc[ct][e] = Z_t^T[co][pixel = lane&31] with co = 32 ct + (e&3) + 8 (e>>2) + 4 half
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -200,10 +215,11 @@ void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
 
 }  // namespace
 
-void launch_tail_fused(const float* y, const float* wt1, const float* s4, const float* b4, const float* w2t, float bias2,
+void launch_tail_fused(const void* y, const void* wt1, int bf16, const float* s4, const float* b4, const float* w2t, float bias2,
                        float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s) {
   const long long M = (long long)N * h4 * w4;
-  if (M * 64 * 4 >= (1ll << 31)) fail(OCR_ERR_INVALID, "tail: input exceeds 2^31 bytes; split the batch");
+  const int eb = bf16 ? 2 : 4;
+  if (M * 64 * eb >= (1ll << 31)) fail(OCR_ERR_INVALID, "tail: input exceeds 2^31 bytes; split the batch");
   if (w4 < 1 || h4 < 1) fail(OCR_ERR_INVALID, "tail: bad grid");
   TailArgs a{};
   a.y = y;
@@ -213,7 +229,7 @@ void launch_tail_fused(const float* y, const float* wt1, const float* s4, const 
   a.w2t = w2t;
   a.prob = prob;
   a.bitmap = bitmap;
-  a.y_bytes = (unsigned)(M * 64 * 4);
+  a.y_bytes = (unsigned)(M * 64 * eb);
   a.bias2 = bias2;
   a.thresh = thresh;
   a.M = (int)M;
@@ -221,7 +237,8 @@ void launch_tail_fused(const float* y, const float* wt1, const float* s4, const 
   a.w4 = w4;
   make_magic((unsigned)(h4 * w4), &a.mg_hw, &a.sh_hw);
   make_magic((unsigned)w4, &a.mg_w, &a.sh_w);
-  hipLaunchKernelGGL(tail_fused_kernel, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
+  if (bf16) hipLaunchKernelGGL(tail_fused_kernel<__bf16>, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(tail_fused_kernel<float>, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
 

@@ -96,9 +96,9 @@ def det_forward(params: Dict[str, np.ndarray], x: np.ndarray, stages: dict | Non
 def det_forward_bf16(params: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray:
     """The OCR_PRECISION_BF16 arithmetic of the product, restated (there is no reference behaviour to
     match: the reference is f32 only; BASELINE config 5 names bf16 as an optional precision):
-    every conv from layer1 to bin_conv1 takes operands rounded to bf16 (activations and weights),
+    every conv from conv1 to bin_conv_tr1 takes operands rounded to bf16 (activations and weights),
     accumulates in f32, applies folded batch norm / residual / ReLU in f32 and stores bf16; the FPN
-    top-down sums are stored bf16 too; the stem's conv and everything after bin_conv1 are f32.
+    top-down sums are stored bf16 too; bin_conv_tr1's result, bin_bn2, bin_conv_tr2 and the sigmoid are f32.
     Differences to the product: accumulation order only (then a bf16 rounding may flip by one ulp)."""
     p = _t(params)
 
@@ -119,7 +119,7 @@ def det_forward_bf16(params: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray
 
     with torch.no_grad():
         xs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-        s = F.conv2d(xs, p["conv1.weight"], None, 2, 3)
+        s = F.conv2d(q(xs), q(p["conv1.weight"]), None, 2, 3)
         s = q(F.max_pool2d(F.relu(_bn(s, p, "bn1")), 3, 2, 1, 1, False))
         feats = []
         cur = s
@@ -147,8 +147,8 @@ def det_forward_bf16(params: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray
         p4 = up(q(conv(s4, "out4.weight", 1, 1)), 4)
         p5 = up(q(conv(i5, "out5.weight", 1, 1)), 8)
         fuse = torch.cat([p5, p4, p3, p2], 1)
-        y = F.relu(_bn(conv(fuse, "bin_conv1.weight", 1, 1), p, "bin_bn1"))   # f32 out
-        y = F.conv_transpose2d(y, p["bin_conv_tr1.weight"], p["bin_conv_tr1.bias"], 2, 0)
+        y = q(F.relu(_bn(conv(fuse, "bin_conv1.weight", 1, 1), p, "bin_bn1")))
+        y = F.conv_transpose2d(y, q(p["bin_conv_tr1.weight"]), p["bin_conv_tr1.bias"], 2, 0)
         y = F.relu(_bn(y, p, "bin_bn2"))
         y = F.conv_transpose2d(y, p["bin_conv_tr2.weight"], p["bin_conv_tr2.bias"], 2, 0)
         return torch.sigmoid(y).numpy()
