@@ -44,6 +44,11 @@ const char* ocr_version(void);
 /* Number of visible HIP devices (never throws; 0 when there is no GPU). */
 int ocr_device_count(void);
 
+/* VarStore file -> OCRW blob, host only (no GPU needed): kind 0 / 1 = names as stored (detector), 2 = recogniser
+ * (tch's name__N leafs mapped by shape).  *blob is malloc'ed by the library; release it with ocr_blob_free. */
+int ocr_varstore_to_blob(const char* path, int kind, void** blob, size_t* blob_bytes);
+void ocr_blob_free(void* blob);
+
 /* ---------------------------------------------------------------------------
  * Detector.  Replaces, for inference:
  *   let net = resnet18(&vs.root()); vs.load(file)      text_detection/mod.rs:35-44
@@ -53,6 +58,10 @@ int ocr_device_count(void);
  * tensor names are the VarStore names of model.rs:68-105; it is copied.
  * ------------------------------------------------------------------------- */
 int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_det_t** out);
+/* The one-call replacement of `vs.load(file)` (text_detection/mod.rs:41-44): reads the file tch's
+ * VarStore::save wrote (utils.rs:55-63) - a libtorch zip archive of named tensors - without libtorch or Python,
+ * checks names and shapes against the graph of model.rs:68-105 and builds the detector. */
+int ocr_det_create_from_varstore(const char* path, int device, ocr_det_t** out);
 void ocr_det_destroy(ocr_det_t* det);
 
 /* Run all later work of this handle on an existing hipStream_t (e.g. the stream
@@ -180,6 +189,10 @@ int ocr_combine_results(const ocr_metrics_item_t* items, int n, double* precisio
  * graph: char_recognition/model.rs:13-39.
  * ------------------------------------------------------------------------- */
 int ocr_rec_create(const void* weights, size_t weights_bytes, int device, ocr_rec_t** out);
+/* `weights.load(file)` of char_recognition/mod.rs:46.  Net::new creates its four layers on one nn::Path
+ * (model.rs:13-24), so the file holds tch's de-duplicated names weight, bias, weight__2, bias__3, ...; they are
+ * mapped onto conv1 / conv2 / fc1 / fc2 by shape (all eight shapes differ).  conv1.weight ... names work too. */
+int ocr_rec_create_from_varstore(const char* path, int device, ocr_rec_t** out);
 void ocr_rec_destroy(ocr_rec_t* rec);
 int ocr_rec_set_stream(ocr_rec_t* rec, void* hip_stream);
 int ocr_rec_synchronize(ocr_rec_t* rec);

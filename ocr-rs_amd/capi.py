@@ -21,6 +21,7 @@ PRECISION_F32, PRECISION_BF16 = 0, 1
 
 EXPORTS = [
     "ocr_last_error", "ocr_version", "ocr_device_count",
+    "ocr_varstore_to_blob", "ocr_blob_free", "ocr_det_create_from_varstore", "ocr_rec_create_from_varstore",
     "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
@@ -69,6 +70,11 @@ def lib() -> C.CDLL:
         L.ocr_det_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_det_destroy.argtypes = [C.c_void_p]
         L.ocr_det_destroy.restype = None
+        L.ocr_det_create_from_varstore.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ocr_rec_create_from_varstore.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ocr_varstore_to_blob.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.ocr_blob_free.argtypes = [C.c_void_p]
+        L.ocr_blob_free.restype = None
         L.ocr_det_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.ocr_det_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.ocr_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -150,6 +156,19 @@ def polygons_to_python(pp) -> Tuple[List[List[List[Tuple[int, int]]]], List[List
     return polys, scores
 
 
+VARSTORE_RAW, VARSTORE_DET, VARSTORE_REC = 0, 1, 2
+
+
+def varstore_to_blob(path: str, kind: int = VARSTORE_RAW) -> bytes:
+    """tch VarStore file -> OCRW blob through the library's own zip + pickle reader (host only, no torch)."""
+    blob, n = C.c_void_p(), C.c_size_t(0)
+    check(lib().ocr_varstore_to_blob(os.fsencode(path), kind, C.byref(blob), C.byref(n)))
+    try:
+        return C.string_at(blob, n.value)
+    finally:
+        lib().ocr_blob_free(blob)
+
+
 def default_params(skip_degenerate: bool = False) -> PostprocParams:
     p = PostprocParams()
     lib().ocr_postproc_default_params(C.byref(p))
@@ -161,10 +180,13 @@ class Detector:
     """Owns an ocr_det_t.  Mirrors `resnet18(&vs.root())` + `vs.load(..)`
     (/root/reference/src/text_detection/mod.rs:35-44)."""
 
-    def __init__(self, weights_blob: bytes, device: int = 0):
+    def __init__(self, weights_blob: Optional[bytes], device: int = 0, varstore_path: Optional[str] = None):
         self._h = C.c_void_p()
         self._blob = weights_blob
-        check(lib().ocr_det_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
+        if varstore_path is not None:   # `vs.load(file)`: the library reads the tch archive itself
+            check(lib().ocr_det_create_from_varstore(os.fsencode(varstore_path), device, C.byref(self._h)))
+        else:
+            check(lib().ocr_det_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
@@ -337,9 +359,12 @@ class Recognizer:
     """Owns an ocr_rec_t.  Mirrors `Net::new(&weights.root())` + `weights.load(..)`
     (/root/reference/src/char_recognition/mod.rs:44-46)."""
 
-    def __init__(self, weights_blob: bytes, device: int = 0):
+    def __init__(self, weights_blob: Optional[bytes], device: int = 0, varstore_path: Optional[str] = None):
         self._h = C.c_void_p()
-        check(lib().ocr_rec_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
+        if varstore_path is not None:
+            check(lib().ocr_rec_create_from_varstore(os.fsencode(varstore_path), device, C.byref(self._h)))
+        else:
+            check(lib().ocr_rec_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:

@@ -1,6 +1,7 @@
 // extern "C" boundary (include/ocr_amd.h).  Nothing throws across it.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -183,7 +184,31 @@ int ocr_det_create(const void* weights, size_t bytes, int device, ocr_det_t** ou
     *out = new ocr_det(weights, bytes, device);
   });
 }
+int ocr_det_create_from_varstore(const char* path, int device, ocr_det_t** out) {
+  return guard([&] {
+    if (!out) ocr::fail(OCR_ERR_INVALID, "ocr_det_create_from_varstore: out is null");
+    *out = nullptr;
+    const std::vector<uint8_t> blob = ocr::varstore_to_blob(path, 1);
+    *out = new ocr_det(blob.data(), blob.size(), device);
+  });
+}
 void ocr_det_destroy(ocr_det_t* det) { delete det; }
+
+int ocr_varstore_to_blob(const char* path, int kind, void** blob, size_t* blob_bytes) {
+  return guard([&] {
+    if (!blob || !blob_bytes) ocr::fail(OCR_ERR_INVALID, "ocr_varstore_to_blob: null output");
+    *blob = nullptr;
+    *blob_bytes = 0;
+    if (kind < 0 || kind > 2) ocr::fail(OCR_ERR_INVALID, "ocr_varstore_to_blob: kind %d", kind);
+    const std::vector<uint8_t> b = ocr::varstore_to_blob(path, kind);
+    void* p = std::malloc(b.size() ? b.size() : 1);
+    if (!p) ocr::fail(OCR_ERR_INTERNAL, "out of memory");
+    std::memcpy(p, b.data(), b.size());
+    *blob = p;
+    *blob_bytes = b.size();
+  });
+}
+void ocr_blob_free(void* blob) { std::free(blob); }
 
 int ocr_det_set_stream(ocr_det_t* det, void* s) {
   return guard([&] {
@@ -389,6 +414,14 @@ int ocr_rec_create(const void* weights, size_t bytes, int device, ocr_rec_t** ou
     if (!out) ocr::fail(OCR_ERR_INVALID, "ocr_rec_create: out is null");
     *out = nullptr;
     *out = new ocr_rec(weights, bytes, device);
+  });
+}
+int ocr_rec_create_from_varstore(const char* path, int device, ocr_rec_t** out) {
+  return guard([&] {
+    if (!out) ocr::fail(OCR_ERR_INVALID, "ocr_rec_create_from_varstore: out is null");
+    *out = nullptr;
+    const std::vector<uint8_t> blob = ocr::varstore_to_blob(path, 2);
+    *out = new ocr_rec(blob.data(), blob.size(), device);
   });
 }
 void ocr_rec_destroy(ocr_rec_t* rec) { delete rec; }

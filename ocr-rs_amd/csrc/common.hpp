@@ -137,6 +137,18 @@ void launch_rec_conv(const RecWeights& w, const float* crops, int n, float* feat
 std::vector<float> rec_fc2_fragments(const float* w_62x512);
 void launch_rec_fc2_softmax(const RecWeights& w, const float* hid, int n, float* logits62, int32_t* labels, double* probs, hipStream_t s);
 
+// tch VarStore archives (varstore.cpp): `vs.load(file)` without libtorch
+struct NamedTensor {
+  std::string name;
+  std::vector<int> dims;
+  std::vector<float> data;  // f32, row-major
+};
+std::vector<NamedTensor> read_varstore(const char* path);
+void rename_tch_rec(std::vector<NamedTensor>& tensors);
+std::vector<uint8_t> pack_ocrw(const std::vector<NamedTensor>& tensors);
+// kind: 0 = names as stored, 1 = detector (same), 2 = recogniser (tch's name__N leafs mapped by shape)
+std::vector<uint8_t> varstore_to_blob(const char* path, int kind);
+
 // box score: masked mean of prob over rasterised polygons (metrics.rs:150-184)
 struct BoxScoreJob {
   int image;      // batch index
