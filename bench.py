@@ -426,6 +426,26 @@ def main():
                     P.all_gather_results(pl, sc, comm_dev)
                 fence()
                 e2e = max_over_ranks(time.perf_counter() - t1)
+            # the same exchange through the C ABI (ocr_comm_*, RCCL called from the library, no torch in the path): what a
+            # non-Python host binds.  Only with the nccl backend (one GPU per rank); a failure is reported, never fatal.
+            cabi = {}
+            if backend == "nccl":
+                try:
+                    idb = [capi.Comm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(idb, src=0)
+                    comm = capi.Comm(idb[0], world, rank, local)
+                    cp, cs = comm.all_gather_polygons(polys, scores)
+                    same = cp == all_p and cs == all_s
+                    fence()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        comm.all_gather_polygons(polys, scores)
+                    cabi = {"all_gather_results_c_abi_ms": round(max_over_ranks((time.perf_counter() - t1) / 10 * 1e3), 3),
+                            "all_gather_results_c_abi_matches": bool(same), "rccl_version_c_abi": capi.Comm.rccl_version()}
+                    comm.close()
+                except Exception as e:
+                    cabi = {"all_gather_results_c_abi_error": f"{type(e).__name__}: {e}"}
+            post.update(cabi)
             post.update({"rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
                          "collective_backend": backend + (f" (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})" if backend == "nccl" else ""),
                          "all_gather_results_ms": round(gather_ms, 3),

@@ -58,6 +58,18 @@ void ocr_blob_free(void* blob);
  * tensor names are the VarStore names of model.rs:68-105; it is copied.
  * ------------------------------------------------------------------------- */
 int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_det_t** out);
+/* The same with explicit engine options, "key=value;key=value" (NULL or "" = the defaults).  The library never reads
+ * the environment: which schedule runs is the caller's choice.  Every combination computes the same graph and is
+ * held to the same parity bars (tests/test_gpu_parity.py::test_engine_modes_agree); they exist for A/B measurements.
+ *   winograd_fused=0|1   (1)    fused Winograd F(2x2,3x3) kernel for the 3x3 s1 convs of the large grids
+ *   winograd=<cin>|0     (256)  unfused Winograd for 3x3 s1 trunk convs with Cin >= cin that have no fused form; 0 = off
+ *   fpn_unfused=0|1      (0)    1 = layer-by-layer FPN (laterals, top-down sums, out_k, gathered bin_conv1) as model.rs writes it
+ *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)
+ *   tail_unfused=0|1     (0)    1 = probability head as two launches
+ *   overlap=0|1|2        (0)    second stream for small independent launches (1) and the FPN branch (2)
+ *   precision=f32|bf16   (f32)  same as ocr_det_set_precision */
+int ocr_det_create_with_options(const void* weights, size_t weights_bytes, int device, const char* options,
+                                ocr_det_t** out);
 /* The one-call replacement of `vs.load(file)` (text_detection/mod.rs:41-44): reads the file tch's
  * VarStore::save wrote (utils.rs:55-63) - a libtorch zip archive of named tensors - without libtorch or Python,
  * checks names and shapes against the graph of model.rs:68-105 and builds the detector. */
@@ -213,6 +225,30 @@ int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels,
                      int mem_kind);
 /* The label alphabet, utils.rs:7 ("A-Za-z0-9", 62 symbols, NUL terminated). */
 const char* ocr_rec_alphabet(void);
+
+/* ---------------------------------------------------------------------------
+ * Multi-GPU exchange.  Frames and crops are independent (eval-mode batch norm), so a batch shards over the GPUs of
+ * a node with no data-path collective: one process (or thread) per GPU, each with its own detector / recogniser
+ * handle and its own contiguous slice of the batch.  The single exchange step is the all-gather of the results,
+ * over RCCL (xGMI inside a node).  The reference has no counterpart (it is single-device); a Rust
+ * host binds these four calls next to the others.
+ *   rank 0: ocr_comm_unique_id(id) and hand the 128 bytes to the other ranks (file, environment, launcher ...);
+ *   every rank: ocr_comm_create(id, world, rank, device, &comm)      - collective
+ *               ocr_comm_all_gather_polygons(comm, mine, &all)       - collective; `all` holds the frames of rank 0,
+ *                                                                      then rank 1, ...; free with ocr_polygons_free
+ * RCCL is loaded on first use (librccl.so.1); without it these calls fail with a message, nothing else is affected.
+ * ------------------------------------------------------------------------- */
+typedef struct ocr_comm ocr_comm_t;
+#define OCR_COMM_ID_BYTES 128
+int ocr_comm_unique_id(uint8_t* id /* [OCR_COMM_ID_BYTES] */);
+int ocr_comm_rccl_version(int* version);
+int ocr_comm_create(const uint8_t* id, int world, int rank, int device, ocr_comm_t** out);
+void ocr_comm_destroy(ocr_comm_t* comm);
+int ocr_comm_all_gather_polygons(ocr_comm_t* comm, const ocr_polygons_t* local, ocr_polygons_t** all);
+/* labels of the local crops (host memory) -> labels of every rank's crops in rank order; counts[world] receives
+ * the number each rank contributed (may be NULL); fails if more than `capacity` labels arrive. */
+int ocr_comm_all_gather_labels(ocr_comm_t* comm, const int32_t* labels, int n_local, int32_t* all, int capacity,
+                               int32_t* counts, int* n_all);
 
 #ifdef __cplusplus
 }

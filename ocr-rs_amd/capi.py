@@ -22,12 +22,14 @@ PRECISION_F32, PRECISION_BF16 = 0, 1
 EXPORTS = [
     "ocr_last_error", "ocr_version", "ocr_device_count",
     "ocr_varstore_to_blob", "ocr_blob_free", "ocr_det_create_from_varstore", "ocr_rec_create_from_varstore",
-    "ocr_det_create", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
+    "ocr_det_create", "ocr_det_create_with_options", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet",
+    "ocr_comm_unique_id", "ocr_comm_rccl_version", "ocr_comm_create", "ocr_comm_destroy",
+    "ocr_comm_all_gather_polygons", "ocr_comm_all_gather_labels",
 ]
 
 
@@ -70,6 +72,7 @@ def lib() -> C.CDLL:
         L.ocr_det_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_det_destroy.argtypes = [C.c_void_p]
         L.ocr_det_destroy.restype = None
+        L.ocr_det_create_with_options.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
         L.ocr_det_create_from_varstore.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_rec_create_from_varstore.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_varstore_to_blob.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -110,7 +113,31 @@ def lib() -> C.CDLL:
         L.ocr_rec_classify_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
                                                C.POINTER(C.c_double), C.POINTER(C.c_int)]
-        # host-geometry test hooks
+        L.ocr_comm_unique_id.argtypes = [C.c_void_p]
+        L.ocr_comm_rccl_version.argtypes = [C.POINTER(C.c_int)]
+        L.ocr_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.ocr_comm_destroy.argtypes = [C.c_void_p]
+        L.ocr_comm_destroy.restype = None
+        L.ocr_comm_all_gather_polygons.argtypes = [C.c_void_p, C.POINTER(Polygons), C.POINTER(C.POINTER(Polygons))]
+        L.ocr_comm_all_gather_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                 C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+_test_lib = None
+TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libocr_amd_test.so")
+
+
+def test_lib() -> C.CDLL:
+    """libocr_amd_test.so: the ocr_test_* hooks (kernel-level parity, host geometry, tuning aids).  A separate
+    library on top of the product one - nothing of it ships in libocr_amd.so."""
+    global _test_lib
+    if _test_lib is None:
+        lib()                                   # the product library first: the hooks link against it
+        if not os.path.exists(TEST_LIB_PATH):
+            raise OcrError(-1, f"{TEST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(TEST_LIB_PATH)
         L.ocr_test_contour_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int, C.POINTER(C.c_int)]
         L.ocr_test_expand_polygon.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int,
@@ -123,10 +150,11 @@ def lib() -> C.CDLL:
                                         [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2)
         L.ocr_test_set_conv_tile.argtypes = [C.c_int]
         L.ocr_test_winograd_conv.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int] +
-                                             [C.c_void_p] * 3 + [C.c_int, C.c_void_p])
+                                             [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p])
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
-        _lib = L
-    return _lib
+        L.ocr_test_comm_assemble.argtypes = [C.POINTER(C.POINTER(Polygons)), C.c_int, C.POINTER(C.POINTER(Polygons))]
+        _test_lib = L
+    return _test_lib
 
 
 def check(code: int) -> None:
@@ -180,13 +208,16 @@ class Detector:
     """Owns an ocr_det_t.  Mirrors `resnet18(&vs.root())` + `vs.load(..)`
     (/root/reference/src/text_detection/mod.rs:35-44)."""
 
-    def __init__(self, weights_blob: Optional[bytes], device: int = 0, varstore_path: Optional[str] = None):
+    def __init__(self, weights_blob: Optional[bytes], device: int = 0, varstore_path: Optional[str] = None,
+                 options: Optional[str] = None):
+        """options: "key=value;..." engine options of ocr_det_create_with_options (None = defaults)."""
         self._h = C.c_void_p()
         self._blob = weights_blob
         if varstore_path is not None:   # `vs.load(file)`: the library reads the tch archive itself
             check(lib().ocr_det_create_from_varstore(os.fsencode(varstore_path), device, C.byref(self._h)))
         else:
-            check(lib().ocr_det_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
+            check(lib().ocr_det_create_with_options(weights_blob, len(weights_blob), device,
+                                                    options.encode() if options else None, C.byref(self._h)))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
@@ -274,9 +305,9 @@ class Detector:
     def debug_stage(self, stage_id: int, shape_nhwc) -> np.ndarray:
         """Test hook: NHWC intermediate of the last forward, returned as NCHW."""
         n = C.c_size_t(0)
-        check(lib().ocr_test_det_stage(self._h, stage_id, None, 0, C.byref(n)))
+        check(test_lib().ocr_test_det_stage(self._h, stage_id, None, 0, C.byref(n)))
         out = np.empty(n.value, np.float32)
-        check(lib().ocr_test_det_stage(self._h, stage_id, _ptr(out), n.value, C.byref(n)))
+        check(test_lib().ocr_test_det_stage(self._h, stage_id, _ptr(out), n.value, C.byref(n)))
         return np.ascontiguousarray(out.reshape(shape_nhwc).transpose(0, 3, 1, 2))
 
     def preprocess_image(self, rgba: np.ndarray, target_w: int, target_h: int, want_f32: bool = False):
@@ -293,7 +324,7 @@ class Detector:
     def debug_conv_bench(self, n, h, w, cin, cout, ks=3, stride=1, src_mode=0, iters=5) -> float:
         """Test hook: average milliseconds of one conv_igemm launch of this shape."""
         ms = C.c_float(0.0)
-        check(lib().ocr_test_conv_bench(self._h, n, h, w, cin, cout, ks, stride, src_mode, iters, C.byref(ms)))
+        check(test_lib().ocr_test_conv_bench(self._h, n, h, w, cin, cout, ks, stride, src_mode, iters, C.byref(ms)))
         return ms.value
 
     def debug_conv_run(self, x_nhwc, wgt_ohwi, stride=1, scale=None, bias=None, residual=None, up_residual=None,
@@ -311,12 +342,12 @@ class Detector:
         out2 = np.empty((n, ho, wo, cout), np.float32) if want_out2 else None
         sc, bi, rs, ur = f(scale), f(bias), f(residual), f(up_residual)
         p = lambda a: None if a is None else _ptr(a)
-        check(lib().ocr_test_conv_run(self._h, int(in_bf16), int(out_bf16), _ptr(x), n, h, w, cin, _ptr(wg), cout, ks,
+        check(test_lib().ocr_test_conv_run(self._h, int(in_bf16), int(out_bf16), _ptr(x), n, h, w, cin, _ptr(wg), cout, ks,
                                       stride, p(sc), p(bi), p(rs), p(ur), int(relu), int(bool(cat4_shape)),
                                       p(out), p(out2)))
         return out, out2
 
-    def debug_winograd_conv(self, x_nhwc, wgt_ohwi, scale=None, bias=None, residual=None, relu=False):
+    def debug_winograd_conv(self, x_nhwc, wgt_ohwi, scale=None, bias=None, residual=None, relu=False, unfused=False):
         """3x3 s1 p1 conv through the Winograd path on caller data (test hook): N x H x W x Cout f32."""
         f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
         x, wg = f(x_nhwc), f(wgt_ohwi)
@@ -326,8 +357,8 @@ class Detector:
         sc, bi, rs = f(scale), f(bias), f(residual)
         p = lambda a: None if a is None else _ptr(a)
         out = np.empty((n, h, w, cout), np.float32)
-        check(lib().ocr_test_winograd_conv(self._h, _ptr(x), n, h, w, cin, _ptr(wg), cout, p(sc), p(bi), p(rs),
-                                           int(relu), _ptr(out)))
+        check(test_lib().ocr_test_winograd_conv(self._h, _ptr(x), n, h, w, cin, _ptr(wg), cout, p(sc), p(bi), p(rs),
+                                                int(relu), int(unfused), _ptr(out)))
         return out
 
     def debug_box_scores(self, pred_hw: np.ndarray, polys):
@@ -338,7 +369,7 @@ class Detector:
         cnt = np.asarray([len(p) for p in polys], dtype=np.int32)
         sums = np.empty(len(polys), np.float64)
         counts = np.empty(len(polys), np.float64)
-        check(lib().ocr_test_box_scores(self._h, _ptr(pred), h, w, _ptr(xy), _ptr(cnt), len(polys), _ptr(sums),
+        check(test_lib().ocr_test_box_scores(self._h, _ptr(pred), h, w, _ptr(xy), _ptr(cnt), len(polys), _ptr(sums),
                                         _ptr(counts)))
         return sums, counts
 
@@ -415,6 +446,85 @@ class Recognizer:
                                            probs_ptr or None))
 
 
+def python_to_polygons(polys, scores):
+    """PolygonScores as Python lists -> (Polygons struct, keep-alive arrays) for the calls that take a block."""
+    img = np.cumsum([0] + [len(p) for p in polys]).astype(np.int32)
+    flat = [pg for p in polys for pg in p]
+    po = np.cumsum([0] + [len(pg) for pg in flat]).astype(np.int32)
+    xy = np.asarray([c for pg in flat for v in pg for c in v], dtype=np.uint32)
+    sc = np.asarray([s for ss in scores for s in ss], dtype=np.float64)
+    st = Polygons(len(polys), len(flat), int(po[-1]), img.ctypes.data_as(C.POINTER(C.c_int32)),
+                  po.ctypes.data_as(C.POINTER(C.c_int32)), xy.ctypes.data_as(C.POINTER(C.c_uint32)),
+                  sc.ctypes.data_as(C.POINTER(C.c_double)))
+    return st, (img, po, xy, sc)
+
+
+class Comm:
+    """Owns an ocr_comm_t: the RCCL communicator behind the C ABI (one per rank; creation is collective)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(lib().ocr_comm_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def rccl_version() -> int:
+        v = C.c_int(0)
+        check(lib().ocr_comm_rccl_version(C.byref(v)))
+        return v.value
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int = 0):
+        self._h = C.c_void_p()
+        self.world, self.rank = world, rank
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib().ocr_comm_create(buf, world, rank, device, C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ocr_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_polygons(self, polys, scores):
+        st, keep = python_to_polygons(polys, scores)
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_comm_all_gather_polygons(self._h, C.byref(st), C.byref(out)))
+        try:
+            return polygons_to_python(out)
+        finally:
+            lib().ocr_polygons_free(out)
+
+    def all_gather_labels(self, labels: np.ndarray, capacity: int):
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        out = np.empty(capacity, np.int32)
+        counts = np.zeros(self.world, np.int32)
+        n = C.c_int(0)
+        check(lib().ocr_comm_all_gather_labels(self._h, _ptr(labels), labels.size, _ptr(out), capacity, _ptr(counts), C.byref(n)))
+        return out[:n.value].copy(), counts
+
+
+def comm_assemble(shards):
+    """Test hook: what ocr_comm_all_gather_polygons returns for these per-rank (polys, scores) shards, without RCCL."""
+    structs, keep = [], []
+    for polys, scores in shards:
+        st, k = python_to_polygons(polys, scores)
+        structs.append(st)
+        keep.append(k)
+    arr = (C.POINTER(Polygons) * len(structs))(*[C.pointer(s) for s in structs])
+    out = C.POINTER(Polygons)()
+    check(test_lib().ocr_test_comm_assemble(arr, len(structs), C.byref(out)))
+    try:
+        return polygons_to_python(out)
+    finally:
+        lib().ocr_polygons_free(out)
+
+
 # ---- host-geometry hooks (CPU only; used by tests to pin the C++ geometry to the KATs)
 def host_contour_candidates(bitmap01: np.ndarray) -> List[List[Tuple[int, int]]]:
     bm = np.ascontiguousarray(bitmap01, dtype=np.uint8)
@@ -423,7 +533,7 @@ def host_contour_candidates(bitmap01: np.ndarray) -> List[List[Tuple[int, int]]]
     xy = np.empty(2 * max_pts, np.int32)
     cnt = np.empty(max_polys, np.int32)
     n = C.c_int(0)
-    check(lib().ocr_test_contour_candidates(_ptr(bm), h, w, _ptr(xy), _ptr(cnt), max_pts, max_polys, C.byref(n)))
+    check(test_lib().ocr_test_contour_candidates(_ptr(bm), h, w, _ptr(xy), _ptr(cnt), max_pts, max_polys, C.byref(n)))
     out, pos = [], 0
     for k in range(n.value):
         c = int(cnt[k])
@@ -437,7 +547,7 @@ def host_expand_polygon(pts: Sequence[Tuple[int, int]], factor: float = 2.0):
     out = np.empty(8192, np.int32)
     n = C.c_int(0)
     ss = C.c_double(0.0)
-    check(lib().ocr_test_expand_polygon(_ptr(a), len(pts), factor, _ptr(out), 4096, C.byref(n), C.byref(ss)))
+    check(test_lib().ocr_test_expand_polygon(_ptr(a), len(pts), factor, _ptr(out), 4096, C.byref(n), C.byref(ss)))
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)], ss.value
 
 
@@ -445,5 +555,5 @@ def host_min_area_box(pts: Sequence[Tuple[int, int]]):
     a = np.asarray(pts, dtype=np.int32).reshape(-1)
     box = np.empty(8, np.int32)
     ss = C.c_double(0.0)
-    check(lib().ocr_test_min_area_box(_ptr(a), len(pts), _ptr(box), C.byref(ss)))
+    check(test_lib().ocr_test_min_area_box(_ptr(a), len(pts), _ptr(box), C.byref(ss)))
     return [(int(box[2 * i]), int(box[2 * i + 1])) for i in range(4)], ss.value

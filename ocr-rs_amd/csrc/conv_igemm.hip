@@ -562,16 +562,12 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.nblk_m = (a.M + BM - 1) / BM;
   a.up_shift = d.up == 8 ? 3 : d.up == 4 ? 2 : 1;
   a.batch = d.batch > 1 ? d.batch : 1;
-  {
-    static const int chunked = [] { const char* e = getenv("OCR_PYR_ORDER"); return e ? atoi(e) : 1; }();
-    a.pyr_chunked = chunked;
-    a.pyr_nsrc = d.pyr_nsrc == 3 ? 3 : 4;
-  }
+  a.pyr_chunked = 1;
+  a.pyr_nsrc = d.pyr_nsrc == 3 ? 3 : 4;
   a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
-  static const int extra_lds = getenv("OCR_CONV_EXTRA_LDS") ? atoi(getenv("OCR_CONV_EXTRA_LDS")) : 0;  // tuning knob: caps residency
-  hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), extra_lds, s, a);
+  hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
 

@@ -184,14 +184,55 @@ ConvW Detector::compose_upsampled(const ConvW& out, const ConvW& in_up) {
   return phase_conv(compose_taps(out, in_up), out.cout, in_up.cin, 2);
 }
 
-Detector::Detector(const void* blob, size_t bytes, int device) : device_(device) {
+// "key=value;key=value" -> engine options (include/ocr_amd.h, ocr_det_create_with_options).  The environment is
+// never consulted: which schedule runs is the caller's explicit choice.
+void Detector::parse_options(const char* options) {
+  if (!options) return;
+  std::string s(options);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find_first_of(";,", pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string item = s.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.find_first_not_of(" \t") == std::string::npos) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) fail(OCR_ERR_INVALID, "detector option '%s': expected key=value", item.c_str());
+    auto trim = [](std::string v) {
+      const size_t a = v.find_first_not_of(" \t"), b = v.find_last_not_of(" \t");
+      return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+    };
+    const std::string key = trim(item.substr(0, eq)), val = trim(item.substr(eq + 1));
+    auto num = [&]() {
+      char* endp = nullptr;
+      const long v = std::strtol(val.c_str(), &endp, 10);
+      if (val.empty() || *endp) fail(OCR_ERR_INVALID, "detector option %s: '%s' is not an integer", key.c_str(), val.c_str());
+      return (int)v;
+    };
+    if (key == "winograd_fused") winograd_fused_ = num() != 0;
+    else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
+    else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
+    else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
+    else if (key == "tail_unfused") fused_tail_ = num() == 0;
+    else if (key == "overlap") overlap_ = num();
+    else if (key == "precision") {
+      if (val == "bf16") opt_bf16_ = true;
+      else if (val == "f32") opt_bf16_ = false;
+      else fail(OCR_ERR_INVALID, "detector option precision: '%s' (f32 or bf16)", val.c_str());
+    } else fail(OCR_ERR_INVALID, "unknown detector option '%s'", key.c_str());
+  }
+}
+
+Detector::Detector(const void* blob, size_t bytes, int device, const char* options) : device_(device) {
   check_device(device);
+  parse_options(options);
   WeightBlob wb(blob, bytes);
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
   {
-    const char* e = getenv("OCR_OVERLAP");
-    if (e) overlap_ = atoi(e);
+    hipDeviceProp_t prop;
+    OCR_HIP(hipGetDeviceProperties(&prop, device));
+    num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (overlap_) {
       OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
       OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
@@ -233,14 +274,6 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     in_[l] = make_conv(wb, "in" + std::to_string(l + 2) + ".weight", "", 256, 64 << l, 1);
     out_[l] = make_conv(wb, "out" + std::to_string(l + 2) + ".weight", "", 64, 256, 3);
   }
-  {
-    const char* e = getenv("OCR_WINOGRAD");
-    if (e) winograd_min_cin_ = atoi(e) > 0 ? atoi(e) : (1 << 30);
-  }
-  {
-    const char* e = getenv("OCR_WINOGRAD_FUSED");
-    winograd_fused_ = !(e && e[0] == '0');
-  }
   if (winograd_fused_) {
     for (int b = 0; b < 2; ++b)
       for (int c = 0; c < 2; ++c) add_winograd_fused_weights(layer_[0][b][c]);
@@ -259,10 +292,6 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     add_winograd_weights(layer_[l][0][1]);
     add_winograd_weights(layer_[l][1][0]);
     add_winograd_weights(layer_[l][1][1]);
-  }
-  {
-    const char* e = getenv("OCR_FPN_UNFUSED");
-    fpn_composed_ = !(e && e[0] == '1');
   }
   if (fpn_composed_)
     for (int l = 0; l < 2; ++l) {
@@ -289,10 +318,6 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     const std::vector<double> t2 = slice(3);
     bin_p2_ = finish_composed(std::vector<float>(t2.begin(), t2.end()), 64, 64, 3);
     bin_up_[2].bias = bin1_.bias;  // the p5 term is accumulated last: it adds the bias and applies the ReLU
-    {
-      const char* e = getenv("OCR_BIN_PYR");
-      bin_pyr_on_ = !(e && e[0] == '0');
-    }
     if (bin_pyr_on_) {
       // [phase = 8 a + b][cout][slot][64]: slots 4 s + (th * nw + tw) for the upsampled sources s = 0 (p5, up 8),
       // 1 (p4, up 4), 2 (p3, up 2) with the tap merging of phase_conv(), slots 12 + 3 dy + dx for p2
@@ -367,8 +392,6 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
       for (int k = 0; k < 4; ++k) tt[ci * 4 + k] = w[ci * 4 + k];
     tr2_wt_ = arena_.upload(tt);
     tr2_bias_ = wb.get("bin_conv_tr2.bias", {1}).data[0];
-    const char* e = getenv("OCR_TAIL_UNFUSED");
-    fused_tail_ = !(e && e[0] == '1');
   }
   for (int l = 0; l < 4; ++l) {
     for (int b = 0; b < 2; ++b)
@@ -387,10 +410,7 @@ Detector::Detector(const void* blob, size_t bytes, int device) : device_(device)
     for (int l = 0; l < 3; ++l) all_convs_.push_back(&bin_up_[l]);
     all_convs_.push_back(&bin_p2_);
   }
-  {
-    const char* e = getenv("OCR_DET_PRECISION");
-    if (e && std::string(e) == "bf16") set_precision(1);
-  }
+  if (opt_bf16_) set_precision(1);
 }
 
 // f32 -> bf16, round to nearest even (NaN stays NaN)
@@ -691,7 +711,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     if (!bf && cw.wino_fused) {  // 64 -> 64: transforms fused into the GEMM kernel
       rec.begin();
       launch_winograd_fused(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
-                            relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, cs);
+                            relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
       const double px = (double)n * hh * ww;
       rec.end(cw.cin == 64 ? "winograd_fused<c64>" : cw.cin == 128 ? "winograd_fused<c128>" : "winograd_fused<c256>", 2.0 * 16.0 * (px / 4.0) * cw.cin * cw.cout,
               px * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 16.0 * cw.cin * cw.cout * 4);
@@ -908,7 +928,7 @@ const float* Detector::stage(int id, size_t* elems) const {
   if (id == 0) { *elems = px(2) * 64; return f(s_); }
   if (id >= 1 && id <= 4) { *elems = px(1 + id) * ((size_t)64 << (id - 1)); return f(x_[id - 1]); }
   if (id >= 5 && id <= 8 && !(id == 5 ? sum_[0] : i_[id - 5]))
-    fail(OCR_ERR_INVALID, "stage %d is not materialised by the composed FPN (OCR_FPN_UNFUSED=1 keeps it)", id);
+    fail(OCR_ERR_INVALID, "stage %d is not materialised by the composed FPN (option fpn_unfused=1 keeps it)", id);
   if (id == 5) { *elems = px(2) * 256; return f(sum_[0]); }  // in2 only exists inside its top-down sum
   if (id >= 6 && id <= 8) { *elems = px(id - 3) * 256; return f(i_[id - 5]); }
   if (id >= 9 && id <= 12) { *elems = px(id - 7) * 64; return f(p_[id - 9]); }

@@ -45,7 +45,8 @@ struct ConvW {
 
 class Detector {
  public:
-  Detector(const void* blob, size_t bytes, int device);
+  // options: "key=value;..." (include/ocr_amd.h, ocr_det_create_with_options) or null for the defaults
+  Detector(const void* blob, size_t bytes, int device, const char* options = nullptr);
   ~Detector();
   void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
   hipStream_t stream() const { return stream_; }
@@ -71,10 +72,13 @@ class Detector {
   void free_workspace();
   ConvW make_conv(const WeightBlob& wb, const std::string& wname, const std::string& bn, int cout, int cin, int ks);
 
+  void parse_options(const char* options);
   int device_;
+  int num_cus_ = 256;      // multiProcessorCount of the device: sizes the persistent grids
+  bool opt_bf16_ = false;  // option precision=bf16
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
   // Optional second stream (measured: no gain - the launches are MFMA / power bound).
-  // OCR_OVERLAP=1: the small independent launches side by side (the 1x1 s2 downsample next to its block's
+  // overlap=1: the small independent launches side by side (the 1x1 s2 downsample next to its block's
   // 3x3 s2 conv1, out5 next to in4 / out4); =2: also the FPN branch (p2, p3) next to layer3 / layer4.
   // forward_profile always runs one stream (clean per-launch timing).
   int overlap_ = 0;
@@ -98,7 +102,7 @@ class Detector {
   ConvW bin_up_[3], bin_p2_;
   // ... or all four terms in ONE launch (SRC_PYR4): per output phase (y mod 8, x mod 8) a weight row of 21 tap
   // slots (4 + 4 + 4 for p5, p4, p3 and 9 for p2) x 64 channels; partial sums stay in the accumulators.
-  // OCR_BIN_PYR=0 keeps the four-launch form.
+  // option bin_pyr=0 keeps the four-launch form.
   ConvW bin_pyr_;
   bool bin_pyr_on_ = true;
   ConvW finish_composed(std::vector<float>&& t, int cout, int cin, int ks);
@@ -106,17 +110,17 @@ class Detector {
   ConvW compose_upsampled(const ConvW& out, const ConvW& in_up);
   ConvW phase_conv(const std::vector<double>& taps, int cout, int cin, int up);
   bool fpn_composed_ = true;
-  // Winograd for 3x3 s1 trunk convs with Cin >= this (f32 precision only); OCR_WINOGRAD=0 disables, =<cin> overrides
+  // Winograd for 3x3 s1 trunk convs with Cin >= this (f32 precision only); option winograd=0 disables, =<cin> overrides
   int winograd_min_cin_ = 256;
   float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [16][T][C] and [16][T][K] scratch of the layer in flight
   void add_winograd_weights(ConvW& cw);
   void add_winograd_fused_weights(ConvW& cw);
-  bool winograd_fused_ = true;   // OCR_WINOGRAD_FUSED=0: direct convs for the 64 -> 64 layers  // OCR_FPN_UNFUSED=1: the layer-by-layer laterals / sums / out convs
+  bool winograd_fused_ = true;   // option winograd_fused=0: direct convs instead of the fused Winograd kernel
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;
   float* tr2_wt_ = nullptr;   // [64 co][4 u] for the fused head
-  bool fused_tail_ = true;    // OCR_TAIL_UNFUSED=1 keeps the two-kernel head (A/B and debugging)
+  bool fused_tail_ = true;    // option tail_unfused=1 keeps the two-kernel head (A/B and debugging)
   float tr2_bias_ = 0.f;
 
   bool bf16_ = false;

@@ -1,0 +1,340 @@
+// Test and tuning hooks (libocr_amd_test.so): NOT part of the drop-in surface and not in libocr_amd.so.  They reach
+// into the product library's internals (it exports its C++ symbols) so that kernels and host geometry can be pinned
+// one piece at a time: the host-geometry hooks need no GPU and pin the C++ geometry against the reference KATs.
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+
+#include "api_internal.hpp"
+
+using ocr::guard;
+using ocr::align256;
+
+extern "C" {
+
+int ocr_test_contour_candidates(const uint8_t* bitmap01, int h, int w, int32_t* xy_out, int32_t* counts_out,
+                                int max_pts, int max_polys, int* n_polys) {
+  return guard([&] {
+    std::vector<std::vector<ocr::geom::Pt>> cands;
+    ocr::geom::contour_candidates(bitmap01, h, w, cands);
+    int np = 0, used = 0;
+    for (const auto& c : cands) {
+      if (np >= max_polys || used + (int)c.size() > max_pts) ocr::fail(OCR_ERR_INVALID, "test buffer too small");
+      counts_out[np++] = (int)c.size();
+      for (const auto& p : c) {
+        xy_out[2 * used] = p.x;
+        xy_out[2 * used + 1] = p.y;
+        ++used;
+      }
+    }
+    *n_polys = np;
+  });
+}
+int ocr_test_expand_polygon(const int32_t* xy, int n, double factor, int32_t* xy_out, int max_out, int* n_out,
+                            double* sside_out) {
+  return guard([&] {
+    std::vector<ocr::geom::Pt> in(n), out;
+    for (int i = 0; i < n; ++i) in[i] = {xy[2 * i], xy[2 * i + 1]};
+    if (!ocr::geom::expand_polygon(in, factor, out)) {
+      *n_out = 0;
+      return;
+    }
+    if ((int)out.size() > max_out) ocr::fail(OCR_ERR_INVALID, "test buffer too small");
+    for (size_t i = 0; i < out.size(); ++i) {
+      xy_out[2 * i] = out[i].x;
+      xy_out[2 * i + 1] = out[i].y;
+    }
+    *n_out = (int)out.size();
+    ocr::geom::Pt box[4];
+    if (sside_out) *sside_out = ocr::geom::min_area_bounding_box(out, box);
+  });
+}
+int ocr_test_det_stage(ocr_det_t* det, int id, float* out_host, size_t capacity, size_t* elems) {
+  return guard([&] {
+    if (!det || !elems) ocr::fail(OCR_ERR_INVALID, "null argument");
+    const float* p = det->impl.stage(id, elems);
+    if (out_host) {
+      if (*elems > capacity) ocr::fail(OCR_ERR_INVALID, "stage %d needs %zu floats", id, *elems);
+      det->impl.synchronize();
+      OCR_HIP(hipMemcpy(out_host, p, *elems * sizeof(float), hipMemcpyDeviceToHost));
+    }
+  });
+}
+// raw GPU box scores of given polygons over a host map (sum and pixel count per polygon)
+int ocr_test_box_scores(ocr_det_t* det, const float* prob_host, int h, int w, const int32_t* xy, const int32_t* counts,
+                        int n_polys, double* sums_out, double* counts_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det) fail(OCR_ERR_INVALID, "null handle");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    std::vector<BoxScoreJob> jobs;
+    int pos = 0;
+    for (int k = 0; k < n_polys; ++k) {
+      int mnx = INT32_MAX, mxx = 0, mny = INT32_MAX, mxy = 0;
+      for (int i = 0; i < counts[k]; ++i) {
+        mnx = std::min(mnx, xy[2 * (pos + i)]);
+        mxx = std::max(mxx, xy[2 * (pos + i)]);
+        mny = std::min(mny, xy[2 * (pos + i) + 1]);
+        mxy = std::max(mxy, xy[2 * (pos + i) + 1]);
+      }
+      mnx = std::clamp(mnx, 0, h - 1);
+      mxx = std::clamp(mxx, 0, h - 1);
+      mny = std::clamp(mny, 0, w - 1);
+      mxy = std::clamp(mxy, 0, w - 1);
+      if (mxx >= w || mxy >= h || counts[k] > kBoxScoreMaxPts) fail(OCR_ERR_INVALID, "bad test polygon");
+      jobs.push_back({0, pos, counts[k], mnx, mny, mxx - mnx + 1, mxy - mny + 1});
+      pos += counts[k];
+    }
+    const size_t o_jobs = align256((size_t)h * w * 4), o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
+    const size_t o_sum = o_pts + align256((size_t)pos * 8), o_cnt = o_sum + align256((size_t)n_polys * 8);
+    char* sc = static_cast<char*>(det->impl.scratch(0, o_cnt + align256((size_t)n_polys * 8)));
+    OCR_HIP(hipMemcpyAsync(sc, prob_host, (size_t)h * w * 4, hipMemcpyHostToDevice, s));
+    OCR_HIP(hipMemcpyAsync(sc + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
+    OCR_HIP(hipMemcpyAsync(sc + o_pts, xy, (size_t)pos * 8, hipMemcpyHostToDevice, s));
+    launch_box_scores(reinterpret_cast<const float*>(sc), h, w, reinterpret_cast<const BoxScoreJob*>(sc + o_jobs),
+                      reinterpret_cast<const int32_t*>(sc + o_pts), n_polys, reinterpret_cast<double*>(sc + o_sum),
+                      reinterpret_cast<double*>(sc + o_cnt), s);
+    OCR_HIP(hipMemcpyAsync(sums_out, sc + o_sum, (size_t)n_polys * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipMemcpyAsync(counts_out, sc + o_cnt, (size_t)n_polys * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
+  });
+}
+// one conv_igemm launch on caller data (kernel-level parity hook).  All host arrays are f32; with in_bf16 /
+// out_bf16 they are rounded to bf16 (nearest even) on the way in and widened on the way out, so the caller
+// compares against a reference computed from the SAME rounded operands.  in: NHWC; cat4: the four pyramid
+// levels p5 (h/8), p4 (h/4), p3 (h/2), p2 (h) back to back, 64 channels each.  wgt: [cout][ks*ks][cin].
+int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in, int n, int h, int w, int cin,
+                      const float* wgt, int cout, int ks, int stride, const float* scale, const float* bias,
+                      const float* residual, const float* up_residual, int relu, int cat4, float* out, float* out2) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !in || !wgt) fail(OCR_ERR_INVALID, "null argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const int pad = (ks - 1) / 2;
+    const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
+    size_t lvl[4] = {0, 0, 0, 0};
+    size_t in_e = (size_t)n * h * w * cin;
+    if (cat4) {
+      if (cin != 256 || (h % 8) || (w % 8)) fail(OCR_ERR_INVALID, "cat4 needs cin 256 and h, w multiples of 8");
+      in_e = 0;
+      for (int l = 0; l < 4; ++l) {
+        lvl[l] = in_e;
+        in_e += (size_t)n * (h >> (3 - l)) * (w >> (3 - l)) * 64;
+      }
+    }
+    const size_t w_e = (size_t)cout * ks * ks * cin, out_e = (size_t)n * ho * wo * cout;
+    const size_t up_e = (size_t)n * (ho / 2) * (wo / 2) * cout;
+    auto bf16_bits = [](float f) {
+      uint32_t u;
+      std::memcpy(&u, &f, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    std::vector<void*> allocs;
+    auto up = [&](const float* src, size_t elems, bool bf) -> void* {
+      if (!src) return nullptr;
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, elems * (bf ? 2 : 4)));
+      allocs.push_back(d);
+      if (bf) {
+        std::vector<uint16_t> t(elems);
+        for (size_t i = 0; i < elems; ++i) t[i] = bf16_bits(src[i]);
+        OCR_HIP(hipMemcpy(d, t.data(), elems * 2, hipMemcpyHostToDevice));
+      } else {
+        OCR_HIP(hipMemcpy(d, src, elems * 4, hipMemcpyHostToDevice));
+      }
+      return d;
+    };
+    auto down = [&](float* dst, const void* dev, size_t elems, bool bf) {
+      if (!dst) return;
+      if (bf) {
+        std::vector<uint16_t> t(elems);
+        OCR_HIP(hipMemcpy(t.data(), dev, elems * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < elems; ++i) {
+          const uint32_t u = (uint32_t)t[i] << 16;
+          std::memcpy(&dst[i], &u, 4);
+        }
+      } else {
+        OCR_HIP(hipMemcpy(dst, dev, elems * 4, hipMemcpyDeviceToHost));
+      }
+    };
+    const size_t ies = in_bf16 ? 2 : 4, oes = out_bf16 ? 2 : 4;
+    char* d_in = static_cast<char*>(up(in, in_e, in_bf16));
+    ConvDesc d{};
+    d.in_bf16 = in_bf16 ? 1 : 0;
+    d.out_bf16 = out_bf16 ? 1 : 0;
+    d.src_mode = cat4 ? SRC_CAT4 : SRC_PLAIN;
+    d.src[0] = d_in;
+    if (cat4) {
+      for (int l = 0; l < 4; ++l) d.src[l] = d_in + lvl[l] * ies;
+      d.src_base = d_in;
+    }
+    d.src_bytes = in_e * ies;
+    d.wgt = up(wgt, w_e, in_bf16);
+    d.wgt_bytes = w_e * ies;
+    d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    d.ks = ks; d.stride = stride; d.pad = pad;
+    d.scale = static_cast<const float*>(up(scale, cout, false));
+    d.bias = static_cast<const float*>(up(bias, cout, false));
+    d.residual = up(residual, out_e, out_bf16);
+    d.up_residual = up(up_residual, up_e, out_bf16);
+    d.relu = relu; d.store_mode = STORE_NHWC; d.name = "test_conv";
+    void* d_out = nullptr;
+    void* d_out2 = nullptr;
+    if (out) { OCR_HIP(hipMalloc(&d_out, out_e * oes)); allocs.push_back(d_out); }
+    if (out2) { OCR_HIP(hipMalloc(&d_out2, out_e * oes)); allocs.push_back(d_out2); }
+    d.out = d_out;
+    d.out2 = d_out2;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    launch_conv_igemm(d, s);
+    OCR_HIP(hipStreamSynchronize(s));
+    down(out, d_out, out_e, out_bf16);
+    down(out2, d_out2, out_e, out_bf16);
+  });
+}
+// one 3x3 s1 p1 conv (+ scale / bias / residual / ReLU) through the Winograd F(2x2,3x3) path on caller data:
+// weight transform, input transform, batched 16-problem GEMM, output transform.  x: NHWC, wgt: [cout][9][cin].
+int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, int cin, const float* wgt, int cout,
+                           const float* scale, const float* bias, const float* residual, int relu, int unfused, float* out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !x || !wgt || !out) fail(OCR_ERR_INVALID, "null argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const size_t th = (h + 1) / 2, tw = (w + 1) / 2, T = (size_t)n * th * tw;
+    const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
+    const std::vector<float> u = winograd_weights(wgt, cout, cin);
+    std::vector<void*> allocs;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    auto dev = [&](const float* src, size_t elems) -> float* {
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, elems * 4));
+      allocs.push_back(d);
+      if (src) OCR_HIP(hipMemcpy(d, src, elems * 4, hipMemcpyHostToDevice));
+      return static_cast<float*>(d);
+    };
+    float* d_x = dev(x, in_e);
+    float* d_u = dev(u.data(), u.size());
+    float* d_v = dev(nullptr, 16 * T * cin);
+    float* d_m = dev(nullptr, 16 * T * cout);
+    float* d_y = dev(nullptr, out_e);
+    const float* d_sc = scale ? dev(scale, cout) : nullptr;
+    const float* d_bi = bias ? dev(bias, cout) : nullptr;
+    const float* d_res = residual ? dev(residual, out_e) : nullptr;
+    if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && !unfused) {  // the fused kernel
+      std::vector<float> un = u;
+      for (size_t i = (size_t)12 * cout * cin; i < un.size(); ++i) un[i] = -un[i];
+      float* d_un = dev(un.data(), un.size());
+      launch_winograd_fused(d_x, d_un, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
+      OCR_HIP(hipStreamSynchronize(s));
+      OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
+      return;
+    }
+    launch_winograd_input(d_x, d_v, n, h, w, cin, s);
+    ConvDesc d{};
+    d.src[0] = d_v;
+    d.src_mode = SRC_PLAIN;
+    d.src_bytes = 16 * T * cin * 4;
+    d.wgt = d_u;
+    d.wgt_bytes = u.size() * 4;
+    d.batch = 16;
+    d.N = 1; d.Hin = d.Ho = 1; d.Win = d.Wo = (int)T; d.Cin = cin; d.Cout = cout;
+    d.ks = 1; d.stride = 1; d.pad = 0; d.store_mode = STORE_NHWC; d.out = d_m; d.name = "test_winograd";
+    launch_conv_igemm(d, s);
+    launch_winograd_output(d_m, d_sc, d_bi, d_res, relu, d_y, n, h, w, cout, s);
+    OCR_HIP(hipStreamSynchronize(s));
+    OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
+  });
+}
+int ocr_test_set_conv_tile(int t) {
+  ocr::set_conv_tile_override(t);
+  return OCR_OK;
+}
+// micro-benchmark of one conv_igemm launch shape on constant data (kernel tuning aid)
+int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, int ks, int stride, int src_mode,
+                        int iters, float* ms_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det) fail(OCR_ERR_INVALID, "null handle");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const int pad = (ks - 1) / 2;
+    const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
+    const size_t in_e = (size_t)n * h * w * cin, w_e = (size_t)cout * ks * ks * cin, out_e = (size_t)n * ho * wo * cout;
+    float *in = nullptr, *wt = nullptr, *out = nullptr;
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&in), in_e * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&wt), w_e * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&out), out_e * 4));
+    OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(in), 0x3f8ccccd, in_e, s));   // 1.1f
+    OCR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wt), 0x3c23d70a, w_e, s));    // 0.01f
+    if (src_mode & 32) {  // random operands: MFMA power (and with it the clock) depends on the data
+      src_mode &= ~32;
+      std::vector<float> h(std::max(in_e, w_e));
+      uint32_t st = 12345u;
+      auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+      for (size_t i = 0; i < in_e; ++i) h[i] = rnd();
+      OCR_HIP(hipMemcpy(in, h.data(), in_e * 4, hipMemcpyHostToDevice));
+      for (size_t i = 0; i < w_e; ++i) h[i] = 0.05f * rnd();
+      OCR_HIP(hipMemcpy(wt, h.data(), w_e * 4, hipMemcpyHostToDevice));
+    }
+    ConvDesc d{};
+    d.src[0] = in;
+    d.src_mode = SRC_PLAIN;
+    const int bf = src_mode == 16 ? 1 : 0;  // src_mode 16: bf16 operands and output (the buffers are just reinterpreted)
+    d.in_bf16 = d.out_bf16 = bf;
+    d.src_bytes = in_e * (bf ? 2 : 4);
+    d.wgt_bytes = w_e * (bf ? 2 : 4); d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    d.ks = ks; d.stride = stride; d.pad = pad; d.wgt = wt; d.relu = 1; d.store_mode = STORE_NHWC; d.out = out;
+    d.name = "bench";
+    hipEvent_t e0, e1;
+    OCR_HIP(hipEventCreate(&e0));
+    OCR_HIP(hipEventCreate(&e1));
+    launch_conv_igemm(d, s);
+    OCR_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_conv_igemm(d, s);
+    OCR_HIP(hipEventRecord(e1, s));
+    OCR_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    OCR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(in);
+    (void)hipFree(wt);
+    (void)hipFree(out);
+  });
+}
+int ocr_test_min_area_box(const int32_t* xy, int n, int32_t* box_xy, double* sside) {
+  return guard([&] {
+    std::vector<ocr::geom::Pt> in(n);
+    for (int i = 0; i < n; ++i) in[i] = {xy[2 * i], xy[2 * i + 1]};
+    ocr::geom::Pt box[4];
+    *sside = ocr::geom::min_area_bounding_box(in, box);
+    for (int i = 0; i < 4; ++i) {
+      box_xy[2 * i] = box[i].x;
+      box_xy[2 * i + 1] = box[i].y;
+    }
+  });
+}
+
+// the result all-gather without RCCL: packs every shard as its rank would and assembles them as the receiver does
+int ocr_test_comm_assemble(const ocr_polygons_t* const* shards, int world, ocr_polygons_t** all) {
+  return guard([&] {
+    if (!shards || !all || world < 1) ocr::fail(OCR_ERR_INVALID, "null argument");
+    std::vector<std::vector<uint8_t>> packed;
+    std::vector<const uint8_t*> ptr;
+    std::vector<size_t> len;
+    for (int r = 0; r < world; ++r) {
+      packed.push_back(ocr::pack_shard(*shards[r]));
+      ptr.push_back(packed.back().data());
+      len.push_back(packed.back().size());
+    }
+    auto res = std::make_unique<ocr::PolygonsOwned>();
+    ocr::assemble_shards(ptr.data(), len.data(), world, *res);
+    *all = &res.release()->view;
+  });
+}
+
+}  // extern "C"

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 }  // namespace
 
 void launch_winograd_fused(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,
-                           int relu, float* y, int N, int H, int W, int C, int K, hipStream_t s) {
+                           int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s) {
   if (N <= 0 || H <= 0 || W <= 0 || (C != 64 && C != 128 && C != 256) || K % 64 || K <= 0)
     fail(OCR_ERR_INVALID, "winograd fused: bad shape N=%d H=%d W=%d C=%d K=%d", N, H, W, C, K);
   const long long bytes = (long long)N * H * W * C * 4;
@@ -338,11 +338,11 @@ void launch_winograd_fused(const float* x, const float* u_neg3, const float* sca
   const long long blocks = (long long)N * a.bh * a.bw * a.kblocks;
   if (blocks >= (1ll << 31)) fail(OCR_ERR_INVALID, "winograd fused: grid too large");
   a.nblocks = (int)blocks;
-  const unsigned grid = blocks > 512 ? 512u : (unsigned)blocks;  // 256 CUs x 2 resident workgroups
-  static const int extra_lds = getenv("OCR_WF_EXTRA_LDS") ? atoi(getenv("OCR_WF_EXTRA_LDS")) : 0;  // tuning knob: caps residency
-  if (C == 64) hipLaunchKernelGGL(winograd_fused_kernel<2>, dim3(grid), dim3(256), extra_lds, s, a);
-  else if (C == 128) hipLaunchKernelGGL(winograd_fused_kernel<4>, dim3(grid), dim3(256), extra_lds, s, a);
-  else hipLaunchKernelGGL(winograd_fused_kernel<8>, dim3(grid), dim3(256), extra_lds, s, a);
+  const long long resident = 2ll * (num_cus > 0 ? num_cus : 256);  // persistent: two workgroups per CU of THIS device
+  const unsigned grid = blocks > resident ? (unsigned)resident : (unsigned)blocks;
+  if (C == 64) hipLaunchKernelGGL(winograd_fused_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+  else if (C == 128) hipLaunchKernelGGL(winograd_fused_kernel<4>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(winograd_fused_kernel<8>, dim3(grid), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
 

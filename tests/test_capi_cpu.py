@@ -36,6 +36,18 @@ def test_header_symbols_exported():
     assert L.ocr_rec_alphabet().decode() == "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"
 
 
+def test_product_library_ships_no_test_hooks():
+    """The ocr_test_* hooks live in libocr_amd_test.so (on top of the product library), never in libocr_amd.so."""
+    import subprocess
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    prod = {n for n in exported(capi.LIB_PATH) if n.startswith("ocr_")}
+    assert prod == set(capi.EXPORTS)                                   # exactly the header's surface, nothing else
+    hooks = {n for n in exported(capi.TEST_LIB_PATH) if n.startswith("ocr_")}
+    assert hooks and all(n.startswith("ocr_test_") for n in hooks)
+
+
 def test_no_cpu_fallback_without_gpu():
     if capi.lib().ocr_device_count() > 0:
         pytest.skip("a GPU is visible")

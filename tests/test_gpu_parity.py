@@ -94,12 +94,10 @@ def test_det_other_weights_seed():
     d.close()
 
 
-def test_det_two_kernel_head_matches_fused_head(det_w, monkeypatch):
-    """OCR_TAIL_UNFUSED=1 keeps bin_conv_tr1 / bin_conv_tr2 as two launches; both heads must agree."""
+def test_det_two_kernel_head_matches_fused_head(det_w):
+    """Option tail_unfused=1 keeps bin_conv_tr1 / bin_conv_tr2 as two launches; both heads must agree."""
     x = W.synth_image_batch(12, 2, 64, 96)
-    monkeypatch.setenv("OCR_TAIL_UNFUSED", "1")
-    d2 = capi.Detector(W.pack_blob(det_w), 0)
-    monkeypatch.delenv("OCR_TAIL_UNFUSED")
+    d2 = capi.Detector(W.pack_blob(det_w), 0, options="tail_unfused=1")
     d1 = capi.Detector(W.pack_blob(det_w), 0)
     a, b = d1.forward_host(x), d2.forward_host(x)
     ref = T.det_forward(det_w, x)
@@ -325,7 +323,7 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     splits bin_conv1 over the concat into phase convs (DESIGN.md section 3).  Exact in real arithmetic;
     in f32 it re-associates sums, so it is held to the same bars as everything else: p2 / p3 and the
     bin_conv1 output against the oracle's activations, the map within TOL of the oracle and of the
-    layer-by-layer engine (OCR_FPN_UNFUSED=1)."""
+    layer-by-layer engine (option fpn_unfused=1)."""
     n, h, w = 2, 96, 160
     x = W.synth_image_batch(21, n, h, w)
     st = {}
@@ -339,8 +337,7 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     assert _rel(p3, fuse[:, 128:192, ::2, ::2]) < 2e-5
     assert _rel(b1, st["bin1"]) < 2e-5
     assert np.abs(prob - ref).max() < TOL
-    monkeypatch.setenv("OCR_FPN_UNFUSED", "1")
-    plain = capi.Detector(W.pack_blob(det_w), 0)
+    plain = capi.Detector(W.pack_blob(det_w), 0, options="fpn_unfused=1")
     try:
         prob_plain = plain.forward_host(x)
         sum2 = plain.debug_stage(5, (n, h // 4, w // 4, 256))     # only the layer-wise graph materialises it
@@ -354,27 +351,47 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
         det.debug_stage(5, (n, h // 4, w // 4, 256))
 
 
-@pytest.mark.parametrize("env", [
-    {"OCR_WINOGRAD_FUSED": "0"},                                   # direct convs on the large grids, unfused Winograd layer3/4
-    {"OCR_WINOGRAD": "0", "OCR_WINOGRAD_FUSED": "0"},             # no Winograd at all
-    {"OCR_BIN_PYR": "0"},                                         # bin_conv1 as four launches
-    {"OCR_FPN_UNFUSED": "1"},                                     # layer-by-layer FPN
-    {"OCR_FPN_UNFUSED": "1", "OCR_WINOGRAD": "0", "OCR_WINOGRAD_FUSED": "0", "OCR_TAIL_UNFUSED": "1"},  # the plain graph
-    {"OCR_OVERLAP": "1"}, {"OCR_OVERLAP": "2"},                   # second-stream schedules
-], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
-def test_engine_modes_agree(det, det_w, monkeypatch, env):
-    """Every graph-level option of the engine computes the same map: within 1e-5 of the
-    default engine and within TOL of the oracle.  The options are read when a detector is created."""
+@pytest.mark.parametrize("options", [
+    "winograd_fused=0",                                            # direct convs on the large grids, unfused Winograd layer3/4
+    "winograd=0;winograd_fused=0",                                 # no Winograd at all
+    "bin_pyr=0",                                                   # bin_conv1 as four launches
+    "fpn_unfused=1",                                               # layer-by-layer FPN
+    "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
+    "overlap=1", "overlap=2",                                      # second-stream schedules
+])
+def test_engine_modes_agree(det, det_w, options):
+    """Every graph-level option of the engine (ocr_det_create_with_options) computes the same
+    map: within 1e-5 of the default engine and within TOL of the oracle."""
     n, h, w = 2, 96, 160
     x = W.synth_image_batch(33, n, h, w)
     base = det.forward_host(x)
     ref = T.det_forward(det_w, x)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    other = capi.Detector(W.pack_blob(det_w), 0)
+    other = capi.Detector(W.pack_blob(det_w), 0, options=options)
     try:
         got = other.forward_host(x)
     finally:
         other.close()
     assert np.abs(got - base).max() < 1e-5
     assert np.abs(got - ref).max() < TOL
+
+
+def test_engine_options_are_explicit_and_checked(det_w, monkeypatch):
+    """The library never reads the environment (a maintainer's shell cannot silently select another engine); unknown
+    or malformed options are errors."""
+    x = W.synth_image_batch(8, 1, 64, 64)
+    base = capi.Detector(W.pack_blob(det_w), 0)
+    want = base.forward_host(x)
+    base.close()
+    for k, v in (("OCR_WINOGRAD_FUSED", "0"), ("OCR_FPN_UNFUSED", "1"), ("OCR_DET_PRECISION", "bf16"), ("OCR_TAIL_UNFUSED", "1")):
+        monkeypatch.setenv(k, v)
+    d = capi.Detector(W.pack_blob(det_w), 0)
+    assert np.array_equal(d.forward_host(x), want)      # bit for bit the default engine
+    d.close()
+    b16 = capi.Detector(W.pack_blob(det_w), 0, options="precision=bf16")
+    assert not np.array_equal(b16.forward_host(x), want)
+    b16.close()
+    for bad in ("winograd_fused", "no_such_option=1", "precision=fp8", "overlap=x"):
+        with pytest.raises(capi.OcrError) as e:
+            capi.Detector(W.pack_blob(det_w), 0, options=bad)
+        assert e.value.code == 1
+

@@ -30,8 +30,8 @@ for lab, n, h, w, ci, co, ks, st in shapes:
         if t == 1 and co % 128:
             cells.append(f"{'-':>16s}")
             continue
-        capi.lib().ocr_test_set_conv_tile(t)
+        capi.test_lib().ocr_test_set_conv_tile(t)
         ms = det.debug_conv_bench(n, h, w, ci, co, ks, st, 16 if bf else 0, 10)
         cells.append(f"{ms:7.4f}ms {fl / ms / 1e9:6.1f}")
     print(f"{lab:26s} " + " ".join(cells))
-capi.lib().ocr_test_set_conv_tile(0)
+capi.test_lib().ocr_test_set_conv_tile(0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch timing of one detector forward (HIP events around every launch).
-usage: python tools/profile_layers.py [batch] [size] [reps] [tile override]"""
+usage: python tools/profile_layers.py [batch] [size] [reps] [tile override or 0] [engine options, e.g. precision=bf16]"""
 import os
 import sys
 
@@ -14,9 +14,9 @@ from ocr_rs_amd import capi, weights as W  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 s = int(sys.argv[2]) if len(sys.argv) > 2 else 640
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)
-if len(sys.argv) > 4:
-    capi.lib().ocr_test_set_conv_tile(int(sys.argv[4]))   # tuning aid: force a conv_igemm tile (1, 2, 3)
+det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0, options=sys.argv[5] if len(sys.argv) > 5 else None)
+if len(sys.argv) > 4 and int(sys.argv[4]):
+    capi.test_lib().ocr_test_set_conv_tile(int(sys.argv[4]))   # tuning aid: force a conv_igemm tile (1, 2, 3)
 x = torch.from_numpy(W.synth_image_batch(1, n, s, s)).cuda()
 prob = torch.empty_like(x)
 torch.cuda.synchronize()
