@@ -62,6 +62,7 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  * the environment: which schedule runs is the caller's choice.  Every combination computes the same graph and is
  * held to the same parity bars (tests/test_gpu_parity.py::test_engine_modes_agree); they exist for A/B measurements.
  *   winograd_fused=0|1   (1)    fused Winograd F(2x2,3x3) kernel for the 3x3 s1 convs of the large grids
+ *   winograd_ws=0|1      (0)    the wave-specialised form of that kernel (multiplier waves fed by helper waves)
  *   winograd=<cin>|0     (256)  unfused Winograd for 3x3 s1 trunk convs with Cin >= cin that have no fused form; 0 = off
  *   fpn_unfused=0|1      (0)    1 = layer-by-layer FPN (laterals, top-down sums, out_k, gathered bin_conv1) as model.rs writes it
  *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)

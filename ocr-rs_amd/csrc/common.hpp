@@ -100,6 +100,11 @@ void launch_winograd_output(const float* m, const float* scale, const float* bia
 // channels, K a multiple of 64.  u_neg3: winograd weights [16][K][C] with the components of row i = 3 (12..15) negated.
 void launch_winograd_fused(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,
                            int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
+// The wave-specialised form of the same conv (winograd_ws.hip): multiplier waves fed by helper waves through LDS.
+// ufrag: winograd_ws_fragments(winograd_weights(...)) - no negated components.
+std::vector<float> winograd_ws_fragments(const std::vector<float>& u, int cout, int cin);
+void launch_winograd_ws(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual, int relu,
+                        float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
 // tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);

@@ -137,6 +137,11 @@ void Detector::add_winograd_weights(ConvW& cw) {
 void Detector::add_winograd_fused_weights(ConvW& cw) {
   if ((cw.cin != 64 && cw.cin != 128 && cw.cin != 256) || cw.cout % 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd: unsupported conv shape");
   std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin);
+  if (winograd_ws_) {
+    cw.wino_ws = arena_.upload(winograd_ws_fragments(u, cw.cout, cw.cin));
+    cw.wino_fused = cw.wino_ws;  // "has a fused form": the schedule tests this pointer
+    return;
+  }
   for (size_t i = (size_t)12 * cw.cout * cw.cin; i < u.size(); ++i) u[i] = -u[i];  // row i = 3 enters the output transform negated
   cw.wino_fused = arena_.upload(u);
 }
@@ -210,6 +215,7 @@ void Detector::parse_options(const char* options) {
       return (int)v;
     };
     if (key == "winograd_fused") winograd_fused_ = num() != 0;
+    else if (key == "winograd_ws") winograd_ws_ = num() != 0;
     else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
@@ -710,10 +716,15 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
                      bool relu = true) {
     if (!bf && cw.wino_fused) {  // 64 -> 64: transforms fused into the GEMM kernel
       rec.begin();
-      launch_winograd_fused(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
-                            relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
+      if (cw.wino_ws)
+        launch_winograd_ws(static_cast<const float*>(src), cw.wino_ws, cw.scale, cw.bias, static_cast<const float*>(residual),
+                           relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
+      else
+        launch_winograd_fused(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
+                              relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
       const double px = (double)n * hh * ww;
-      rec.end(cw.cin == 64 ? "winograd_fused<c64>" : cw.cin == 128 ? "winograd_fused<c128>" : "winograd_fused<c256>", 2.0 * 16.0 * (px / 4.0) * cw.cin * cw.cout,
+      rec.end(cw.wino_ws ? (cw.cin == 64 ? "winograd_ws<c64>" : cw.cin == 128 ? "winograd_ws<c128>" : "winograd_ws<c256>")
+                         : (cw.cin == 64 ? "winograd_fused<c64>" : cw.cin == 128 ? "winograd_fused<c128>" : "winograd_fused<c256>"), 2.0 * 16.0 * (px / 4.0) * cw.cin * cw.cout,
               px * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 16.0 * cw.cin * cw.cout * 4);
       return;
     }

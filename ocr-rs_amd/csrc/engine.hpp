@@ -37,6 +37,7 @@ struct ConvW {
   float* wino = nullptr;   // Winograd F(2x2,3x3) weights U = G g G^T as [16][Cout][Cin] (3x3 s1 convs of the deep layers)
   size_t wino_bytes = 0;
   float* wino_fused = nullptr;  // 64 -> 64 convs: the same with components 12..15 negated (winograd_fused.hip)
+  float* wino_ws = nullptr;     // ... or as MFMA B fragments for the wave-specialised kernel (winograd_ws.hip)
   int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
@@ -115,6 +116,7 @@ class Detector {
   float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [16][T][C] and [16][T][K] scratch of the layer in flight
   void add_winograd_weights(ConvW& cw);
   void add_winograd_fused_weights(ConvW& cw);
+  bool winograd_ws_ = false;     // option winograd_ws=1: the wave-specialised fused Winograd kernel instead of winograd_fused
   bool winograd_fused_ = true;   // option winograd_fused=0: direct convs instead of the fused Winograd kernel
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;

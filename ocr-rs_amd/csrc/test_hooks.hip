@@ -9,6 +9,9 @@
 
 using ocr::guard;
 using ocr::align256;
+#ifdef WS_STAMPS
+namespace ocr { void winograd_ws_read_stamps(long long* out); }
+#endif
 
 extern "C" {
 
@@ -223,6 +226,13 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     const float* d_sc = scale ? dev(scale, cout) : nullptr;
     const float* d_bi = bias ? dev(bias, cout) : nullptr;
     const float* d_res = residual ? dev(residual, out_e) : nullptr;
+    if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && unfused == 2) {  // the wave-specialised fused kernel
+      float* d_uf = dev(winograd_ws_fragments(u, cout, cin).data(), u.size());
+      launch_winograd_ws(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
+      OCR_HIP(hipStreamSynchronize(s));
+      OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
+      return;
+    }
     if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && !unfused) {  // the fused kernel
       std::vector<float> un = u;
       for (size_t i = (size_t)12 * cout * cin; i < un.size(); ++i) un[i] = -un[i];
@@ -336,5 +346,9 @@ int ocr_test_comm_assemble(const ocr_polygons_t* const* shards, int world, ocr_p
     *all = &res.release()->view;
   });
 }
+
+#ifdef WS_STAMPS
+int ocr_test_ws_stamps(long long* out) { ocr::winograd_ws_read_stamps(out); return 0; }
+#endif
 
 }  // extern "C"

@@ -158,3 +158,28 @@ def test_winograd_conv_matches_aten(det, case):
     got = det.debug_winograd_conv(x, wg, scale, bias, res, relu)
     ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
     _check(got, ref, False)
+
+
+WS_CASES = [c for c in WINO_CASES if c[3] in (64, 128, 256) and c[4] % 64 == 0] + [
+    (1, 40, 40, 256, 64, False, False, False),   # out4 (256 -> 64): eight channel chunks
+    (2, 24, 48, 256, 256, True, True, True),     # layer3-like, four output-channel blocks share a patch
+    (5, 8, 16, 64, 64, True, True, True),        # fewer blocks than workgroups
+    (1, 64, 272, 64, 64, True, True, False),     # many blocks per image row, several per workgroup on a small grid
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_winograd_ws_conv_matches_aten(det, case):
+    """The wave-specialised fused Winograd kernel (winograd_ws.hip: multiplier waves fed by helper waves) against
+    ATen's direct conv2d on the same operands, same bar as the other Winograd forms."""
+    n, h, w, cin, cout, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:5]) & 0xFFFF)
+    x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
+    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, h, w, cout), dtype=np.float32) if has_res else None
+    got = det.debug_winograd_conv(x, wg, scale, bias, res, relu, unfused=2)
+    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
+    _check(got, ref, False)
+
