@@ -385,20 +385,20 @@ def main():
         adj = np.ones((n, 2))
         torch.cuda.synchronize()
         polys, scores = det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
-        reps = 3
+        reps = 5
         t1 = time.perf_counter()
-        for _ in range(reps):
-            det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
+        for _ in range(reps):   # the library call (ocr_det_postprocess), not the conversion of its CSR block to Python lists
+            det.postprocess_counts(pm, n, s, s, adj, capi.MEM_DEVICE, params)
         post = {"postprocess_images_per_s": round(n * reps / (time.perf_counter() - t1), 1),
                 "postprocess_polygons_per_image": round(sum(len(p) for p in polys) / n, 2)}
         if rank == 0 and not a.no_extras:
             dm = torch.from_numpy(dense_text_maps(n, s, 5)).to(x.device)
-            dp, _ = det.postprocess(dm, n, s, s, adj, capi.MEM_DEVICE, params)
+            npoly, _ = det.postprocess_counts(dm, n, s, s, adj, capi.MEM_DEVICE, params)
             t1 = time.perf_counter()
             for _ in range(reps):
-                det.postprocess(dm, n, s, s, adj, capi.MEM_DEVICE, params)
+                det.postprocess_counts(dm, n, s, s, adj, capi.MEM_DEVICE, params)
             post["postprocess_dense_images_per_s"] = round(n * reps / (time.perf_counter() - t1), 1)
-            post["postprocess_dense_polygons_per_image"] = round(sum(len(p) for p in dp) / n, 2)
+            post["postprocess_dense_polygons_per_image"] = round(npoly / n, 2)
     except Exception as e:  # side numbers never hide the headline
         post["postprocess_error"] = f"{type(e).__name__}: {e}"
         polys = None
@@ -453,6 +453,38 @@ def main():
                          "detect_postprocess_gather_images_per_s": round(n * world * k / e2e, 1),
                          "detect_postprocess_gather_note": "per step and rank: forward of its 32 frames, get_boxes_and_box_scores over 32 "
                                                            "text-like maps, all-gather of the polygon lists; sequential on one stream"})
+
+    # ---- detection END TO END on one GPU: forward + get_boxes_and_box_scores of the forward's own maps, software-
+    # pipelined inside the library (ocr_det_detect_pipelined).  Random weights give noise maps, so this leg runs the
+    # text-following synthetic weights on synthetic pages (weights.make_det_weights_text / synth_text_pages): same graph,
+    # same kernels, maps with ~20 word polygons per page.
+    if rank == 0 and not a.no_extras and a.dtype == "f32":
+        try:
+            dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local)
+            dt.set_stream(stream.cuda_stream)
+            pages, boxes = W.synth_text_pages(77, n, s, s)
+            xp = torch.from_numpy(pages).to(x.device)
+            pr2 = [torch.empty_like(xp), torch.empty_like(xp)]
+            adj1 = np.ones((n, 2))
+            params = capi.default_params(skip_degenerate=True)
+            torch.cuda.synchronize()
+            k, found = max(6, a.steps // 2), 0
+            for it in range(2):                      # warm-up, then timed
+                t1 = time.perf_counter()
+                for j in range(k):
+                    r = dt.detect_pipelined(xp.data_ptr(), n, s, s, pr2[j & 1].data_ptr(), adj1, params, convert=False)
+                    found += r[0] if (r and it) else 0
+                r = dt.detect_pipelined(0, 0, 0, 0, 0, convert=False)
+                found += r[0] if it else 0
+                torch.cuda.synchronize()
+                e2e = time.perf_counter() - t1
+            post["detect_postprocess_pipelined_images_per_s"] = round(n * k / e2e, 1)
+            post["detect_postprocess_pipelined_polygons_per_image"] = round(found / (n * k), 2)
+            post["detect_postprocess_pipelined_note"] = ("ocr_det_detect_pipelined: forward of batch k+1 overlapped with binarize + contours + "
+                                                         "box scores + unclip of batch k; text-following synthetic weights and pages")
+            dt.close()
+        except Exception as e:
+            post["detect_postprocess_pipelined_error"] = f"{type(e).__name__}: {e}"
 
     extras = {}
     rec_w = W.make_rec_weights(0)

@@ -167,6 +167,15 @@ int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, 
                         ocr_polygons_t** out);
 void ocr_polygons_free(ocr_polygons_t* p);
 
+/* forward_t + get_boxes_and_box_scores over a STREAM of batches, software-pipelined inside the library: the call
+ * enqueues the forward of THIS batch (device pointers; x_dev N x 1 x H x W f32 -> prob_dev, which must stay untouched
+ * until the next call has returned) and, while the GPU runs it, post-processes the batch handed in by the PREVIOUS call
+ * - its host geometry on the handle's thread pool, its kernels and copies on a second stream.  *prev_out receives that
+ * previous batch's polygons (NULL on the first call).  Finish with x_dev = NULL: nothing is enqueued, the last
+ * batch's polygons come back.  Results are exactly those of ocr_det_forward + ocr_det_postprocess per batch. */
+int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, int w, float* prob_dev,
+                             const double* adj_xy, const ocr_postproc_params_t* params, ocr_polygons_t** prev_out);
+
 /* Detect -> recognise link (BUILD-DEFINED: the reference never implemented its "Character
  * Segmentation" step, README.md:20-26, so there is no reference rule to match).  For every polygon
  * of `polys` (as returned by ocr_det_postprocess for the same batch) the axis-aligned bounding box,

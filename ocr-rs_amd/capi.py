@@ -24,7 +24,7 @@ EXPORTS = [
     "ocr_varstore_to_blob", "ocr_blob_free", "ocr_det_create_from_varstore", "ocr_rec_create_from_varstore",
     "ocr_det_create", "ocr_det_create_with_options", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
-    "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_polygons_free",
+    "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_det_detect_pipelined", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet",
@@ -94,6 +94,9 @@ def lib() -> C.CDLL:
         L.ocr_det_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(PostprocParams),
                                           C.POINTER(C.POINTER(Polygons))]
+        L.ocr_det_detect_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.POINTER(C.c_double), C.POINTER(PostprocParams),
+                                               C.POINTER(C.POINTER(Polygons))]
         L.ocr_polygons_free.argtypes = [C.POINTER(Polygons)]
         L.ocr_polygons_free.restype = None
         L.ocr_evaluate_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -172,15 +175,13 @@ def _ptr(a) -> int:
 def polygons_to_python(pp) -> Tuple[List[List[List[Tuple[int, int]]]], List[List[float]]]:
     """CSR block -> PolygonScores{polygons: Vec<MultiPolygon<u32>>, scores: Vec<Vec<f64>>}."""
     p = pp.contents
-    polys, scores = [], []
-    for b in range(p.n_images):
-        ip, isc = [], []
-        for k in range(p.img_offsets[b], p.img_offsets[b + 1]):
-            v0, v1 = p.poly_offsets[k], p.poly_offsets[k + 1]
-            ip.append([(int(p.xy[2 * v]), int(p.xy[2 * v + 1])) for v in range(v0, v1)])
-            isc.append(float(p.scores[k]))
-        polys.append(ip)
-        scores.append(isc)
+    ni, npoly, nv = p.n_images, p.n_polygons, p.n_vertices
+    img = np.ctypeslib.as_array(p.img_offsets, shape=(ni + 1,)).tolist()
+    po = np.ctypeslib.as_array(p.poly_offsets, shape=(npoly + 1,)).tolist() if npoly else [0]
+    pts = list(map(tuple, np.ctypeslib.as_array(p.xy, shape=(2 * nv,)).reshape(-1, 2).tolist())) if nv else []
+    sc = np.ctypeslib.as_array(p.scores, shape=(npoly,)).tolist() if npoly else []
+    polys = [[pts[po[k]:po[k + 1]] for k in range(img[b], img[b + 1])] for b in range(ni)]
+    scores = [sc[img[b]:img[b + 1]] for b in range(ni)]
     return polys, scores
 
 
@@ -372,6 +373,38 @@ class Detector:
         check(test_lib().ocr_test_box_scores(self._h, _ptr(pred), h, w, _ptr(xy), _ptr(cnt), len(polys), _ptr(sums),
                                         _ptr(counts)))
         return sums, counts
+
+    def detect_pipelined(self, x_ptr: int, n: int, h: int, w: int, prob_ptr: int, adjust_values=None,
+                         params: Optional[PostprocParams] = None, convert: bool = True):
+        """ocr_det_detect_pipelined: enqueue this batch's forward, get the PREVIOUS batch's polygons (None on the first
+        call); x_ptr = 0 flushes.  convert=False returns (n_polygons, n_vertices) instead of Python lists."""
+        adj_p = None
+        if x_ptr:
+            adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+            adj_p = adj.ctypes.data_as(C.POINTER(C.c_double))
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_detect_pipelined(self._h, x_ptr or None, n, h, w, prob_ptr or None, adj_p,
+                                             C.byref(params) if params is not None else None, C.byref(out)))
+        if not out:
+            return None
+        try:
+            return polygons_to_python(out) if convert else (out.contents.n_polygons, out.contents.n_vertices)
+        finally:
+            lib().ocr_polygons_free(out)
+
+    def postprocess_counts(self, prob, n: int, h: int, w: int, adjust_values: np.ndarray, mem_kind: int = MEM_HOST,
+                           params: Optional[PostprocParams] = None) -> Tuple[int, int]:
+        """get_boxes_and_box_scores without turning the CSR block into Python objects: (polygons, vertices).
+        What a benchmark times when it wants the library, not the harness."""
+        adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_postprocess(self._h, _ptr(prob), n, h, w, mem_kind,
+                                        adj.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(params) if params is not None else None, C.byref(out)))
+        try:
+            return out.contents.n_polygons, out.contents.n_vertices
+        finally:
+            lib().ocr_polygons_free(out)
 
     def postprocess(self, prob, n: int, h: int, w: int, adjust_values: np.ndarray, mem_kind: int = MEM_HOST,
                     params: Optional[PostprocParams] = None):

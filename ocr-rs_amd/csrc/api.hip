@@ -1,12 +1,14 @@
 // extern "C" boundary (include/ocr_amd.h).  Nothing throws across it.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
 
 
 #include "api_internal.hpp"
+#include "thread_pool.hpp"
 
 namespace ocr {
 thread_local std::string g_last_error;
@@ -17,54 +19,52 @@ using ocr::guard;
 using ocr::PolygonsOwned;
 using ocr::align256;
 
-// get_boxes_and_box_scores (metrics.rs:37-56) over the whole batch.
+// get_boxes_and_box_scores (metrics.rs:37-56) over the whole batch.  Dense, regular work on the GPU (binarisation into
+// a packed bit image, box scores), irregular work on the detector's host thread pool, one image per task.
 void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
-                 const ocr_postproc_params_t& prm, ocr_polygons_t** out) {
+                 const ocr_postproc_params_t& prm, ocr_polygons_t** out, hipStream_t s) {
   using namespace ocr;
+#ifdef POSTPROC_TIMING
+  auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double T0 = tnow();
+  double T1 = 0, T2 = 0, T3 = 0;
+#endif
   if (!prob || !adj || !out) fail(OCR_ERR_INVALID, "det_postprocess: null argument");
   if (n <= 0 || h <= 0 || w <= 0) fail(OCR_ERR_INVALID, "det_postprocess: bad shape");
   OCR_HIP(hipSetDevice(det.device()));
-  hipStream_t s = det.stream();
-  const size_t px = (size_t)n * h * w;
-  // scratch: [prob copy if host] [bitmap]
-  const size_t off_bitmap = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
-  char* scratch = static_cast<char*>(det.scratch(0, off_bitmap + align256(px)));
+  const size_t hw = (size_t)h * w, px = (size_t)n * hw;
+  const size_t wpi = binarize_pack_words(hw);  // 32-bit words per packed image
+  // scratch: [prob copy if host] [packed bitmaps]
+  const size_t off_bits = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
+  char* scratch = static_cast<char*>(det.scratch(0, off_bits + align256((size_t)n * wpi * 4)));
   const float* prob_dev = prob;
   if (mem_kind == OCR_MEM_HOST) {
     OCR_HIP(hipMemcpyAsync(scratch, prob, px * 4, hipMemcpyHostToDevice, s));
     prob_dev = reinterpret_cast<const float*>(scratch);
   }
-  uint8_t* bitmap_dev = reinterpret_cast<uint8_t*>(scratch + off_bitmap);
-  launch_binarize(prob_dev, bitmap_dev, (float)prm.thresh, px, s);  // metrics.rs:41,129
-  std::vector<uint8_t> bitmap(px);
-  OCR_HIP(hipMemcpyAsync(bitmap.data(), bitmap_dev, px, hipMemcpyDeviceToHost, s));
+  uint32_t* bits_dev = reinterpret_cast<uint32_t*>(scratch + off_bits);
+  launch_binarize_pack(prob_dev, bits_dev, (float)prm.thresh, n, hw, s);  // metrics.rs:41,129
+  std::vector<uint32_t> bits((size_t)n * wpi);
+  OCR_HIP(hipMemcpyAsync(bits.data(), bits_dev, bits.size() * 4, hipMemcpyDeviceToHost, s));
   OCR_HIP(hipStreamSynchronize(s));
+#ifdef POSTPROC_TIMING
+  T1 = tnow();
+#endif
 
-  // contour tracing + Douglas-Peucker on host threads, one image at a time per thread
+  // contour tracing + Douglas-Peucker (metrics.rs:78-98)
+  ThreadPool& pool = det.pool();
   std::vector<std::vector<std::vector<geom::Pt>>> cands(n);
-  {
-    std::atomic<int> next{0};
-    std::string err;
-    std::atomic<bool> failed{false};
-    auto work = [&]() {
-      try {
-        for (int b = next++; b < n; b = next++) geom::contour_candidates(bitmap.data() + (size_t)b * h * w, h, w, cands[b]);
-      } catch (const std::exception& e) {
-        if (!failed.exchange(true)) err = e.what();
-      }
-    };
-    const int nt = std::max(1, std::min<int>(n, (int)std::thread::hardware_concurrency()));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
-    if (failed) fail(OCR_ERR_INTERNAL, "contour stage: %s", err.c_str());
-  }
+  pool.parallel_for(n, [&](int b) { geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]); });
+#ifdef POSTPROC_TIMING
+  T2 = tnow();
+#endif
 
   // box scores on the GPU (metrics.rs:99 -> :150-184)
   std::vector<BoxScoreJob> jobs;
   std::vector<int32_t> pts;
-  for (int b = 0; b < n; ++b)
+  std::vector<int> first_job(n + 1, 0);
+  for (int b = 0; b < n; ++b) {
+    first_job[b] = (int)jobs.size();
     for (const auto& c : cands[b]) {
       if ((int)c.size() > kBoxScoreMaxPts) fail(OCR_ERR_INVALID, "polygon with %zu vertices exceeds %d", c.size(), kBoxScoreMaxPts);
       int mnx = INT32_MAX, mxx = 0, mny = INT32_MAX, mxy = 0;
@@ -88,6 +88,8 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
         pts.push_back(p.y);
       }
     }
+  }
+  first_job[n] = (int)jobs.size();
   const int nj = (int)jobs.size();
   std::vector<double> sums(nj), counts(nj);
   if (nj > 0) {
@@ -106,25 +108,46 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     OCR_HIP(hipMemcpyAsync(counts.data(), scratch + o_cnt, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
     OCR_HIP(hipStreamSynchronize(s));
   }
+#ifdef POSTPROC_TIMING
+  T3 = tnow();
+#endif
 
-  // unclip + filters + coordinate adjustment (metrics.rs:100-123), assemble the CSR block
-  auto res = std::make_unique<PolygonsOwned>();
-  res->img_offsets.push_back(0);
-  res->poly_offsets.push_back(0);
-  int j = 0;
-  for (int b = 0; b < n; ++b) {
+  // unclip + filters + coordinate adjustment (metrics.rs:100-123) per image on the pool, then the CSR block in image order
+  struct PerImage {
+    std::vector<uint32_t> xy;
+    std::vector<int32_t> lens;
+    std::vector<double> scores;
+  };
+  std::vector<PerImage> per(n);
+  pool.parallel_for(n, [&](int b) {
+    PerImage& r = per[b];
+    int j = first_job[b];
     for (const auto& c : cands[b]) {
       const double score = sums[j] / counts[j];
       ++j;
-      if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, res->xy)) {
-        res->poly_offsets.push_back((int32_t)(res->xy.size() / 2));
-        res->scores.push_back(score);
+      const size_t before = r.xy.size();
+      if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, r.xy)) {
+        r.lens.push_back((int32_t)((r.xy.size() - before) / 2));
+        r.scores.push_back(score);
       }
     }
+  });
+  auto res = std::make_unique<PolygonsOwned>();
+  res->img_offsets.push_back(0);
+  res->poly_offsets.push_back(0);
+  for (int b = 0; b < n; ++b) {
+    const PerImage& r = per[b];
+    res->xy.insert(res->xy.end(), r.xy.begin(), r.xy.end());
+    for (int32_t L : r.lens) res->poly_offsets.push_back(res->poly_offsets.back() + L);
+    res->scores.insert(res->scores.end(), r.scores.begin(), r.scores.end());
     res->img_offsets.push_back((int32_t)res->scores.size());
   }
   res->finish();
   *out = &res.release()->view;
+#ifdef POSTPROC_TIMING
+  fprintf(stderr, "postprocess n=%d: binarize+copy %.3f ms, contours %.3f ms, box scores (%d) %.3f ms, finish %.3f ms\n", n, T1 - T0, T2 - T1,
+          nj, T3 - T2, tnow() - T3);
+#endif
 }
 }  // namespace
 
@@ -364,7 +387,39 @@ int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, 
     ocr_postproc_default_params(&prm);
     if (params) prm = *params;
     if (out) *out = nullptr;
-    postprocess(det->impl, prob, n, h, w, mem_kind, adj, prm, out);
+    postprocess(det->impl, prob, n, h, w, mem_kind, adj, prm, out, det->impl.stream());
+  });
+}
+
+int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, int w, float* prob_dev, const double* adj_xy,
+                             const ocr_postproc_params_t* params, ocr_polygons_t** prev_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !prev_out) fail(OCR_ERR_INVALID, "detect_pipelined: null argument");
+    *prev_out = nullptr;
+    Detector& d = det->impl;
+    OCR_HIP(hipSetDevice(d.device()));
+    Detector::Pending next;
+    if (x_dev) {
+      if (!prob_dev || !adj_xy) fail(OCR_ERR_INVALID, "detect_pipelined: null tensor");
+      d.forward(x_dev, n, h, w, prob_dev, nullptr, 0.f, nullptr);   // enqueue: runs while the previous batch is post-processed
+      next.prob = prob_dev;
+      next.n = n;
+      next.h = h;
+      next.w = w;
+      next.adj.assign(adj_xy, adj_xy + 2 * (size_t)n);
+      ocr_postproc_default_params(&next.params);
+      if (params) next.params = *params;
+      next.event = d.pipeline_event();
+      OCR_HIP(hipEventRecord(next.event, d.stream()));
+      next.valid = true;
+    }
+    Detector::Pending prev = d.swap_pending(next);
+    if (prev.valid) {
+      hipStream_t ps = d.post_stream();
+      OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
+    }
   });
 }
 

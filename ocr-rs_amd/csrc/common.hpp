@@ -113,6 +113,10 @@ void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, floa
 void launch_tail_fused(const void* y, const void* wt1, int bf16, const float* s4, const float* b4, const float* w2t, float bias2,
                        float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s);
 void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n, hipStream_t s);
+// the same as one bit per pixel, every image packed on its own (bit i & 31 of word i >> 5 for its pixel i, padded to
+// binarize_pack_words(px) 32-bit words): what the host contour tracer reads
+size_t binarize_pack_words(size_t px_per_image);
+void launch_binarize_pack(const float* prob, uint32_t* bits, float thresh, int n_images, size_t px_per_image, hipStream_t s);
 
 // preprocess_image (image_ops.rs:188-220): Triangle resize + luma + zero pad, preprocess.hip
 void resize_dimensions(int width, int height, int nwidth, int nheight, int* ow, int* oh);

@@ -5,6 +5,10 @@
 // to per-channel scale/bias); activations live in NHWC f32 workspaces in HBM.
 #include "engine.hpp"
 
+#include <thread>
+
+#include "thread_pool.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -472,12 +476,38 @@ Detector::~Detector() {
     (void)hipEventDestroy(ev_fork_);
     (void)hipEventDestroy(ev_join_);
   }
+  if (post_stream_) {
+    (void)hipStreamSynchronize(post_stream_);
+    (void)hipStreamDestroy(post_stream_);
+  }
+  for (hipEvent_t ev : pipe_ev_)
+    if (ev) (void)hipEventDestroy(ev);
   free_workspace();
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
   if (stage_in_) (void)hipFree(stage_in_);
   if (stage_out_) (void)hipFree(stage_out_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+ThreadPool& Detector::pool() {
+  if (!pool_) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    pool_ = std::make_unique<ThreadPool>((int)std::min(15u, hc > 1 ? hc - 1 : 0u));  // + the calling thread
+  }
+  return *pool_;
+}
+
+hipStream_t Detector::post_stream() {
+  if (!post_stream_) OCR_HIP(hipStreamCreateWithFlags(&post_stream_, hipStreamNonBlocking));
+  return post_stream_;
+}
+
+hipEvent_t Detector::pipeline_event() {
+  hipEvent_t& e = pipe_ev_[pipe_ev_next_];
+  pipe_ev_next_ ^= 1;
+  if (!e) OCR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
 }
 
 void Detector::synchronize() {

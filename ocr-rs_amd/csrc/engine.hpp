@@ -3,10 +3,14 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "common.hpp"
 #include "weights_blob.hpp"
 
 namespace ocr {
+
+class ThreadPool;
 
 struct ProfileEntry {
   const char* name;
@@ -64,6 +68,24 @@ class Detector {
   // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
+  // host threads of the post-processing stages (created on first use, one image per task)
+  ThreadPool& pool();
+  // ocr_det_detect_pipelined: the batch whose forward is in flight and whose post-processing is still owed
+  struct Pending {
+    bool valid = false;
+    const float* prob = nullptr;
+    int n = 0, h = 0, w = 0;
+    std::vector<double> adj;
+    ocr_postproc_params_t params{};
+    hipEvent_t event = nullptr;
+  };
+  Pending swap_pending(Pending& next) {
+    Pending prev = std::move(pending_);
+    pending_ = std::move(next);
+    return prev;
+  }
+  hipStream_t post_stream();     // second stream: post-processing kernels and copies next to the following forward
+  hipEvent_t pipeline_event();   // alternating pair of events marking the end of a pipelined forward
   // test hook: NHWC intermediate of the last forward (0 stem, 1-4 layer1-4, 5-8 in2-5,
   // 9-12 p2-p5 (before upsampling), 13 bin_conv1, 14 bin_conv_tr1)
   const float* stage(int id, size_t* elems) const;
@@ -138,6 +160,11 @@ class Detector {
   size_t pcat_bytes_ = 0;
   void forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                      std::vector<ProfileEntry>* prof);
+  std::unique_ptr<ThreadPool> pool_;
+  Pending pending_;
+  hipStream_t post_stream_ = nullptr;
+  hipEvent_t pipe_ev_[2] = {nullptr, nullptr};
+  int pipe_ev_next_ = 0;
   void* scratch_[2] = {nullptr, nullptr};
   size_t scratch_bytes_[2] = {0, 0};
   float *stage_in_ = nullptr, *stage_out_ = nullptr;

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <map>
+#include <new>
 #include <tuple>
 
 namespace ocr {
@@ -37,65 +38,115 @@ static inline int dir_index(int dx, int dy) {
   return -1;
 }
 
-void find_contours(const uint8_t* bitmap, int h, int w, std::vector<std::vector<Pt>>& out) {
+// The working grid of the algorithm (0 background, 1 foreground, +-id once a border has passed) is kept as the
+// immutable foreground BIT image plus a label array that only border pixels ever touch: value(x, y) = fg ? (label ?
+// label : 1) : 0.  A pixel can only start a border at the first or last pixel of a horizontal foreground run (its
+// left resp. right neighbour must be zero), so the raster scan walks run boundaries found with word-wide bit tricks
+// instead of testing every pixel - the cost is O(runs + border pixels), not O(H W).
+// bits: row-major, bit (x & 31) of word (y * w + x) >> 5 (w is a multiple of 32 on the product path; any w works).
+void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& out) {
   out.clear();
-  std::vector<int32_t> v((size_t)h * w);
-  for (size_t i = 0; i < v.size(); ++i) v[i] = bitmap[i] ? 1 : 0;
-  auto nz = [&](int x, int y) { return x >= 0 && x < w && y >= 0 && y < h && v[(size_t)y * w + x] != 0; };
+  const size_t npx = (size_t)h * w;
+  int32_t* lab = static_cast<int32_t*>(std::calloc(npx ? npx : 1, sizeof(int32_t)));  // lazily zeroed pages
+  if (!lab) throw std::bad_alloc();
+  struct Free { int32_t* p; ~Free() { std::free(p); } } free_lab{lab};
+  auto fg = [&](size_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; };
+  auto nz = [&](int x, int y) { return x >= 0 && x < w && y >= 0 && y < h && fg((size_t)y * w + x); };
   int border = 1;
-  for (int y = 0; y < h; ++y) {
-    int32_t* row = &v[(size_t)y * w];
-    for (int x = 0; x < w; ++x) {
-      if (row[x] == 0) continue;
-      int adjx;
-      if (row[x] == 1 && x > 0 && row[x - 1] == 0) adjx = x - 1;           // outer border start
-      else if (row[x] > 0 && x + 1 < w && row[x + 1] == 0) adjx = x + 1;   // hole border start
-      else continue;
-      ++border;
-      std::vector<Pt> pts;
-      const int start = dir_index(adjx - x, 0);
-      int p1x = 0, p1y = 0;
-      bool found = false;
-      for (int k = 0; k < 8 && !found; ++k) {  // clockwise from the adjacent zero pixel
-        const int d = (start + k) & 7;
-        if (nz(x + kDx[d], y + kDy[d])) {
-          p1x = x + kDx[d];
-          p1y = y + kDy[d];
-          found = true;
-        }
+  auto trace = [&](int x, int y, int adjx) {
+    ++border;
+    std::vector<Pt> pts;
+    const int start = dir_index(adjx - x, 0);
+    int p1x = 0, p1y = 0;
+    bool found = false;
+    for (int k = 0; k < 8 && !found; ++k) {  // clockwise from the adjacent zero pixel
+      const int d = (start + k) & 7;
+      if (nz(x + kDx[d], y + kDy[d])) {
+        p1x = x + kDx[d];
+        p1y = y + kDy[d];
+        found = true;
       }
-      if (!found) {
-        pts.push_back({x, y});
-        row[x] = -border;
-      } else {
-        int p2x = p1x, p2y = p1y, p3x = x, p3y = y;
-        for (;;) {
-          pts.push_back({p3x, p3y});
-          const int base = dir_index(p2x - p3x, p2y - p3y);
-          int p4x = 0, p4y = 0;
-          bool right_edge = false;
-          for (int k = 1; k <= 8; ++k) {  // counter-clockwise, starting just after dir(p2)
-            const int d = (base - k) & 7;
-            if (nz(p3x + kDx[d], p3y + kDy[d])) {
-              p4x = p3x + kDx[d];
-              p4y = p3y + kDy[d];
-              break;
-            }
-            if (d == 4) right_edge = true;  // the E neighbour was examined and is zero
+    }
+    if (!found) {
+      pts.push_back({x, y});
+      lab[(size_t)y * w + x] = -border;
+    } else {
+      int p2x = p1x, p2y = p1y, p3x = x, p3y = y;
+      for (;;) {
+        pts.push_back({p3x, p3y});
+        const int base = dir_index(p2x - p3x, p2y - p3y);
+        int p4x = 0, p4y = 0;
+        bool right_edge = false;
+        for (int k = 1; k <= 8; ++k) {  // counter-clockwise, starting just after dir(p2)
+          const int d = (base - k) & 7;
+          if (nz(p3x + kDx[d], p3y + kDy[d])) {
+            p4x = p3x + kDx[d];
+            p4y = p3y + kDy[d];
+            break;
           }
-          int32_t& cell = v[(size_t)p3y * w + p3x];
-          if (p3x + 1 == w || right_edge) cell = -border;
-          else if (cell == 1) cell = border;
-          if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
-          p2x = p3x;
-          p2y = p3y;
-          p3x = p4x;
-          p3y = p4y;
+          if (d == 4) right_edge = true;  // the E neighbour was examined and is zero
         }
+        int32_t& cell = lab[(size_t)p3y * w + p3x];
+        if (p3x + 1 == w || right_edge) cell = -border;
+        else if (cell == 0) cell = border;
+        if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
+        p2x = p3x;
+        p2y = p3y;
+        p3x = p4x;
+        p3y = p4y;
       }
-      out.push_back(std::move(pts));
+    }
+    out.push_back(std::move(pts));
+  };
+  // one pixel of the raster scan: outer border start if value == 1 and the W neighbour is 0 (x > 0), else hole border
+  // start if value > 0 and the E neighbour is 0 (x + 1 < w)
+  auto visit = [&](int x, int y) {
+    const size_t i = (size_t)y * w + x;
+    const int32_t l = lab[i];
+    if (l == 0 && x > 0 && !fg(i - 1)) trace(x, y, x - 1);
+    else if (l >= 0 && x + 1 < w && !fg(i + 1)) trace(x, y, x + 1);
+  };
+  for (int y = 0; y < h; ++y) {
+    const size_t r0 = (size_t)y * w;
+    int x = 0;
+    while (x < w) {
+      // next foreground pixel at or after x
+      size_t i = r0 + x;
+      const size_t rend = r0 + w;
+      unsigned cur = bits[i >> 5] >> (i & 31);
+      while (!cur) {
+        i = ((i >> 5) + 1) << 5;
+        if (i >= rend) break;
+        cur = bits[i >> 5];
+      }
+      if (i >= rend) break;
+      i += __builtin_ctz(cur);
+      if (i >= rend) break;
+      const int x0 = (int)(i - r0);
+      // end of this run: last foreground pixel before the next zero (or the row end)
+      size_t j = i;
+      unsigned inv = ~bits[j >> 5] >> (j & 31);   // set bits = zero pixels from j on (the shift fills with "no zero here")
+      while (!inv) {
+        j = ((j >> 5) + 1) << 5;
+        if (j >= rend) break;
+        inv = ~bits[j >> 5];
+      }
+      size_t z = j >= rend ? rend : j + __builtin_ctz(inv);  // first zero pixel after the run
+      if (z > rend) z = rend;
+      const int x1 = (int)(z - r0) - 1;
+      visit(x0, y);
+      if (x1 != x0) visit(x1, y);
+      x = x1 + 1;
     }
   }
+}
+
+void find_contours(const uint8_t* bitmap, int h, int w, std::vector<std::vector<Pt>>& out) {
+  const size_t npx = (size_t)h * w;
+  std::vector<uint32_t> bits((npx + 31) / 32 + 1, 0u);
+  for (size_t i = 0; i < npx; ++i)
+    if (bitmap[i]) bits[i >> 5] |= 1u << (i & 31);
+  find_contours_bits(bits.data(), h, w, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -543,10 +594,22 @@ bool expand_polygon(const std::vector<Pt>& pts, double factor, std::vector<Pt>& 
 // ---------------------------------------------------------------------------
 // per-image driver, split around the GPU box-score step
 // ---------------------------------------------------------------------------
+static void candidates_of(const std::vector<std::vector<Pt>>& contours, std::vector<std::vector<Pt>>& cands);
+
 void contour_candidates(const uint8_t* bitmap, int h, int w, std::vector<std::vector<Pt>>& cands) {
-  cands.clear();
   std::vector<std::vector<Pt>> contours;
   find_contours(bitmap, h, w, contours);
+  candidates_of(contours, cands);
+}
+
+void contour_candidates_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& cands) {
+  std::vector<std::vector<Pt>> contours;
+  find_contours_bits(bits, h, w, contours);
+  candidates_of(contours, cands);
+}
+
+static void candidates_of(const std::vector<std::vector<Pt>>& contours, std::vector<std::vector<Pt>>& cands) {
+  cands.clear();
   std::vector<Pt> pts;
   for (const auto& c : contours) {
     double eps = 0.01 * arc_length(c, true);  // metrics.rs:87-90

@@ -20,6 +20,8 @@ struct DegeneratePolygon : std::runtime_error {
 };
 
 void find_contours(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& out);
+// the same on a packed image: bit (i & 31) of word i >> 5 for the row-major pixel index i = y * w + x
+void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& out);
 double arc_length(const std::vector<Pt>& p, bool closed);
 void approximate_polygon_dp(const std::vector<Pt>& curve, double eps, bool closed, std::vector<Pt>& out);
 double min_area_bounding_box(const std::vector<Pt>& pts, Pt res[4]);
@@ -42,6 +44,7 @@ void combine_results(const MetricsItem* r, int n, double* precision, double* rec
 
 // contours -> Douglas-Peucker polygons with >= 4 points (metrics.rs:78-98)
 void contour_candidates(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& cands);
+void contour_candidates_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& cands);
 // score threshold, unclip, min-size filter, round(p/adj) as u32 (metrics.rs:100-123).
 // Appends x,y pairs to xy_out and returns true when the polygon is kept.
 bool finish_polygon(const std::vector<Pt>& cand, double score, double adj_x, double adj_y,

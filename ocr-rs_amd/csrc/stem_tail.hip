@@ -283,7 +283,34 @@ __global__ __launch_bounds__(256) void binarize_kernel(const float* __restrict__
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bitmap[i] = prob[i] > thresh ? 1 : 0;
 }
 
+// binarize(pred, thresh) (metrics.rs:129-131) as a packed image for the host contour tracer: bit (i & 31) of word
+// i >> 5 for the row-major pixel index i; one 64-bit ballot per wave = two words, 5 bytes per pixel moved instead of 8
+// Image blockIdx.y is packed on its own (its first pixel is bit 0 of its first word), padded to whole 64-bit words.
+__global__ __launch_bounds__(256) void binarize_pack_kernel(const float* __restrict__ prob, unsigned long long* __restrict__ bits64,
+                                                            float thresh, size_t px_per_image, size_t words64_per_image) {
+  const float* img = prob + (size_t)blockIdx.y * px_per_image;
+  unsigned long long* out = bits64 + (size_t)blockIdx.y * words64_per_image;
+  const size_t n64 = words64_per_image * 64, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += stride) {  // whole waves: every lane reaches the ballot
+    const unsigned long long b = __ballot(i < px_per_image && img[i] > thresh);
+    if ((threadIdx.x & 63) == 0) out[i >> 6] = b;
+  }
+}
+
 }  // namespace
+
+size_t binarize_pack_words(size_t px_per_image) { return (px_per_image + 63) / 64 * 2; }
+
+void launch_binarize_pack(const float* prob, uint32_t* bits, float thresh, int n_images, size_t px_per_image, hipStream_t s) {
+  if (n_images <= 0 || px_per_image == 0) return;
+  if (n_images > 65535) fail(OCR_ERR_INVALID, "binarize_pack: %d images in one call", n_images);
+  const size_t w64 = (px_per_image + 63) / 64;
+  size_t blocks = (w64 * 64 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(binarize_pack_kernel, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, s, prob,
+                     reinterpret_cast<unsigned long long*>(bits), thresh, px_per_image, w64);
+  OCR_HIP(hipGetLastError());
+}
 
 void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias, void* out, int out_bf16, int N,
                  int H, int W, hipStream_t s) {

@@ -167,3 +167,23 @@ def test_cpp_host_mirror_compiles_and_reports_errors(tmp_path):
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
     else:
         assert r.returncode == 0 and "classified as" in r.stdout
+
+
+@pytest.mark.parametrize("h,w,density,seed", [(37, 45, 0.55, 1), (64, 64, 0.5, 2), (9, 131, 0.6, 3), (50, 33, 0.35, 4),
+                                              (1, 70, 0.5, 5), (70, 1, 0.5, 6), (40, 96, 0.97, 7)])
+def test_run_based_border_following_matches_the_oracle_on_noise(h, w, density, seed):
+    """The product's tracer walks horizontal runs of a packed bit image instead of testing every pixel; on noise
+    (holes inside blobs, blobs touching every edge, widths that are no multiple of 32) it must report exactly the
+    borders the per-pixel Suzuki-Abe restatement of the oracle reports, in the same order."""
+    rng = np.random.RandomState(seed)
+    bm = (rng.rand(h, w) < density).astype(np.uint8)
+    got = capi.host_contour_candidates(bm)
+    want = []   # the oracle's pieces: contours -> DP (epsilon 1 % of the closed arc length) -> >= 4 points
+    for c in O.find_contours(bm):
+        eps = 0.01 * O.arc_length(c, True)
+        pts = O.approximate_polygon_dp(c, eps if eps != 0.0 else 0.01, True)
+        if len(pts) > 1 and pts[0] == pts[-1]:
+            pts = pts[:-1]
+        if len(pts) >= 4:
+            want.append([(int(p[0]), int(p[1])) for p in pts])
+    assert got == want

@@ -162,3 +162,28 @@ def test_config4_128_pages_bf16_properties(det_w, rec_w):
         assert np.array_equal(one[4], labels[offs[i]:offs[i + 1]])
     det.close()
     rec.close()
+
+
+def test_pipelined_detection_equals_batch_by_batch(det_w):
+    """ocr_det_detect_pipelined overlaps the post-processing of batch k with the forward of batch k + 1 (second stream,
+    host thread pool); what it returns must be exactly forward + get_boxes_and_box_scores of each batch, in order."""
+    import torch
+    det = capi.Detector(W.pack_blob(det_w), 0)
+    params = capi.default_params(skip_degenerate=True)
+    batches = [W.synth_text_pages(900 + b, 3 + b, S, S)[0] for b in range(4)]     # ragged batch sizes 3, 4, 5, 6
+    want = []
+    for fr in batches:
+        prob = det.forward_host(fr)
+        want.append(det.postprocess(prob, fr.shape[0], S, S, np.ones((fr.shape[0], 2)), capi.MEM_HOST, params))
+    xs = [torch.from_numpy(fr).cuda() for fr in batches]
+    probs = [torch.empty_like(x) for x in xs]
+    torch.cuda.synchronize()
+    got = []
+    for x, pr in zip(xs, probs):
+        r = det.detect_pipelined(x.data_ptr(), x.shape[0], S, S, pr.data_ptr(), np.ones((x.shape[0], 2)), params)
+        got.append(r)
+    got.append(det.detect_pipelined(0, 0, 0, 0, 0))            # flush: the last batch
+    assert got[0] is None and det.detect_pipelined(0, 0, 0, 0, 0) is None   # nothing pending any more
+    assert got[1:] == want
+    assert all(sum(len(p) for p in polys) > 0 for polys, _ in want)
+    det.close()
