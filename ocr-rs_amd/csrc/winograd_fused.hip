@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
   // start of every second one to de-phase the pairs did not help.  A variant with 16-channel chunks (44 KB of LDS,
   // a second V buffer per wave so that the next transform overlaps the MFMAs, three workgroups per CU at 168
   // VGPRs) was 25 % slower: twice the steps, half the MFMA burst per step, register spills.
+  // epilogue items of this thread (k = 0, 1: tile = (k * 256 + tid) >> 4, four output channels): position inside a
+  // block and element offset from the block's origin, computed once - per block only a scalar base and the bounds
+  // checks remain (integer multiplies are slow, and every VALU instruction is time taken from the matrix stream)
+  int ep_y[2], ep_x[2], ep_off[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = k * 256 + tid;
+    const int tile = item >> 4, c4 = (item & 15) * 4;
+    ep_y[k] = 2 * (tile >> 3);
+    ep_x[k] = 2 * (tile & 7);
+    ep_off[k] = (ep_y[k] * p.W + ep_x[k]) * p.K + c4;
+  }
+  const int row_el = p.W * p.K;  // elements per image row
   bool patch_in_flight = false;  // chunk 0 of this block's patch was requested during the previous block
   for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
   // block -> (image, pixel block, output-channel block); innermost kb: the K / 64 workgroups of a pixel block share
@@ -138,13 +151,14 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) xoff[g] = ((2 * g + half) ^ fsw) * 16;
 
-  f32x16 z0[2], z1[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) z0[nt][e] = z1[nt][e] = 0.f;
+  // M_iw accumulated per component row i over all channel chunks; the row step of the output transform
+  // (Z_w[0] = M_0w + M_1w + M_2w, Z_w[1] = M_1w - M_2w - M_3w; i = 3 is stored negated) is applied once per block.
+  // On gfx950 the f32-input MFMA runs on the vector ALU, so every VALU instruction is time taken from the matrix
+  // stream (tools/probes/mfma_valu_coissue.hip): adding a temporary into z0 / z1 after every i = 1, 2 step cost 64
+  // v_add per step, this costs 128 per block.
+  f32x16 m4[4][2];  // started by the first chunk's MFMAs from a constant-zero C operand: no zeroing instructions
 
-  auto gemm = [&](f32x16 (&acc)[2]) {
+  auto gemm = [&](f32x16 (&acc)[2], bool first) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 af = *reinterpret_cast<const f32x4*>(vbuf + frow * 128 + xoff[g]);
@@ -154,7 +168,10 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[nt][e], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x16 zero = {};
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[nt][e], (first && g == 0 && e == 0) ? zero : acc[nt], 0, 0, 0);
+        }
     }
   };
 
@@ -219,24 +236,7 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
           patch_in_flight = true;
         }
       }
-      if (i == 0) {
-        gemm(z0);
-      } else if (i == 3) {
-        gemm(z1);  // weights negated on the host: z1 -= M_3w
-      } else {
-        f32x16 t[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) t[nt][e] = 0.f;
-        gemm(t);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          z0[nt] += t[nt];
-          if (i == 1) z1[nt] += t[nt];
-          else z1[nt] -= t[nt];
-        }
-      }
+      gemm(m4[i], hc == 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of U / V has returned
       if (4 * hc + i + 1 < 4 * NCH) issue_u(4 * hc + i + 1);  // the buffer is free: the next step's weights fly
     }
@@ -258,19 +258,18 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int tile = (e & 3) + 8 * (e >> 2) + 4 * half, co = nt * 32 + frow;
-        zb[(wave * 32 + tile) * ZROW + co] = a == 0 ? z0[nt][e] : z1[nt][e];
+        zb[(wave * 32 + tile) * ZROW + co] = a == 0 ? m4[0][nt][e] + m4[1][nt][e] + m4[2][nt][e] : m4[1][nt][e] - m4[2][nt][e] + m4[3][nt][e];
       }
+    const size_t blk_el = (((size_t)n * p.H + y0) * p.W + x0) * p.K + kb * 64;  // wave-uniform: scalar arithmetic
     if (a == 0 && p.residual) {
       // residual rows of this thread's epilogue items (tile, 4 couts): in flight during the exchange
+      const float* rbase = p.residual + blk_el;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int item = k * 256 + tid;
-        const int tile = item >> 4, c4 = (item & 15) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int yy = y0 + 2 * (tile >> 3) + (q >> 1), xx = x0 + 2 * (tile & 7) + (q & 1);
-          if (yy < p.H && xx < p.W)
-            res[k][q] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4);
+          if (y0 + ep_y[k] + (q >> 1) < p.H && x0 + ep_x[k] + (q & 1) < p.W)
+            res[k][q] = *reinterpret_cast<const f32x4*>(rbase + ep_off[k] + (q >> 1) * row_el + (q & 1) * p.K);
         }
       }
     }
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
     for (int k = 0; k < 2; ++k) {
       const int item = k * 256 + tid;
       const int tile = item >> 4, c4 = (item & 15) * 4;
-      const int ty = tile >> 3, tx = tile & 7;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
       if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + kb * 64 + c4);
@@ -288,19 +286,17 @@ __global__ __launch_bounds__(256, 2) void winograd_fused_kernel(WfArgs p) {
       for (int w = 0; w < 4; ++w) z[w] = *reinterpret_cast<const f32x4*>(&zb[(w * 32 + tile) * ZROW + c4]);
       const f32x4 o0 = z[0] + z[1] + z[2];
       const f32x4 o1 = z[1] - z[2] - z[3];
-      const int yy = y0 + 2 * ty + a;
-      if (yy >= p.H) continue;
+      if (y0 + ep_y[k] + a >= p.H) continue;
+      float* ybase = p.y + blk_el;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int xx = x0 + 2 * tx + q;
-        if (xx >= p.W) continue;
-        const size_t o = (((size_t)n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4;
+        if (x0 + ep_x[k] + q >= p.W) continue;
         f32x4 val = (q ? o1 : o0) * sc + bi + res[k][2 * a + q];
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
         }
-        *reinterpret_cast<f32x4*>(p.y + o) = val;
+        *reinterpret_cast<f32x4*>(ybase + ep_off[k] + a * row_el + q * p.K) = val;
       }
     }
   }
