@@ -150,7 +150,7 @@ def test_lib() -> C.CDLL:
                                           C.c_void_p, C.c_void_p]
         L.ocr_test_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.POINTER(C.c_float)]
         L.ocr_test_conv_run.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] +
-                                        [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2)
+                                        [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 2)
         L.ocr_test_set_conv_tile.argtypes = [C.c_int]
         L.ocr_test_winograd_conv.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int] +
                                              [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p])
@@ -329,7 +329,7 @@ class Detector:
         return ms.value
 
     def debug_conv_run(self, x_nhwc, wgt_ohwi, stride=1, scale=None, bias=None, residual=None, up_residual=None,
-                       relu=False, cat4_shape=None, in_bf16=False, out_bf16=False, want_out=True, want_out2=False):
+                       relu=False, cat4_shape=None, in_bf16=False, out_bf16=False, want_out=True, want_out2=False, variant=0):
         """One conv_igemm launch on caller data (test hook).  x_nhwc: N x H x W x Cin f32, or with
         cat4_shape=(n, h, w) the flat concatenation p5|p4|p3|p2.  Returns (out, out2) as N x Ho x Wo x Cout f32."""
         f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
@@ -344,8 +344,8 @@ class Detector:
         sc, bi, rs, ur = f(scale), f(bias), f(residual), f(up_residual)
         p = lambda a: None if a is None else _ptr(a)
         check(test_lib().ocr_test_conv_run(self._h, int(in_bf16), int(out_bf16), _ptr(x), n, h, w, cin, _ptr(wg), cout, ks,
-                                      stride, p(sc), p(bi), p(rs), p(ur), int(relu), int(bool(cat4_shape)),
-                                      p(out), p(out2)))
+                                           stride, p(sc), p(bi), p(rs), p(ur), int(relu), int(bool(cat4_shape)), int(variant),
+                                           p(out), p(out2)))
         return out, out2
 
     def debug_winograd_conv(self, x_nhwc, wgt_ohwi, scale=None, bias=None, residual=None, relu=False, unfused=False):

@@ -90,6 +90,11 @@ void launch_stem(const float* x, const float* w49x64, const float* scale, const 
 std::vector<uint16_t> stem_bf16_fragments(const float* w64x49);
 void launch_stem_bf16(const float* x, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
                       hipStream_t s);
+// bf16 precision: 3x3 s1 p1 conv 64 -> 64 with the input patch staged once in LDS and register-resident weights
+// (conv3x3_bf16_c64.hip); wfrag from conv3x3_bf16_c64_fragments([Cout 64][9][Cin 64] f32)
+std::vector<uint16_t> conv3x3_bf16_c64_fragments(const float* ohwi);
+void launch_conv3x3_bf16_c64(const void* x, const void* wfrag, const float* scale, const float* bias, const void* residual, int relu,
+                             void* y, int N, int H, int W, int num_cus, hipStream_t s);
 // Winograd F(2x2, 3x3) transforms around a batched 16-problem GEMM (winograd.hip): 3x3 s1 p1 convs of the deep,
 // small-grid layers.  x: [N][H][W][C] f32 -> v: [16][T][C], T = N * ceil(H/2) * ceil(W/2) tiles (zero padding
 // and odd sizes handled here); m: [16][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.

@@ -448,6 +448,10 @@ void Detector::set_precision(int precision) {
       tr1_.w_bf16 = upload_bf16(t1.data(), t1.size());
     }
     for (ConvW* cw : all_convs_) {
+      if (cw->ks == 3 && cw->cin == 64 && cw->cout == 64 && !cw->w_bf16_c64 && !cw->host.empty()) {
+        const std::vector<uint16_t> fr = conv3x3_bf16_c64_fragments(cw->host.data());
+        cw->w_bf16_c64 = upload_bf16(fr.data(), fr.size());
+      }
       if (cw->w_bf16) continue;
       std::vector<float> packed((cw->host.size() + 1) / 2);
       uint16_t* h = reinterpret_cast<uint16_t*>(packed.data());
@@ -758,6 +762,13 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
               px * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 16.0 * cw.cin * cw.cout * 4);
       return;
     }
+    if (bf && cw.w_bf16_c64 && (long long)n * hh * ww * 128 < (1ll << 31)) {  // bf16 64 -> 64: patch staged once, weights in registers
+      rec.begin();
+      launch_conv3x3_bf16_c64(src, cw.w_bf16_c64, cw.scale, cw.bias, residual, relu ? 1 : 0, out, n, hh, ww, num_cus_, cs);
+      const double px = (double)n * hh * ww;
+      rec.end("conv3x3_bf16_c64", 2.0 * px * 64 * 576, px * 2.0 * 64 * (residual ? 3.0 : 2.0) + 9.0 * 64 * 64 * 2);
+      return;
+    }
     const size_t th = (hh + 1) / 2, tw = (ww + 1) / 2, T = (size_t)n * th * tw;
     if (bf || !cw.wino || !wino_v_ || 16 * T * std::max(cw.cin, cw.cout) * 4 >= ((size_t)1 << 31)) {
       Extra ex;
@@ -804,7 +815,7 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     Extra up;
     up.store = STORE_PHASE;
     conv("fpn.upsampled", fpn_b_[lv], x_[lv + 1], h >> (3 + lv), w >> (3 + lv), 1, p_[lv], false, up);
-    if (fpn_a_[lv].wino_fused && !bf) {
+    if ((fpn_a_[lv].wino_fused && !bf) || (bf && fpn_a_[lv].w_bf16_c64)) {
       conv3x3("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), p_[lv], p_[lv], false);
     } else {
       Extra lat;

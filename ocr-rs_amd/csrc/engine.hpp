@@ -36,6 +36,7 @@ struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
   size_t w_bytes = 0;
   void* w_bf16 = nullptr;  // same layout in bf16 (filled by Detector::set_precision)
+  void* w_bf16_c64 = nullptr;  // 3x3 64 -> 64 convs: bf16 MFMA fragments for conv3x3_bf16_c64.hip
   std::vector<float> host; // the f32 layout, kept for the bf16 conversion
   std::vector<float> host_scale;  // folded batch norm scale (empty: none), kept for weight composition
   float* wino = nullptr;   // Winograd F(2x2,3x3) weights U = G g G^T as [16][Cout][Cin] (3x3 s1 convs of the deep layers)

@@ -109,7 +109,7 @@ int ocr_test_box_scores(ocr_det_t* det, const float* prob_host, int h, int w, co
 // levels p5 (h/8), p4 (h/4), p3 (h/2), p2 (h) back to back, 64 channels each.  wgt: [cout][ks*ks][cin].
 int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in, int n, int h, int w, int cin,
                       const float* wgt, int cout, int ks, int stride, const float* scale, const float* bias,
-                      const float* residual, const float* up_residual, int relu, int cat4, float* out, float* out2) {
+                      const float* residual, const float* up_residual, int relu, int cat4, int variant, float* out, float* out2) {
   return guard([&] {
     using namespace ocr;
     if (!det || !in || !wgt) fail(OCR_ERR_INVALID, "null argument");
@@ -191,6 +191,19 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
     d.out = d_out;
     d.out2 = d_out2;
     struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    if (variant == 1) {  // conv3x3_bf16_c64.hip instead of conv_igemm
+      if (!in_bf16 || !out_bf16 || ks != 3 || stride != 1 || cin != 64 || cout != 64 || cat4 || out2 || !out)
+        fail(OCR_ERR_INVALID, "variant 1 is the bf16 3x3 s1 64 -> 64 kernel");
+      const std::vector<uint16_t> fr = conv3x3_bf16_c64_fragments(wgt);
+      void* d_fr = nullptr;
+      OCR_HIP(hipMalloc(&d_fr, fr.size() * 2));
+      allocs.push_back(d_fr);
+      OCR_HIP(hipMemcpy(d_fr, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+      launch_conv3x3_bf16_c64(d_in, d_fr, d.scale, d.bias, d.residual, relu, d_out, n, h, w, 256, s);
+      OCR_HIP(hipStreamSynchronize(s));
+      down(out, d_out, out_e, true);
+      return;
+    }
     launch_conv_igemm(d, s);
     OCR_HIP(hipStreamSynchronize(s));
     down(out, d_out, out_e, out_bf16);

@@ -183,3 +183,21 @@ def test_winograd_ws_conv_matches_aten(det, case):
     ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
     _check(got, ref, False)
 
+
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 9, 21), (3, 1, 1), (2, 160, 160), (1, 8, 16), (5, 24, 40), (1, 64, 272)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("has_res,relu,bn", [(True, True, True), (False, False, False), (True, False, True)])
+def test_bf16_c64_patch_conv_matches_aten(det, shape, has_res, relu, bn):
+    """conv3x3_bf16_c64.hip (bf16 3x3 s1 64 -> 64: patch staged once, weights in registers) against ATen on the same
+    bf16-rounded operands: at most one bf16 ulp, like every other bf16 kernel."""
+    n, h, w = shape
+    rng = np.random.default_rng(hash(shape) & 0xFFFF)
+    x = _q(np.maximum(rng.standard_normal((n, h, w, 64), dtype=np.float32), 0))
+    wg = _q((rng.standard_normal((64, 9, 64), dtype=np.float32) / np.sqrt(9 * 64)).astype(np.float32))
+    scale = (0.5 + rng.random(64, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(64, dtype=np.float32) if bn else None
+    res = _q(rng.standard_normal((n, h, w, 64), dtype=np.float32)) if has_res else None
+    out, _ = det.debug_conv_run(x, wg, 1, scale, bias, res, None, relu, None, True, True, True, False, variant=1)
+    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
+    _check(out, ref, True)
+
