@@ -258,14 +258,68 @@ def dry_run(a) -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "all_gather_results": {"images": images}}), flush=True)
+        emit({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "all_gather_results": {"images": images}})
+
+
+def c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, line, deadline_s=90.0):
+    """The result exchange through the C ABI (ocr_comm_*: RCCL called from the library, no torch in the data path) - what a
+    non-Python host binds.  It runs LAST, under a deadline: if a rank fails or stalls inside the library's communicator, every
+    rank leaves through the timer (rank 0 prints the line it already has, with the error noted) instead of hanging the job."""
+    import threading
+
+    def expire():
+        if line is not None:
+            line["all_gather_results_c_abi_error"] = f"no completion within {deadline_s:.0f} s"
+            emit(line)
+        os._exit(0)
+
+    timer = threading.Timer(deadline_s, expire)
+    timer.daemon = True
+    timer.start()
+    out = {}
+    try:
+        idb = [capi.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(idb, src=0)
+        comm = capi.Comm(idb[0], world, rank, local)
+        cp, cs = comm.all_gather_polygons(polys, scores)
+        same = cp == gathered[0] and cs == gathered[1]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            comm.all_gather_polygons(polys, scores)
+        ms = (time.perf_counter() - t1) / 10 * 1e3
+        out = {"all_gather_results_c_abi_ms": round(ms, 3), "all_gather_results_c_abi_matches": bool(same),
+               "all_gather_results_c_abi_note": "rank 0's wall time per call, ocr_comm_all_gather_polygons",
+               "rccl_version_c_abi": capi.Comm.rccl_version()}
+        comm.close()
+    except Exception as e:
+        out = {"all_gather_results_c_abi_error": f"{type(e).__name__}: {e}"}
+    timer.cancel()
+    return out
+
+
+_RESULT_FD = None
+
+
+def reserve_stdout() -> None:
+    """Keep the process's stdout for the ONE result line: libraries write banners there (RCCL prints its version block to
+    stdout when a communicator is created, gloo its connection note), so fd 1 is pointed at stderr for everything else."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line) -> None:
+    data = (json.dumps(line) + "\n").encode()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, data)
 
 
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    reserve_stdout()
     if a.dry_run:
         return dry_run(a)
 
@@ -288,6 +342,9 @@ def main():
     backend = os.environ.get("OCR_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % torch.cuda.device_count()
+    # OCR_BENCH_C_ABI=1 with the gloo rehearsal: attempt the library's own RCCL communicator anyway (two ranks on one GPU make
+    # RCCL refuse - that exercises the error path of c_abi_exchange)
+    try_c_abi = backend == "nccl" or os.environ.get("OCR_BENCH_C_ABI") == "1"
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -377,7 +434,7 @@ def main():
     # of its shard (get_boxes_and_box_scores) and the variable-length polygon blocks are all-gathered -
     # RCCL over xGMI when the backend is nccl (ocr-rs_amd/parallel.py)
     post = {}
-    polys = scores = pm = adj = params = None
+    polys = scores = pm = adj = params = gathered = None
     try:
         params = capi.default_params(skip_degenerate=True)
         maps = text_like_maps(n, s, seed=rank)
@@ -426,26 +483,7 @@ def main():
                     P.all_gather_results(pl, sc, comm_dev)
                 fence()
                 e2e = max_over_ranks(time.perf_counter() - t1)
-            # the same exchange through the C ABI (ocr_comm_*, RCCL called from the library, no torch in the path): what a
-            # non-Python host binds.  Only with the nccl backend (one GPU per rank); a failure is reported, never fatal.
-            cabi = {}
-            if backend == "nccl":
-                try:
-                    idb = [capi.Comm.unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(idb, src=0)
-                    comm = capi.Comm(idb[0], world, rank, local)
-                    cp, cs = comm.all_gather_polygons(polys, scores)
-                    same = cp == all_p and cs == all_s
-                    fence()
-                    t1 = time.perf_counter()
-                    for _ in range(10):
-                        comm.all_gather_polygons(polys, scores)
-                    cabi = {"all_gather_results_c_abi_ms": round(max_over_ranks((time.perf_counter() - t1) / 10 * 1e3), 3),
-                            "all_gather_results_c_abi_matches": bool(same), "rccl_version_c_abi": capi.Comm.rccl_version()}
-                    comm.close()
-                except Exception as e:
-                    cabi = {"all_gather_results_c_abi_error": f"{type(e).__name__}: {e}"}
-            post.update(cabi)
+            gathered = (all_p, all_s)
             post.update({"rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
                          "collective_backend": backend + (f" (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})" if backend == "nccl" else ""),
                          "all_gather_results_ms": round(gather_ms, 3),
@@ -563,11 +601,17 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(det_w, rec_w, s, a.cpu_seconds)
             except Exception as e:
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(line), flush=True)
+        if dist is not None and try_c_abi and gathered is not None:
+            line.update(c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, line))
+        emit(line)
+    elif dist is not None and try_c_abi and gathered is not None:
+        c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, None)
     det.close()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:   # no closing barrier: the launcher waits for every rank, and a rank that left through the deadline in
+            dist.destroy_process_group()   # c_abi_exchange must not stall the others after the line is out
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -1015,7 +1015,7 @@ Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(dev
   WeightBlob wb(blob, bytes);
   OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-  arena_.reserve((size_t)4 << 20);
+  arena_.reserve((size_t)8 << 20);
   auto vec = [&](const char* name, std::initializer_list<int> shape) {
     const TensorView& t = wb.get(name, shape);
     return std::vector<float>(t.data, t.data + t.count);
@@ -1024,8 +1024,10 @@ Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(dev
   w_.c1f = arena_.upload(rec_conv1_fragments(vec("conv1.weight", {32, 1, 5, 5}).data()));
   w_.c1b = arena_.upload(vec("conv1.bias", {32}));
   w_.c2f = arena_.upload(rec_conv2_fragments(vec("conv2.weight", {64, 32, 5, 5}).data()));
+  w_.c2s = arena_.upload(rec_conv2_small_fragments(vec("conv2.weight", {64, 32, 5, 5}).data()));
   w_.c2b = arena_.upload(vec("conv2.bias", {64}));
   w_.f1w = arena_.upload(vec("fc1.weight", {512, 1024}));
+  w_.f1s = arena_.upload(rec_fc1_small_weights(vec("fc1.weight", {512, 1024}).data()));
   w_.f1b = arena_.upload(vec("fc1.bias", {512}));
   std::vector<float> b2 = vec("fc2.bias", {62});
   b2.resize(64, 0.f);  // two padding columns: the kernel works on 32-column MFMA tiles
@@ -1052,7 +1054,7 @@ void Recognizer::ensure_workspace(int n) {
   if (feat_) OCR_HIP(hipFree(feat_));
   feat_ = hid_ = nullptr;
   ws_cap_ = 0;
-  const int cap = std::min(kChunk, std::max(n, 256));
+  const int cap = std::min(kChunk, std::max((n + 15) / 16 * 16, 256));  // whole 16-crop tiles (small-batch feat layout)
   OCR_HIP(hipMalloc(reinterpret_cast<void**>(&feat_), (size_t)cap * (1024 + 512) * sizeof(float)));
   hid_ = feat_ + (size_t)cap * 1024;
   ws_cap_ = cap;
@@ -1066,9 +1068,11 @@ void Recognizer::classify(const float* crops, int n, float* logits, int32_t* lab
     const int nb = std::min(kChunk, n - b);
     ensure_workspace(nb);
     Recorder rec(prof, stream_);
+    const bool small = rec_small_batch(nb);
     rec.begin();
-    launch_rec_conv(w_, crops + (size_t)b * 784, nb, feat_, stream_);
-    rec.end(rec_crops_per_block(nb) == 1 ? "rec_conv<1>" : rec_crops_per_block(nb) == 2 ? "rec_conv<2>" : "rec_conv<4>",
+    if (small) launch_rec_conv_small(w_, crops + (size_t)b * 784, nb, feat_, stream_);
+    else launch_rec_conv(w_, crops + (size_t)b * 784, nb, feat_, stream_);
+    rec.end(small ? "rec_conv_small" : rec_crops_per_block(nb) == 2 ? "rec_conv<2>" : "rec_conv<4>",
             2.0 * nb * (576.0 * 32 * 26 + 64.0 * 64 * 800), (double)nb * (784 + 1024) * 4 + 13 * 64 * 4 + 25 * 2048 * 4);
     // fc1 + bias + ReLU as a plain GEMM over the batch: M = crops, K = Cin, N = Cout
     auto fc = [&](const char* name, const float* in, const float* wgt, const float* bias, int cin, int cout, bool relu, float* out) {
@@ -1095,7 +1099,13 @@ void Recognizer::classify(const float* crops, int n, float* logits, int32_t* lab
       launch_conv_igemm(d, stream_);
       rec.end(name, 2.0 * nb * cin * cout, 4.0 * ((double)nb * (cin + cout) + (double)cin * cout));
     };
-    fc("rec_fc1", feat_, w_.f1w, w_.f1b, 1024, 512, true, hid_);
+    if (small) {
+      rec.begin();
+      launch_rec_fc1_small(w_, feat_, nb, hid_, stream_);
+      rec.end("rec_fc1_small", 2.0 * nb * 1024 * 512, 4.0 * ((double)nb * (1024 + 512) + 1024.0 * 512));
+    } else {
+      fc("rec_fc1", feat_, w_.f1w, w_.f1b, 1024, 512, true, hid_);
+    }
     rec.begin();
     launch_rec_fc2_softmax(w_, hid_, nb, logits ? logits + (size_t)b * 62 : nullptr, labels ? labels + b : nullptr,
                            probs ? probs + b : nullptr, stream_);

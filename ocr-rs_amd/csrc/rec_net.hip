@@ -184,6 +184,148 @@ __global__ __launch_bounds__(256, 2) void rec_conv_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Low-latency forms for small batches (BASELINE configs[2] is 256 crops: one launch wave, nothing to amortise).  The
+// time of the kernels above is then the LENGTH OF ONE DEPENDENT MFMA CHAIN: conv2 accumulates K = 800 as 400
+// v_mfma_f32_32x32x2_f32 of 64 cycles each, fc1 K = 1024 as 512.  v_mfma_f32_16x16x4_f32 contracts four k per
+// instruction with a 40-cycle dependent latency, and fed with k in the order (0,4,1,5),(2,6,3,7) of every group of
+// eight it produces the SAME BITS as the 32x32x2 chain in its (0,4),(1,5),(2,6),(3,7) order
+// (tools/probes/mfma_chain_order.hip): the small-batch path is 2.5x shorter per chain, uses 16 waves per crop, and a
+// crop's logits still do not depend on the batch it arrives in.
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// conv1 + pool + conv2 + pool of ONE crop per 1024-thread workgroup.  conv1 as in rec_conv_kernel (18 tiles over the
+// 16 waves); conv2: wave w owns the 16 x 16 tile (pixel rows 2 (w >> 2), 2 (w >> 2) + 1 of the 8 x 8 output = four
+// pool windows, output channels 16 (w & 3) .. + 15).  Tile row 4 slot + sub is sub-pixel `sub` of window `slot`:
+// a lane's four accumulator registers are one window, the pool is a max over them.
+__global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __restrict__ crops, int n, const float* __restrict__ w1f,
+                                                              const float* __restrict__ b1, const float* __restrict__ w2s,
+                                                              const float* __restrict__ b2, float* __restrict__ feat) {
+  __shared__ __attribute__((aligned(16))) float p1[P1_PIX * P1_ROW];
+  __shared__ __attribute__((aligned(16))) float img[IMG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int crop = blockIdx.x;
+  if (tid < IMG / 4) *reinterpret_cast<f32x4*>(img + tid * 4) = *reinterpret_cast<const f32x4*>(crops + (size_t)crop * IMG + tid * 4);
+  float w1r[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) w1r[s] = w1f[s * 64 + lane];
+  const float bias1 = b1[lane & 31];
+  __syncthreads();
+  for (int tile = wave; tile < 18; tile += 16) {
+    const int i = lane & 31, h = lane >> 5, j = lane & 31;
+    const int wi = tile * 8 + (i >> 2);
+    const int qy = wi / 12, qx = wi - qy * 12;
+    const float* im = img + (2 * qy + ((i >> 1) & 1)) * 28 + 2 * qx + (i & 1);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      const int k0 = 2 * s, k1 = 2 * s + 1;
+      const int o0 = (k0 / 5) * 28 + k0 % 5;
+      const int o1 = k1 < 25 ? (k1 / 5) * 28 + k1 % 5 : 0;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(im[h ? o1 : o0], w1r[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      p1[p1_index(tile * 8 + 2 * g + h, j)] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias1;
+  }
+  __syncthreads();
+  // conv2: 16 x 16 x 4 MFMA, lane (row r = lane & 15, k slot q = lane >> 4)
+  const int r = lane & 15, q = lane >> 4;
+  const int rt = wave >> 2, ct = wave & 3;
+  const int slot = r >> 2, sub = r & 3;
+  const int pix0 = (2 * rt + (sub >> 1)) * 12 + 2 * slot + (sub & 1);      // window (py = rt, px = slot)
+  const int el = q >> 1, c16 = q & 1;                                      // element pair (el, el + 2) of chunk 2 g + c16
+  const f32x4* wf = reinterpret_cast<const f32x4*>(w2s) + ct * 2 * 64 + lane;  // [tap][ct][gpair][lane] float4
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // a tap is 8 MFMAs = 320 cycles, an L2 round trip is longer: the weights of the next DEPTH taps are kept in flight
+  constexpr int DEPTH = 5;
+  f32x4 ring[DEPTH][2];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    ring[d][0] = wf[(d * 4 * 2) * 64];
+    ring[d][1] = wf[(d * 4 * 2 + 1) * 64];
+  }
+#pragma unroll
+  for (int tap = 0; tap < 25; ++tap) {
+    const f32x4 bc0 = ring[tap % DEPTH][0], bc1 = ring[tap % DEPTH][1];
+    if (tap + DEPTH < 25) {
+      ring[tap % DEPTH][0] = wf[((tap + DEPTH) * 4 * 2) * 64];
+      ring[tap % DEPTH][1] = wf[((tap + DEPTH) * 4 * 2 + 1) * 64];
+    }
+    const int ky = tap / 5, kx = tap - ky * 5;
+    const int pix = pix0 + ky * 12 + kx;
+    const float* row = p1 + pix * P1_ROW;
+    const int sw = (pix >> 1) & 7;
+    f32x4 a[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a[g] = *reinterpret_cast<const f32x4*>(row + (((2 * g + c16) ^ sw) << 2));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // group g of eight input channels: instruction 0 multiplies k = (0,4,1,5) + 8 g, instruction 1 k = (2,6,3,7) + 8 g
+      const f32x4 bw = g < 2 ? bc0 : bc1;
+      const float a0 = el ? a[g][1] : a[g][0], a1 = el ? a[g][3] : a[g][2];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[2 * (g & 1)], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[2 * (g & 1) + 1], acc, 0, 0, 0);
+    }
+  }
+  // C/D map of 16x16x4: column = lane & 15, rows 4 q .. 4 q + 3 in the four registers = window q of this tile.
+  // feat goes out in the operand order of rec_fc1_small_kernel (see there): k = co * 16 + p of crop `crop`
+  const int co = 16 * ct + r;
+  const float v = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + b2[co];
+  const int kk = co * 16 + 4 * rt + q;
+  feat[((((size_t)(crop >> 4) * 128 + (kk >> 3)) * 2 + ((kk >> 2) & 1)) * 16 + (crop & 15)) * 4 + (kk & 3)] = v;
+}
+
+// fc1 + bias + ReLU for small batches: wave = one 16 crops x 16 outputs tile over the whole K = 1024 as 256 dependent
+// v_mfma_f32_16x16x4_f32 in conv_igemm's k order (bit-identical to the large-batch GEMM).  Both operands are read in
+// OPERAND ORDER, [tile][group G of eight k][4 c16 + ...]: float index (((tile * 128 + G) * 2 + c16) * 16 + r) * 4 + e
+// holds element (row r of the tile, k = 8 G + 4 c16 + e) - a wave load is 512 contiguous bytes (rec_conv_small_kernel
+// writes feat that way, the host re-lays fc1.weight out).  grid (ceil(n / 16), 8), 4 waves = 64 output columns.
+__global__ __launch_bounds__(256) void rec_fc1_small_kernel(const float* __restrict__ feat_t, int n, const float* __restrict__ w_t,
+                                                            const float* __restrict__ bias, float* __restrict__ hid) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4, el = q >> 1, c16 = q & 1;
+  const int row0 = blockIdx.x * 16, ct = blockIdx.y * 4 + wave;
+  const f32x4* ap = reinterpret_cast<const f32x4*>(feat_t) + (size_t)blockIdx.x * 128 * 32 + c16 * 16 + r;
+  const f32x4* bp = reinterpret_cast<const f32x4*>(w_t) + (size_t)ct * 128 * 32 + c16 * 16 + r;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;  // groups in flight: 16 loads per lane ahead of their 16 MFMAs (640 cycles)
+  f32x4 a[2][U], b[2][U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    a[0][u] = ap[u * 32];
+    b[0][u] = bp[u * 32];
+  }
+#pragma unroll
+  for (int g0 = 0; g0 < 128; g0 += U) {
+    const int cur = (g0 / U) & 1;
+    if (g0 + U < 128) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[cur ^ 1][u] = ap[(g0 + U + u) * 32];
+        b[cur ^ 1][u] = bp[(g0 + U + u) * 32];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(el ? a[cur][u][1] : a[cur][u][0], el ? b[cur][u][1] : b[cur][u][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(el ? a[cur][u][3] : a[cur][u][2], el ? b[cur][u][3] : b[cur][u][2], acc, 0, 0, 0);
+    }
+  }
+  const int col = 16 * ct + r;
+  const float bv = bias[col];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = row0 + 4 * q + e;
+    if (row < n) hid[(size_t)row * 512 + col] = fmaxf(acc[e] + bv, 0.f);
+  }
+}
+
 // fc2 (512 -> 62, as 64 columns with two zero ones) + bias, then softmax(-1, f64) and its top-1: 64 crops per
 // 1024-thread workgroup.  Wave w multiplies the 32 x 32 tile (crops 32 ((w >> 1) & 1) .., columns 32 (w & 1) ..) over
 // the K quarter w >> 2 (16 waves: the dependent MFMA chain is 64 long instead of 256 - this kernel is latency-bound at
@@ -291,6 +433,50 @@ std::vector<float> rec_conv2_fragments(const float* w) {
           }
   return f;
 }
+
+// conv2 [64][32][5][5] for the 16x16x4 form: [25 taps][4 ct][2 gpair][64 lanes][4]; lane (c = l & 15, q = l >> 4) of
+// group g = 2 gpair + (e >> 1) holds w[16 ct + c][ci][tap] for ci = 8 g + (q >> 1) + 4 (q & 1) + 2 (e & 1)
+std::vector<float> rec_conv2_small_fragments(const float* w) {
+  std::vector<float> f((size_t)25 * 4 * 2 * 64 * 4);
+  for (int tap = 0; tap < 25; ++tap)
+    for (int ct = 0; ct < 4; ++ct)
+      for (int gp = 0; gp < 2; ++gp)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 4; ++e) {
+            const int c = l & 15, q = l >> 4, g = 2 * gp + (e >> 1);
+            const int co = 16 * ct + c, ci = 8 * g + (q >> 1) + 4 * (q & 1) + 2 * (e & 1);
+            f[((((size_t)tap * 4 + ct) * 2 + gp) * 64 + l) * 4 + e] = w[((size_t)co * 32 + ci) * 25 + tap];
+          }
+  return f;
+}
+
+// fc1.weight [512][1024] in the operand order of rec_fc1_small_kernel: [32 column tiles][128 G][2 c16][16 c][4 e]
+std::vector<float> rec_fc1_small_weights(const float* w) {
+  std::vector<float> f((size_t)512 * 1024);
+  for (int ct = 0; ct < 32; ++ct)
+    for (int G = 0; G < 128; ++G)
+      for (int c16 = 0; c16 < 2; ++c16)
+        for (int c = 0; c < 16; ++c)
+          for (int e = 0; e < 4; ++e)
+            f[((((size_t)ct * 128 + G) * 2 + c16) * 16 + c) * 4 + e] = w[(size_t)(16 * ct + c) * 1024 + 8 * G + 4 * c16 + e];
+  return f;
+}
+
+constexpr int kRecSmallBatch = 1024;  // up to here the chain-latency-optimised kernels; beyond, the throughput ones
+
+void launch_rec_conv_small(const RecWeights& w, const float* crops, int n, float* feat, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(rec_conv_small_kernel, dim3(n), dim3(1024), 0, s, crops, n, w.c1f, w.c1b, w.c2s, w.c2b, feat);
+  OCR_HIP(hipGetLastError());
+}
+
+void launch_rec_fc1_small(const RecWeights& w, const float* feat, int n, float* hid, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(rec_fc1_small_kernel, dim3((n + 15) / 16, 8), dim3(256), 0, s, feat, n, w.f1s, w.f1b, hid);
+  OCR_HIP(hipGetLastError());
+}
+
+bool rec_small_batch(int n) { return n <= kRecSmallBatch; }
 
 int rec_crops_per_block(int n) { return n <= 768 ? 1 : n <= 3072 ? 2 : 4; }
 

@@ -20,8 +20,8 @@ def test_bare_command_launches_its_ranks():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--batch", "7", "--steps", "4", "--warmup", "1"],
                        env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1                      # ONE line, from rank 0
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout   # ONE line, from rank 0: library banners (gloo, RCCL) go to stderr
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1
     assert line["all_gather_results"]["images"] == 14   # both shards arrived, in rank order

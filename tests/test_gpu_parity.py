@@ -310,7 +310,9 @@ def test_rec_device_path_guards_and_profile(rec, rec_w):
     prof = rec.classify_profile(d.data_ptr(), n, labels.data_ptr(), probs.data_ptr())
     rec.synchronize()
     names = [p[0] for p in prof]
-    assert names[0].startswith("rec_conv<") and names[1] == "rec_fc1" and names[2] == "rec_fc2_softmax_top1"
+    assert names == ["rec_conv_small", "rec_fc1_small", "rec_fc2_softmax_top1"]     # n <= 1024: the chain-latency kernels
+    big = rec.classify_profile(torch.from_numpy(W.synth_crops(6, 2000)).cuda().data_ptr(), 2000)
+    assert [p[0] for p in big] == ["rec_conv<2>", "rec_fc1", "rec_fc2_softmax_top1"]
     assert all(ms > 0 for _, ms, _, _ in prof)
     assert abs(sum(fl for _, _, fl, _ in prof) / n / 8.587264e6 - 1.0) < 0.05   # executes the reference graph's work (+ K / N padding)
     rl, _ = T.rec_classify(T.rec_forward(rec_w, crops))
