@@ -95,12 +95,12 @@ void launch_stem_bf16(const float* x, const void* wfrag, const float* scale, con
 std::vector<uint16_t> conv3x3_bf16_c64_fragments(const float* ohwi);
 void launch_conv3x3_bf16_c64(const void* x, const void* wfrag, const float* scale, const float* bias, const void* residual, int relu,
                              void* y, int N, int H, int W, int num_cus, hipStream_t s);
-// Winograd F(2x2, 3x3) transforms around a batched 16-problem GEMM (winograd.hip): 3x3 s1 p1 convs of the deep,
-// small-grid layers.  x: [N][H][W][C] f32 -> v: [16][T][C], T = N * ceil(H/2) * ceil(W/2) tiles (zero padding
-// and odd sizes handled here); m: [16][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.
-void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s);
-void launch_winograd_output(const float* m, const float* scale, const float* bias, const float* residual, int relu,
-                            float* y, int N, int H, int W, int K, hipStream_t s);
+// Winograd F(m x m, 3x3) transforms, m = 2 or 4, around a batched GEMM of (m+2)^2 problems (winograd.hip): 3x3 s1 p1 convs
+// of the deep, small-grid layers.  x: [N][H][W][C] f32 -> v: [(m+2)^2][T][C], T = N * ceil(H/m) * ceil(W/m) tiles (zero
+// padding and ragged sizes handled here); mm: [(m+2)^2][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.
+void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, hipStream_t s);
+void launch_winograd_output(const float* mm, const float* scale, const float* bias, const float* residual, int relu,
+                            float* y, int N, int H, int W, int K, int m, hipStream_t s);
 // The same conv with both transforms fused into the GEMM kernel (winograd_fused.hip): C = 64 or 128 input
 // channels, K a multiple of 64.  u_neg3: winograd weights [16][K][C] with the components of row i = 3 (12..15) negated.
 void launch_winograd_fused(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,

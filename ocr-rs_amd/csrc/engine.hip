@@ -111,29 +111,36 @@ ConvW Detector::finish_composed(std::vector<float>&& t, int cout, int cin, int k
   return cw;
 }
 
-// U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]] (f64, rounded once), laid out
-// [16 = 4 i + j][Cout][Cin]: sixteen 1x1-conv weight matrices for conv_igemm's batched mode
-std::vector<float> winograd_weights(const float* ohwi, int cout, int cin) {
-  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+// U = G g G^T per (cout, cin) in f64, rounded once, laid out [(m+2)^2 = (m+2) i + j][Cout][Cin]: that many 1x1-conv weight
+// matrices for conv_igemm's batched mode.  F(2x2,3x3): G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]];
+// F(4x4,3x3): G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+std::vector<float> winograd_weights(const float* ohwi, int cout, int cin, int m) {
+  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  static const double G4[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  if (m != 2 && m != 4) fail(OCR_ERR_INTERNAL, "winograd_weights: m = %d", m);
+  const int a = m + 2;
+  const double(*G)[3] = m == 2 ? G2 : G4;
   const size_t kc = (size_t)cout * cin;
-  std::vector<float> u(16 * kc);
+  std::vector<float> u((size_t)a * a * kc);
   for (int o = 0; o < cout; ++o)
     for (int c = 0; c < cin; ++c) {
       double g[3][3];
       for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ohwi[((size_t)o * 9 + t) * cin + c];
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
+      for (int i = 0; i < a; ++i)
+        for (int j = 0; j < a; ++j) {
           double acc = 0.0;
           for (int p = 0; p < 3; ++p)
             for (int q = 0; q < 3; ++q) acc += G[i][p] * g[p][q] * G[j][q];
-          u[(size_t)(4 * i + j) * kc + (size_t)o * cin + c] = (float)acc;
+          u[(size_t)(a * i + j) * kc + (size_t)o * cin + c] = (float)acc;
         }
     }
   return u;
 }
 
 void Detector::add_winograd_weights(ConvW& cw) {
-  const std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin);
+  cw.wino_tile = cw.cin >= winograd43_min_cin_ ? 4 : 2;
+  const std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin, cw.wino_tile);
   cw.wino = arena_.upload(u);
   cw.wino_bytes = u.size() * sizeof(float);
 }
@@ -221,6 +228,8 @@ void Detector::parse_options(const char* options) {
     if (key == "winograd_fused") winograd_fused_ = num() != 0;
     else if (key == "winograd_ws") winograd_ws_ = num() != 0;
     else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
+    else if (key == "winograd_fused_max_cin") winograd_fused_max_cin_ = num();
+    else if (key == "winograd43") winograd43_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
@@ -252,7 +261,9 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
       OCR_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     }
   }
-  arena_.reserve((size_t)224 << 20);  // 12.2 M parameters = 48.7 MB f32 (+ 24.4 MB of bf16 copies on demand) + padding
+  // 12.2 M parameters = 48.7 MB f32, the Winograd forms (F(4x4): 36 matrices per 3x3 conv of layer3/4, 113 MB; fused F(2x2): 16),
+  // composed FPN weights, 24.4 MB of bf16 copies and fragments on demand, padding
+  arena_.reserve((size_t)384 << 20);
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -291,11 +302,13 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     add_winograd_fused_weights(layer_[1][0][1]);
     add_winograd_fused_weights(layer_[1][1][0]);
     add_winograd_fused_weights(layer_[1][1][1]);
-    // layer3's (256 -> 256 at H/16): 0.34 vs 0.36 ms for the unfused form; layer4's 20 x 20 grids would waste
-    // half of the 8 x 16 pixel blocks and stay unfused
-    add_winograd_fused_weights(layer_[2][0][1]);
-    add_winograd_fused_weights(layer_[2][1][0]);
-    add_winograd_fused_weights(layer_[2][1][1]);
+    // layer3's (256 -> 256 at H/16): fused F(2x2) 0.335 ms, unfused F(2x2) 0.36 ms, unfused F(4x4) 0.233 ms - the default
+    // leaves layer3 and layer4 (20 x 20 grids, 0.286 -> 0.184 ms) to the unfused F(4x4,3x3) path below
+    if (winograd_fused_max_cin_ >= 256) {
+      add_winograd_fused_weights(layer_[2][0][1]);
+      add_winograd_fused_weights(layer_[2][1][0]);
+      add_winograd_fused_weights(layer_[2][1][1]);
+    }
   }
   for (int l = 0; l < 4; ++l) {
     if ((64 << l) < winograd_min_cin_) continue;
@@ -573,11 +586,12 @@ void Detector::ensure_workspace(int n, int h, int w) {
   b1_ = reinterpret_cast<float*>(alloc(N * (h / 4) * (w / 4) * 64 * 4));
   wino_v_ = wino_m_ = nullptr;
   {
-    size_t need = 0;  // 16 * tiles * channels of the largest Winograd layer
+    size_t need = 0;  // components * tiles * channels of the largest Winograd layer
     for (int l = 0; l < 4; ++l)
       if (layer_[l][1][0].wino) {
-        const size_t th = ((h >> (2 + l)) + 1) / 2, tw = ((w >> (2 + l)) + 1) / 2;
-        need = std::max(need, (size_t)16 * N * th * tw * ((size_t)64 << l));
+        const size_t m = layer_[l][1][0].wino_tile, a = m + 2;
+        const size_t th = ((h >> (2 + l)) + m - 1) / m, tw = ((w >> (2 + l)) + m - 1) / m;
+        need = std::max(need, a * a * N * th * tw * ((size_t)64 << l));
       }
     if (need) {
       wino_v_ = reinterpret_cast<float*>(alloc(need * 4));
@@ -769,23 +783,25 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
       rec.end("conv3x3_bf16_c64", 2.0 * px * 64 * 576, px * 2.0 * 64 * (residual ? 3.0 : 2.0) + 9.0 * 64 * 64 * 2);
       return;
     }
-    const size_t th = (hh + 1) / 2, tw = (ww + 1) / 2, T = (size_t)n * th * tw;
-    if (bf || !cw.wino || !wino_v_ || 16 * T * std::max(cw.cin, cw.cout) * 4 >= ((size_t)1 << 31)) {
+    const size_t wm = cw.wino_tile, wa = (wm + 2) * (wm + 2);   // F(wm x wm, 3x3): wa components
+    const size_t th = (hh + wm - 1) / wm, tw = (ww + wm - 1) / wm, T = (size_t)n * th * tw;
+    if (bf || !cw.wino || !wino_v_ || wa * T * std::max(cw.cin, cw.cout) * 4 >= ((size_t)1 << 31)) {
       Extra ex;
       ex.residual = residual;
       conv(name, cw, src, hh, ww, 1, out, relu, ex);
       return;
     }
     rec.begin();
-    launch_winograd_input(static_cast<const float*>(src), wino_v_, n, hh, ww, cw.cin, stream_);
-    rec.end("winograd_input_transform", 0.0, (double)n * hh * ww * cw.cin * 4.0 + 16.0 * T * cw.cin * 4.0);
+    launch_winograd_input(static_cast<const float*>(src), wino_v_, n, hh, ww, cw.cin, (int)wm, stream_);
+    rec.end(wm == 4 ? "winograd43_input_transform" : "winograd_input_transform", 0.0,
+            (double)n * hh * ww * cw.cin * 4.0 + (double)wa * T * cw.cin * 4.0);
     ConvDesc d{};
     d.src[0] = wino_v_;
     d.src_mode = SRC_PLAIN;
-    d.src_bytes = 16 * T * cw.cin * 4;
+    d.src_bytes = wa * T * cw.cin * 4;
     d.wgt = cw.wino;
     d.wgt_bytes = cw.wino_bytes;
-    d.batch = 16;
+    d.batch = (int)wa;
     d.N = 1;
     d.Hin = d.Ho = 1;
     d.Win = d.Wo = (int)T;
@@ -799,13 +815,13 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.name = name;
     rec.begin();
     launch_conv_igemm(d, stream_);
-    rec.end(conv_igemm_kernel_name(d), 2.0 * 16.0 * T * cw.cin * cw.cout,
-            16.0 * 4.0 * ((double)T * cw.cin + (double)T * cw.cout + (double)cw.cin * cw.cout));
+    rec.end(conv_igemm_kernel_name(d), 2.0 * wa * T * cw.cin * cw.cout,
+            (double)wa * 4.0 * ((double)T * cw.cin + (double)T * cw.cout + (double)cw.cin * cw.cout));
     rec.begin();
     launch_winograd_output(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(out),
-                           n, hh, ww, cw.cout, stream_);
-    rec.end("winograd_output_transform", 0.0,
-            16.0 * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
+                           n, hh, ww, cw.cout, (int)wm, stream_);
+    rec.end(wm == 4 ? "winograd43_output_transform" : "winograd_output_transform", 0.0,
+            (double)wa * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
   };
 
   // composed FPN level lv (0: p2, 1: p3) and its term of bin_conv1: p_k = A_k * x_k + B_k *' x_{k+1} - the

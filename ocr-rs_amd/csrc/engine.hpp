@@ -29,8 +29,8 @@ class DeviceArena {  // bump allocator over one hipMalloc (weights)
   size_t cap_ = 0, used_ = 0;
 };
 
-// U = G g G^T of a 3x3 conv given as [Cout][3x3][Cin], laid out [16][Cout][Cin] (winograd.hip)
-std::vector<float> winograd_weights(const float* ohwi, int cout, int cin);
+// U = G g G^T of a 3x3 conv given as [Cout][3x3][Cin], laid out [(m+2)^2][Cout][Cin] for F(m x m, 3x3), m = 2 or 4 (winograd.hip)
+std::vector<float> winograd_weights(const float* ohwi, int cout, int cin, int m = 2);
 
 struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
@@ -41,6 +41,7 @@ struct ConvW {
   std::vector<float> host_scale;  // folded batch norm scale (empty: none), kept for weight composition
   float* wino = nullptr;   // Winograd F(2x2,3x3) weights U = G g G^T as [16][Cout][Cin] (3x3 s1 convs of the deep layers)
   size_t wino_bytes = 0;
+  int wino_tile = 2;       // ... or F(4x4,3x3), [36][Cout][Cin], where the option winograd43 asks for it
   float* wino_fused = nullptr;  // 64 -> 64 convs: the same with components 12..15 negated (winograd_fused.hip)
   float* wino_ws = nullptr;     // ... or as MFMA B fragments for the wave-specialised kernel (winograd_ws.hip)
   int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
@@ -136,7 +137,9 @@ class Detector {
   bool fpn_composed_ = true;
   // Winograd for 3x3 s1 trunk convs with Cin >= this (f32 precision only); option winograd=0 disables, =<cin> overrides
   int winograd_min_cin_ = 256;
-  float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [16][T][C] and [16][T][K] scratch of the layer in flight
+  int winograd_fused_max_cin_ = 128;  // trunk layers up to this many channels run the fused F(2x2,3x3) kernel (256 adds layer3)
+  int winograd43_min_cin_ = 256;      // unfused Winograd layers with at least this many channels use F(4x4,3x3)
+  float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [(m+2)^2][T][C] and [(m+2)^2][T][K] scratch of the layer in flight
   void add_winograd_weights(ConvW& cw);
   void add_winograd_fused_weights(ConvW& cw);
   bool winograd_ws_ = false;     // option winograd_ws=1: the wave-specialised fused Winograd kernel instead of winograd_fused

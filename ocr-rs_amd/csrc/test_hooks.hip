@@ -219,9 +219,10 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     if (!det || !x || !wgt || !out) fail(OCR_ERR_INVALID, "null argument");
     OCR_HIP(hipSetDevice(det->impl.device()));
     hipStream_t s = det->impl.stream();
-    const size_t th = (h + 1) / 2, tw = (w + 1) / 2, T = (size_t)n * th * tw;
+    const size_t wm = unfused == 3 ? 4 : 2, wa = (wm + 2) * (wm + 2);   // unfused == 3: F(4x4,3x3), unfused
+    const size_t th = (h + wm - 1) / wm, tw = (w + wm - 1) / wm, T = (size_t)n * th * tw;
     const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
-    const std::vector<float> u = winograd_weights(wgt, cout, cin);
+    const std::vector<float> u = winograd_weights(wgt, cout, cin, (int)wm);
     std::vector<void*> allocs;
     struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
     auto dev = [&](const float* src, size_t elems) -> float* {
@@ -233,8 +234,8 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     };
     float* d_x = dev(x, in_e);
     float* d_u = dev(u.data(), u.size());
-    float* d_v = dev(nullptr, 16 * T * cin);
-    float* d_m = dev(nullptr, 16 * T * cout);
+    float* d_v = dev(nullptr, wa * T * cin);
+    float* d_m = dev(nullptr, wa * T * cout);
     float* d_y = dev(nullptr, out_e);
     const float* d_sc = scale ? dev(scale, cout) : nullptr;
     const float* d_bi = bias ? dev(bias, cout) : nullptr;
@@ -255,18 +256,18 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
       OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
       return;
     }
-    launch_winograd_input(d_x, d_v, n, h, w, cin, s);
+    launch_winograd_input(d_x, d_v, n, h, w, cin, (int)wm, s);
     ConvDesc d{};
     d.src[0] = d_v;
     d.src_mode = SRC_PLAIN;
-    d.src_bytes = 16 * T * cin * 4;
+    d.src_bytes = wa * T * cin * 4;
     d.wgt = d_u;
     d.wgt_bytes = u.size() * 4;
-    d.batch = 16;
+    d.batch = (int)wa;
     d.N = 1; d.Hin = d.Ho = 1; d.Win = d.Wo = (int)T; d.Cin = cin; d.Cout = cout;
     d.ks = 1; d.stride = 1; d.pad = 0; d.store_mode = STORE_NHWC; d.out = d_m; d.name = "test_winograd";
     launch_conv_igemm(d, s);
-    launch_winograd_output(d_m, d_sc, d_bi, d_res, relu, d_y, n, h, w, cout, s);
+    launch_winograd_output(d_m, d_sc, d_bi, d_res, relu, d_y, n, h, w, cout, (int)wm, s);
     OCR_HIP(hipStreamSynchronize(s));
     OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
   });

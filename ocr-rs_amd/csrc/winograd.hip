@@ -17,6 +17,7 @@ namespace ocr {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // one thread = one tile x 4 channels; consecutive threads walk the channels of a tile (coalesced 16-byte
 // accesses on both sides).  v layout [16][T][C].
@@ -117,10 +118,143 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
   }
 }
 
+// ---- F(4x4, 3x3): 36 multiplies per 4x4 output tile (2.25 per output instead of 4) for the grids where the transforms are
+// cheap beside the GEMMs (layer4's 512 channels at H/32).  Lavin & Gray's matrices; the weight transform carries the
+// fractions of G (engine.hip, f64 rounded once), so the device side multiplies by 2, 4, 5 and 8 only:
+//
+//   B^T = | 4  0 -5  0  1  0 |     A^T = | 1  1  1  1  1  0 |
+//         | 0 -4 -4  1  1  0 |           | 0  1 -1  2 -2  0 |
+//         | 0  4 -4 -1  1  0 |           | 0  1  1  4  4  0 |
+//         | 0 -2 -1  2  1  0 |           | 0  1 -1  8 -8  1 |
+//         | 0  2 -1 -2  1  0 |
+//         | 0  4  0 -5  0  1 |
+//
+// The products are larger and cancel more than F(2x2)'s: ~1e-6 relative error of a conv output instead of ~1e-7.
+template <typename V>
+__device__ __forceinline__ void bt6(const V d0, const V d1, const V d2, const V d3, const V d4, const V d5, V* t) {
+  const V a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+  t[0] = 4.f * d0 - 5.f * d2 + d4;
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+
+// one thread = one tile x 2 channels (36 loads of 8 bytes; consecutive threads walk the channels).  v layout [36][T][C].
+__global__ __launch_bounds__(256) void winograd43_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H, int W,
+                                                               int C, int th, int tw, long long T) {
+  const int c2n = C >> 1;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= T * c2n) return;
+  const long long t = gid / c2n;
+  const int c = (int)(gid - t * c2n) * 2;
+  const int tx = (int)(t % tw);
+  const long long r = t / tw;
+  const int ty = (int)(r % th);
+  const long long n = r / th;
+  const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+  f32x2 rt[6][6];  // B^T d, column by column
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    f32x2 d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int yy = y0 + i, xx = x0 + j;
+      const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const f32x2 zero = {0.f, 0.f};
+      d[i] = ok ? *reinterpret_cast<const f32x2*>(x + ((n * H + yy) * W + xx) * C + c) : zero;
+    }
+    f32x2 tcol[6];
+    bt6(d[0], d[1], d[2], d[3], d[4], d[5], tcol);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rt[i][j] = tcol[i];
+  }
+  const size_t step = (size_t)T * C;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {  // (B^T d) B
+    f32x2 o[6];
+    bt6(rt[i][0], rt[i][1], rt[i][2], rt[i][3], rt[i][4], rt[i][5], o);
+    float* dst = v + ((size_t)(6 * i) * T + t) * C + c;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(dst + j * step) = o[j];
+  }
+}
+
+template <typename V>
+__device__ __forceinline__ void at6(const V m0, const V m1, const V m2, const V m3, const V m4, const V m5, V* y) {
+  const V s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+  y[0] = m0 + s12 + s34;
+  y[1] = d12 + 2.f * d34;
+  y[2] = s12 + 4.f * s34;
+  y[3] = d12 + 8.f * d34 + m5;
+}
+
+// one thread = one tile x 2 output channels.  m layout [36][T][K]; y NHWC.
+__global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
+                                                                const float* __restrict__ bias, const float* __restrict__ residual,
+                                                                int relu, float* __restrict__ y, int H, int W, int K, int th,
+                                                                int tw, long long T) {
+  const int k2n = K >> 1;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= T * k2n) return;
+  const long long t = gid / k2n;
+  const int k = (int)(gid - t * k2n) * 2;
+  const int tx = (int)(t % tw);
+  const long long r = t / tw;
+  const int ty = (int)(r % th);
+  const long long n = r / th;
+  const size_t step = (size_t)T * K;
+  const float* src = m + (size_t)t * K + k;
+  f32x2 u[4][6];  // A^T M, column by column
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    f32x2 a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * i + j) * step);
+    f32x2 col[4];
+    at6(a[0], a[1], a[2], a[3], a[4], a[5], col);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) u[p][j] = col[p];
+  }
+  f32x2 sc = {1.f, 1.f}, bi = {0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x2*>(scale + k);
+  if (bias) bi = *reinterpret_cast<const f32x2*>(bias + k);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 o4[4];
+    at6(u[p][0], u[p][1], u[p][2], u[p][3], u[p][4], u[p][5], o4);
+    const int yy = 4 * ty + p;
+    if (yy >= H) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int xx = 4 * tx + q;
+      if (xx >= W) continue;
+      const size_t o = ((n * H + yy) * W + xx) * (size_t)K + k;
+      f32x2 val = o4[q] * sc + bi;
+      if (residual) val += *reinterpret_cast<const f32x2*>(residual + o);
+      if (relu) {
+        val[0] = fmaxf(val[0], 0.f);
+        val[1] = fmaxf(val[1], 0.f);
+      }
+      *reinterpret_cast<f32x2*>(y + o) = val;
+    }
+  }
+}
+
 }  // namespace
 
-void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s) {
-  if (N <= 0 || H <= 0 || W <= 0 || C % 4) fail(OCR_ERR_INVALID, "winograd input: bad shape N=%d H=%d W=%d C=%d", N, H, W, C);
+void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || C % 4 || (m != 2 && m != 4)) fail(OCR_ERR_INVALID, "winograd input: bad shape N=%d H=%d W=%d C=%d m=%d", N, H, W, C, m);
+  if (m == 4) {
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)N * th * tw;
+    const long long threads = T * (C / 2);
+    if (threads >= (1ll << 31) * 256) fail(OCR_ERR_INVALID, "winograd input: too large");
+    hipLaunchKernelGGL(winograd43_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, v, H, W, C, th, tw, T);
+    OCR_HIP(hipGetLastError());
+    return;
+  }
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   const long long T = (long long)N * th * tw;
   const long long threads = T * (C / 4);
@@ -130,8 +264,18 @@ void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C,
 }
 
 void launch_winograd_output(const float* m, const float* scale, const float* bias, const float* residual, int relu, float* y,
-                            int N, int H, int W, int K, hipStream_t s) {
-  if (N <= 0 || H <= 0 || W <= 0 || K % 4) fail(OCR_ERR_INVALID, "winograd output: bad shape N=%d H=%d W=%d K=%d", N, H, W, K);
+                            int N, int H, int W, int K, int m_tile, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || K % 4 || (m_tile != 2 && m_tile != 4)) fail(OCR_ERR_INVALID, "winograd output: bad shape N=%d H=%d W=%d K=%d m=%d", N, H, W, K, m_tile);
+  if (m_tile == 4) {
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)N * th * tw;
+    const long long threads = T * (K / 2);
+    if (threads >= (1ll << 31) * 256) fail(OCR_ERR_INVALID, "winograd output: too large");
+    hipLaunchKernelGGL(winograd43_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, scale, bias, residual,
+                       relu, y, H, W, K, th, tw, T);
+    OCR_HIP(hipGetLastError());
+    return;
+  }
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   const long long T = (long long)N * th * tw;
   const long long threads = T * (K / 4);

@@ -160,6 +160,34 @@ def test_winograd_conv_matches_aten(det, case):
     _check(got, ref, False)
 
 
+W43_CASES = [
+    (2, 20, 20, 512, 512, True, True, True),     # layer4 grid at 640x640: 5 x 5 tiles per image
+    (1, 40, 40, 256, 256, True, True, True),     # layer3 grid
+    (1, 9, 21, 256, 256, True, False, True),     # ragged tiles: 9 = 2 * 4 + 1, 21 = 5 * 4 + 1
+    (3, 3, 5, 256, 512, False, False, False),    # smaller than a tile one way, ragged the other, Cin != Cout
+    (1, 1, 1, 512, 512, True, True, False),      # a single pixel
+    (2, 6, 7, 64, 64, False, True, True),        # few channels
+]
+
+
+@pytest.mark.parametrize("case", W43_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_winograd43_conv_matches_aten(det, case):
+    """Winograd F(4x4,3x3) path (36-component weight transform, input transform, batched GEMM, output transform with the
+    epilogue) against ATen's direct conv2d on the same operands.  Its transforms multiply by up to 8 and cancel more than
+    F(2x2)'s, so the bar is 1e-4 of the layer's scale (measured: about 1e-5)."""
+    n, h, w, cin, cout, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:5]) & 0xFFFF)
+    x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
+    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, h, w, cout), dtype=np.float32) if has_res else None
+    got = det.debug_winograd_conv(x, wg, scale, bias, res, relu, unfused=3)
+    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
+    err = float(np.abs(got - ref).max()) / (float(np.abs(ref).max()) + 1e-12)
+    assert err < 1e-4, err
+
+
 WS_CASES = [c for c in WINO_CASES if c[3] in (64, 128, 256) and c[4] % 64 == 0] + [
     (1, 40, 40, 256, 64, False, False, False),   # out4 (256 -> 64): eight channel chunks
     (2, 24, 48, 256, 256, True, True, True),     # layer3-like, four output-channel blocks share a patch
