@@ -66,6 +66,8 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   winograd=<cin>|0     (256)  unfused Winograd for 3x3 s1 trunk convs with Cin >= cin that have no fused form; 0 = off
  *   winograd43=<cin>|0   (256)  of those, the layers with Cin >= cin use F(4x4,3x3) (36 products per 16 outputs) instead of
  *                               F(2x2,3x3) (16 per 4); 0 = F(2x2) everywhere
+ *   winograd43_fused=<cin>|0 (128)  convs of the fused family with Cin <= cin run the fused F(4x4,3x3) kernel
+ *                               (winograd43_fused.hip); 0 = the fused F(2x2,3x3) kernel everywhere
  *   winograd_fused_max_cin=<cin> (128)  trunk layers with more channels than this leave the fused kernel to the unfused path
  *                               (256 puts layer3 back on the fused F(2x2) kernel)
  *   fpn_unfused=0|1      (0)    1 = layer-by-layer FPN (laterals, top-down sums, out_k, gathered bin_conv1) as model.rs writes it

@@ -147,6 +147,11 @@ void Detector::add_winograd_weights(ConvW& cw) {
 
 void Detector::add_winograd_fused_weights(ConvW& cw) {
   if ((cw.cin != 64 && cw.cin != 128 && cw.cin != 256) || cw.cout % 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd: unsupported conv shape");
+  if (cw.cin <= winograd43_fused_max_cin_ && (cw.cin == 64 || cw.cin == 128)) {
+    cw.wino43_fused = arena_.upload(winograd43_fragments(winograd_weights(cw.host.data(), cw.cout, cw.cin, 4), cw.cout, cw.cin));
+    cw.wino_fused = cw.wino43_fused;  // "has a fused form"
+    return;
+  }
   std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin);
   if (winograd_ws_) {
     cw.wino_ws = arena_.upload(winograd_ws_fragments(u, cw.cout, cw.cin));
@@ -229,6 +234,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "winograd_ws") winograd_ws_ = num() != 0;
     else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "winograd_fused_max_cin") winograd_fused_max_cin_ = num();
+    else if (key == "winograd43_fused") winograd43_fused_max_cin_ = num();
     else if (key == "winograd43") winograd43_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
@@ -763,6 +769,15 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
   auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual,
                      bool relu = true) {
     if (!bf && cw.wino_fused) {  // 64 -> 64: transforms fused into the GEMM kernel
+      if (cw.wino43_fused) {
+        rec.begin();
+        launch_winograd43_fused(static_cast<const float*>(src), cw.wino43_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
+                                relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
+        const double px43 = (double)n * hh * ww;
+        rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : "winograd43_fused<c128>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
+                px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 4);
+        return;
+      }
       rec.begin();
       if (cw.wino_ws)
         launch_winograd_ws(static_cast<const float*>(src), cw.wino_ws, cw.scale, cw.bias, static_cast<const float*>(residual),

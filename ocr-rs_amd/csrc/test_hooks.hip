@@ -9,6 +9,7 @@
 
 using ocr::guard;
 using ocr::align256;
+namespace ocr { void winograd43_set_debug(int d); }
 #ifdef WS_STAMPS
 namespace ocr { void winograd_ws_read_stamps(long long* out); }
 #endif
@@ -219,7 +220,7 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     if (!det || !x || !wgt || !out) fail(OCR_ERR_INVALID, "null argument");
     OCR_HIP(hipSetDevice(det->impl.device()));
     hipStream_t s = det->impl.stream();
-    const size_t wm = unfused == 3 ? 4 : 2, wa = (wm + 2) * (wm + 2);   // unfused == 3: F(4x4,3x3), unfused
+    const size_t wm = unfused >= 3 ? 4 : 2, wa = (wm + 2) * (wm + 2);   // unfused == 3: F(4x4,3x3), unfused; 4: its fused kernel
     const size_t th = (h + wm - 1) / wm, tw = (w + wm - 1) / wm, T = (size_t)n * th * tw;
     const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
     const std::vector<float> u = winograd_weights(wgt, cout, cin, (int)wm);
@@ -240,6 +241,13 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     const float* d_sc = scale ? dev(scale, cout) : nullptr;
     const float* d_bi = bias ? dev(bias, cout) : nullptr;
     const float* d_res = residual ? dev(residual, out_e) : nullptr;
+    if (unfused == 4) {  // fused F(4x4,3x3)
+      float* d_uf = dev(winograd43_fragments(u, cout, cin).data(), u.size());
+      launch_winograd43_fused(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
+      OCR_HIP(hipStreamSynchronize(s));
+      OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
+      return;
+    }
     if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && unfused == 2) {  // the wave-specialised fused kernel
       float* d_uf = dev(winograd_ws_fragments(u, cout, cin).data(), u.size());
       launch_winograd_ws(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
@@ -361,6 +369,7 @@ int ocr_test_comm_assemble(const ocr_polygons_t* const* shards, int world, ocr_p
   });
 }
 
+int ocr_test_w43_debug(int d) { ocr::winograd43_set_debug(d); return 0; }
 #ifdef WS_STAMPS
 int ocr_test_ws_stamps(long long* out) { ocr::winograd_ws_read_stamps(out); return 0; }
 #endif

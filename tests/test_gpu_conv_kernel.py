@@ -188,6 +188,34 @@ def test_winograd43_conv_matches_aten(det, case):
     assert err < 1e-4, err
 
 
+W43F_CASES = [
+    (2, 16, 32, 64, 64, True, True, True),       # whole 16 x 16 blocks
+    (1, 9, 21, 64, 64, True, False, True),       # ragged blocks and tiles
+    (3, 1, 1, 64, 64, False, False, False),      # single pixels
+    (2, 160, 160, 64, 64, True, True, True),     # layer1 grid at 640x640
+    (2, 80, 80, 128, 128, True, True, True),     # layer2: eight channel chunks, two output-channel blocks
+    (1, 13, 37, 128, 64, False, True, False),    # p3 lateral term (128 -> 64), ragged
+    (1, 8, 16, 64, 128, True, False, True),      # 64 -> 128
+    (5, 24, 40, 64, 64, True, True, False),
+]
+
+
+@pytest.mark.parametrize("case", W43F_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_winograd43_fused_conv_matches_aten(det, case):
+    """The fused F(4x4,3x3) kernel (winograd43_fused.hip) against ATen's direct conv2d, same bar as the unfused F(4x4) path."""
+    n, h, w, cin, cout, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:5]) & 0xFFFF)
+    x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
+    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, h, w, cout), dtype=np.float32) if has_res else None
+    got = det.debug_winograd_conv(x, wg, scale, bias, res, relu, unfused=4)
+    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
+    err = float(np.abs(got - ref).max()) / (float(np.abs(ref).max()) + 1e-12)
+    assert err < 1e-4, err
+
+
 WS_CASES = [c for c in WINO_CASES if c[3] in (64, 128, 256) and c[4] % 64 == 0] + [
     (1, 40, 40, 256, 64, False, False, False),   # out4 (256 -> 64): eight channel chunks
     (2, 24, 48, 256, 256, True, True, True),     # layer3-like, four output-channel blocks share a patch

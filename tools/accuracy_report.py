@@ -18,6 +18,7 @@ w = W.make_det_weights(0)
 x = W.synth_image_batch(5, n, s, s)
 ref = T.det_forward(w, x)
 for label, options in (("default (composed FPN, fused Winograd, single-launch bin_conv1)", None),
+                       ("winograd43_fused=128 (layer1, layer2, FPN laterals on the fused F(4x4,3x3) kernel)", "winograd43_fused=128"),
                        ("winograd43=0 (layer4 as F(2x2,3x3))", "winograd43=0"),
                        ("winograd43=256;winograd_fused_max_cin=128 (layer3 and layer4 as F(4x4,3x3))", "winograd43=256;winograd_fused_max_cin=128"),
                        ("winograd_fused=0", "winograd_fused=0"),
