@@ -412,10 +412,11 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (ms, fl, by, cnt) = dom
         # the engine reports the MFMA FLOPs a launch EXECUTES: `achieved` / `frac` are matrix-core utilisation.
-        # A fused Winograd F(2x2,3x3) launch is a 3x3 conv whose direct-algorithm work (2 M N 9C, what SURVEY 8d
-        # counts for the reference graph) is 36/16 of that; it is reported beside, never as the fraction.
+        # A fused Winograd launch is a 3x3 conv whose direct-algorithm work (2 M N 9C, what SURVEY 8d counts for the
+        # reference graph) is 36/16 (F(2x2,3x3)) or 4 times (F(4x4,3x3)) that; it is reported beside, never as the fraction.
         executed = fl / (ms * 1e-3) / 1e12
-        alg_factor = 36.0 / 16.0 if name.startswith("winograd_fused") else 1.0
+        # direct-algorithm multiplies per executed one: F(2x2,3x3) 36/16, F(4x4,3x3) 144/36
+        alg_factor = 4.0 if name.startswith("winograd43_fused") else 36.0 / 16.0 if name.startswith("winograd_fused") else 1.0
         executed_gflop = sum(v[1] for v in agg.values()) / reps / 1e9
         traffic, traffic_source = pmc_traffic(name, n, s)
         roof = {"kernel": name, "bound": "mfma", "achieved": round(executed, 2), "peak": peak,

@@ -8,17 +8,23 @@
 // (36 x v_mfma_f32_16x16x4_f32 tiles = 144 registers) hold every component of a (tile, channel) pair in ONE lane:
 // the output transform Y = A^T M A needs no exchange between lanes or waves.  The input channels are walked in
 // chunks of 16:
-//     patch  18 x 18 px x 16 ch (20.25 KB) by LDS-DMA, double-buffered: chunk c + 1 (or the next block's chunk 0) streams in
-//            while chunk c is used
+//     patch  18 x 18 px x 16 ch (20.5 KB with the row padding) by LDS-DMA, double-buffered: chunk c + 1 (or the next block's
+//            chunk 0) streams in while chunk c is used
 //     V = B^T d B   one (tile, channel) item per thread: 36 LDS reads, ~110 VALU, 36 LDS writes -> V[36][16][16] in LDS (36 KB)
 //     M_xi += V_xi [16 x 16] * U_xi [16 x 16]   4 MFMAs per component; the A operand is one ds_read_b128 of V, the B operand
 //                                               comes straight from global memory (L2-resident, host-side fragment order:
 //                                               one 16-byte load per lane and component), prefetched nine components ahead
 // then the output transform in registers, the 16 x 16 x 64 result block staged through LDS (reusing the patch / V space)
 // so that folded BN, residual, ReLU and the stores run on whole 256-byte pixel rows.
-// LDS: 2 x 20.25 KB + 36 KB = 76.5 KB, two workgroups per CU - one multiplies while the other transforms or stores.
+// LDS: 2 x 20.5 KB + 36 KB = 77 KB, two workgroups per CU - one multiplies while the other transforms or stores.
+//
+// The B loads are inline asm with hand-counted s_waitcnt (a compiler-visible load next to the LDS-DMA makes hipcc wait for
+// the DMA too).  The compiler believes such a register is valid as soon as the asm statement has run, so the code keeps every
+// load's issue, wait and use inside one straight-line chunk body; tests/test_gpu_conv_kernel.py (eight shapes, all 36
+// components, every chunk) and the end-to-end parity tests run the shipped binary and fail on any stale operand.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -57,20 +63,29 @@ struct W43Args {
 };
 
 constexpr int PP = 18;                          // patch rows / columns
-constexpr int PATCH_BYTES = PP * PP * 64;       // 18 x 18 px x 16 channels = 20736 B
+constexpr int PITCH = PP * 64 + 16;             // bytes per patch row: 18 px x 16 channels, + 16 so that tile rows (4 patch rows apart)
+                                                // alternate between the two halves of the banks (4 * PITCH = 64 mod 128)
+constexpr int PATCH_BYTES = PP * PITCH;         // 21024 B
 constexpr int V_OFF = 2 * PATCH_BYTES;          // V[36][16 tiles][16 ch] f32
 constexpr int V_BYTES = 36 * 1024;
-constexpr int LDS_BYTES = V_OFF + V_BYTES;      // 78336: two workgroups per CU
+constexpr int LDS_BYTES = V_OFF + V_BYTES;      // 78912: two workgroups per CU
 constexpr unsigned OOB = 0x80000000u;
 #ifdef W43_DEBUG
 #define W43_DBG(p, bit) ((p).debug & (bit))
 #else
 #define W43_DBG(p, bit) false
 #endif
-#define W43_STR2(x) #x
-#define W43_STR(x) W43_STR2(x)
-#ifndef W43_PATCH_WAIT
-#define W43_PATCH_WAIT 18
+#ifdef W43_STAMPS
+// diagnostic build only (make EXTRA=-DW43_STAMPS): s_memtime of workgroup 0, waves 0 and 1, at the phase boundaries of its
+// first four blocks; kept in LDS during the kernel and copied out at the end (tools/w43_stamps.py)
+__device__ long long g_w43_stamps[2 * 4 * 32];
+#define W43_STAMP(k)                                                                                     \
+  do {                                                                                                   \
+    if (blockIdx.x == 0 && wave < 2 && lane == 0 && blk_count < 4)                                       \
+      stamp_lds[(wave * 4 + blk_count) * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime();            \
+  } while (0)
+#else
+#define W43_STAMP(k) do {} while (0)
 #endif
 static_assert(128 * 64 * 4 <= V_BYTES, "half of the staged result block fits the V space");
 
@@ -84,6 +99,27 @@ __device__ __forceinline__ void bt6(const float d0, const float d1, const float 
   t[3] = c + e;
   t[4] = c - e;
   t[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// B^T for two independent columns (or rows) at once: v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32
+__device__ __forceinline__ void bt6x2(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
+                                      f32x2* t) {
+  const f32x2 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+  t[0] = 4.f * d0 - 5.f * d2 + d4;
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+// the same for two tiles at once (v_pk_add_f32 / v_pk_fma_f32: the two halves are registers r, r + 1 of an accumulator)
+__device__ __forceinline__ void at6x2(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
+                                      f32x2* y) {
+  const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+  y[0] = m0 + s12 + s34;
+  y[1] = d12 + 2.f * d34;
+  y[2] = s12 + 4.f * s34;
+  y[3] = d12 + 8.f * d34 + m5;
 }
 __device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
                                     float* y) {
@@ -99,6 +135,10 @@ template <int NCH>
 __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+#ifdef W43_STAMPS
+  __shared__ long long stamp_lds[2 * 4 * 32];
+  int blk_count = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -133,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
       const int yy = y0_ - 1 + row;
       const bool row_ok = (unsigned)yy < (unsigned)p.H;
       const unsigned soff = row_ok ? (unsigned)(((n_ * p.H + yy) * p.W * p.C + c * 16) * 4) : 0u;
-      const unsigned dst = lds0 + (unsigned)(buf * PATCH_BYTES + row * (PP * 64) + part * 1024);
+      const unsigned dst = lds0 + (unsigned)(buf * PATCH_BYTES + row * PITCH + part * 1024);
       const unsigned voff = row_ok ? pvoff : OOB;
       if (!W43_DBG(p, 4) && (part == 0 || lane < 8)) dma16(x_rsrc, __builtin_amdgcn_readfirstlane(dst), voff, __builtin_amdgcn_readfirstlane(soff));
     }
@@ -151,16 +191,23 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
     }
   };
 
-  // transform item of this thread: tile (ty, tx), channel ch of the chunk
-  const int t_tile = tid >> 4, t_ch = tid & 15;
-  const int t_src = ((4 * (t_tile >> 2)) * PP + 4 * (t_tile & 3)) * 64 + t_ch * 4;
-  // A operand of this lane: V[comp][tile = lane & 15][channels 4 (lane >> 4) .. + 3]
-  const unsigned char* a_ptr = lds + V_OFF + (lane & 15) * 64 + (lane >> 4) * 16;
+  // transform item of this thread: tile column tx = wave, tile row ty, channel ch of the chunk - the four tile rows of a wave
+  // read patch rows 4 apart (two bank halves: the natural two cycles of a 64-lane ds_read_b32) and write 256 contiguous
+  // bytes of V.  GEMM row of a tile = 4 tx + ty.
+  const int t_ch = tid & 15, t_ty = (tid >> 4) & 3;
+  const int t_src = 4 * t_ty * PITCH + 4 * wave * 64 + t_ch * 4;
+  // V layout: component (1 KB) x channel group g = ch >> 2 (256 B) x GEMM row (16 B = the group's four channels), the row
+  // XORed with 4 (g & 1): the A operand of lane (row = lane & 15, g = lane >> 4) is one ds_read_b128 and eight consecutive
+  // lanes read 128 contiguous bytes (conflict-free; rows 64 B apart would be a 4-way conflict on every read), while the
+  // transform's ds_write_b32 of a wave (4 rows x 16 channels) spreads over both bank halves.
+  const int v_dst = V_OFF + (t_ch >> 2) * 256 + ((4 * wave + t_ty) ^ (((t_ch >> 2) & 1) << 2)) * 16 + (t_ch & 3) * 4;
+  const unsigned char* a_ptr = lds + V_OFF + (lane >> 4) * 256 + ((lane & 15) ^ (((lane >> 4) & 1) << 2)) * 16;
 
   bool patch_in_flight = false;  // chunk 0 of this block's patch was requested during the previous block
   for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
     int n, y0, x0;
     coords(blk, n, y0, x0);
+    W43_STAMP(0);
     const bool has_next_block = blk + (int)gridDim.x < p.nblocks;
     if (!patch_in_flight) {
       patch_columns(x0);
@@ -170,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
     patch_in_flight = false;
 
     f32x4 acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int c = 0; c < NCH; ++c) {
+    auto chunk = [&](const int c, auto first) {
       // this wave's share of patch c has landed: it went out at step 0 of the previous chunk and the wait of step 4 there
       // covered it (first block: the wait above)
+      W43_STAMP(1 + 4 * c);
       __syncthreads();  // ... every wave's; and nobody still reads the V of the previous chunk
+      W43_STAMP(2 + 4 * c);
       // the B stream of a chunk starts here (the transform covers its latency) and drains inside the chunk: a value loaded by
       // inline asm must not be in flight across the loop's back edge, where the compiler may copy registers it believes ready
       issue_b(c * 12 + 0, ring[0]);
@@ -184,25 +231,40 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
       issue_b(c * 12 + 2, ring[2]);
       if (!W43_DBG(p, 2)) {
         const unsigned char* pb = lds + (c & 1) * PATCH_BYTES + t_src;
-        float rt[6][6];
+        // packed math on register pairs: the column step on pairs of patch columns, the halves regrouped into pairs of rows
+        // (v_pk_mov_b32), the row step on those - 36 + 18 + 36 VALU instead of 144.  Every VALU instruction here competes
+        // with the other workgroup's MFMAs for the same pipe and waits up to a whole MFMA (32 cycles) for its slot.
+        f32x2 tc[6][3];  // (B^T d)[i][2 jp], [i][2 jp + 1]
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          float d[6], t[6];
+        for (int jp = 0; jp < 3; ++jp) {
+          f32x2 d[6], t[6];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float*>(pb + (i * PP + j) * 64);
-          bt6(d[0], d[1], d[2], d[3], d[4], d[5], t);
+          for (int i = 0; i < 6; ++i) {
+            d[i].x = *reinterpret_cast<const float*>(pb + i * PITCH + (2 * jp) * 64);
+            d[i].y = *reinterpret_cast<const float*>(pb + i * PITCH + (2 * jp + 1) * 64);
+          }
+          bt6x2(d[0], d[1], d[2], d[3], d[4], d[5], t);
 #pragma unroll
-          for (int i = 0; i < 6; ++i) rt[i][j] = t[i];
+          for (int i = 0; i < 6; ++i) tc[i][jp] = t[i];
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          float o[6];
-          bt6(rt[i][0], rt[i][1], rt[i][2], rt[i][3], rt[i][4], rt[i][5], o);
+        for (int ip = 0; ip < 3; ++ip) {
+          f32x2 r[6], o[6];  // rows 2 ip, 2 ip + 1 of B^T d, column j
 #pragma unroll
-          for (int j = 0; j < 6; ++j) *reinterpret_cast<float*>(lds + V_OFF + (6 * i + j) * 1024 + tid * 4) = o[j];
+          for (int j = 0; j < 6; ++j)
+            r[j] = (j & 1) ? __builtin_shufflevector(tc[2 * ip][j >> 1], tc[2 * ip + 1][j >> 1], 1, 3)
+                           : __builtin_shufflevector(tc[2 * ip][j >> 1], tc[2 * ip + 1][j >> 1], 0, 2);
+          bt6x2(r[0], r[1], r[2], r[3], r[4], r[5], o);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            *reinterpret_cast<float*>(lds + v_dst + (6 * (2 * ip) + j) * 1024) = o[j].x;
+            *reinterpret_cast<float*>(lds + v_dst + (6 * (2 * ip + 1) + j) * 1024) = o[j].y;
+          }
         }
       }
+      W43_STAMP(3 + 4 * c);
       __syncthreads();  // V of chunk c is complete
+      W43_STAMP(4 + 4 * c);
       const bool last_chunk = c + 1 == NCH;
       const bool has_patch = !last_chunk || has_next_block;
       f32x4 acur[3], anext[3];
@@ -211,7 +273,9 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
         // issue order of a chunk: ... T(t+1) T(t+2) | step t: T(t+3) [, the next patch at t = 0].  Behind triple t are the
-        // three triples after it (9 loads) and, at t = 0..3, the nine patch loads; the stream drains at the chunk's end
+        // three triples after it (9 loads) and, at t = 0..3, the nine patch loads; the stream drains at the chunk's end.
+        // (Requesting the patch two chunks ahead at the END of the matrix phase instead - legal, its buffer is free once the
+        // transform is done - forces it at the next chunk's first B wait: 0.218 vs 0.208 ms.)
         if (t < 9) issue_b(c * 12 + t + 3, ring[(t + 3) & 3]);
         if (t == 0 && has_patch) {
           if (last_chunk) {
@@ -228,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
         if (t < 4) {
-          if (has_patch) asm volatile("s_waitcnt vmcnt(" W43_STR(W43_PATCH_WAIT) ")" ::: "memory");
+          if (has_patch) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         } else if (t < 9) {
           asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -252,20 +316,28 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int q = 0; q < 3; ++q)
-            acc[3 * t + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[q][e], b[q][e], acc[3 * t + q], 0, 0, 0);
+            acc[3 * t + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[q][e], b[q][e],
+                                                                  (decltype(first)::value && e == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[3 * t + q], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) acur[q] = anext[q];
       }
-    }
+    };
+    // (Touching the residual block's lines one chunk ahead - 4 bytes per line into a dump area - made the epilogue's loads L2
+    // hits but cost more than it gave: 0.212 vs 0.207 ms.)
+    // (peeling chunk 0 to start the accumulators from a constant-zero C operand saves 144 v_mov per block, but the peeled
+    // code made the compiler copy B registers whose inline-asm loads were still in flight - wrong results; kept as a loop)
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCH; ++c) chunk(c, std::false_type{});
 
-    // ---- output transform in registers: lane = (output channel wave * 16 + (lane & 15), tile row ty = lane >> 4), register
-    // r of a component = tile column tx.  The result block goes through LDS in two halves of 8 pixel columns (32 KB inside
-    // the V space: patch buffer 0 may already hold the next block's first chunk) so that folded BN, residual, ReLU and the
-    // stores run on whole 256-byte pixel rows.
+    // ---- output transform in registers: lane = (output channel wave * 16 + (lane & 15), tile column tx = lane >> 4), register
+    // r of a component = tile row ty.  The result block goes through LDS in two halves of 8 pixel rows (32 KB inside the V
+    // space: patch buffer 0 may already hold the next block's first chunk) so that folded BN, residual, ReLU and the stores
+    // run on whole 256-byte pixel rows.
     {
-      const int ty = lane >> 4;
-      const int col = ((wave * 16 + (lane & 15)) + 16 * ty) & 63;  // rotated by the tile row: the four rows of a store hit different banks
+      const int tx = lane >> 4;
+      const int col = ((wave * 16 + (lane & 15)) + 16 * tx) & 63;  // rotated by the tile column: the four tiles of a store hit different banks
       const int c4 = (tid & 15) * 4;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
@@ -275,8 +347,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         // residual of this half, requested before the transform so that its latency hides behind it
         f32x4 res[8];
         auto out_index = [&](int k, bool& ok) -> unsigned {   // element index of item k of this thread (y < 2^31 bytes)
-          const int pl = k * 16 + (tid >> 4);                 // pixel of the half: row pl >> 3, column 8 h + (pl & 7)
-          const int yy = y0 + (pl >> 3), xx = x0 + 8 * h + (pl & 7);
+          const int yy = y0 + 8 * h + k, xx = x0 + (tid >> 4);  // pixel k * 16 + (tid >> 4) of the half: row k, column tid >> 4
           ok = yy < p.H && xx < p.W;
           return (unsigned)(((n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4);
         };
@@ -287,32 +358,38 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
           res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (p.residual && ok) res[k] = *reinterpret_cast<const f32x4*>(p.residual + o);
         }
+        W43_STAMP(17 + 4 * h);
         __syncthreads();  // h = 0: every wave is done with V; h = 1: the first half has been read
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int r = 2 * h + rr;
-          float u[4][6];
+        W43_STAMP(18 + 4 * h);
+        {
+          // tile rows 2 h and 2 h + 1 together: registers 2 h, 2 h + 1 of every accumulator as one packed pair
+          auto pr = [&](int comp) { return h == 0 ? acc[comp].xy : acc[comp].zw; };
+          f32x2 u[4][6];
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            float t[4];
-            at6(acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r], t);
+            f32x2 t[4];
+            at6x2(pr(j), pr(6 + j), pr(12 + j), pr(18 + j), pr(24 + j), pr(30 + j), t);
 #pragma unroll
             for (int a = 0; a < 4; ++a) u[a][j] = t[a];
           }
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-            float o[4];
-            at6(u[a][0], u[a][1], u[a][2], u[a][3], u[a][4], u[a][5], o);
+            f32x2 o[4];
+            at6x2(u[a][0], u[a][1], u[a][2], u[a][3], u[a][4], u[a][5], o);
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-              *reinterpret_cast<float*>(lds + V_OFF + (((4 * ty + a) * 8 + 4 * rr + b) * 64 + col) * 4) = o[b];
+            for (int b = 0; b < 4; ++b) {
+              *reinterpret_cast<float*>(lds + V_OFF + ((a * 16 + 4 * tx + b) * 64 + col) * 4) = o[b].x;
+              *reinterpret_cast<float*>(lds + V_OFF + (((4 + a) * 16 + 4 * tx + b) * 64 + col) * 4) = o[b].y;
+            }
           }
         }
+        W43_STAMP(19 + 4 * h);
         __syncthreads();
+        W43_STAMP(20 + 4 * h);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int pl = k * 16 + (tid >> 4);
-          f32x4 v = *reinterpret_cast<const f32x4*>(lds + V_OFF + (pl * 64 + ((c4 + 16 * (pl >> 5)) & 63)) * 4);
+          f32x4 v = *reinterpret_cast<const f32x4*>(lds + V_OFF + (pl * 64 + ((c4 + 16 * (tid >> 6)) & 63)) * 4);
           v = v * sc + bi + res[k];
           if (p.relu) {
 #pragma unroll
@@ -324,11 +401,23 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         }
       }
     }
+    W43_STAMP(25);
+#ifdef W43_STAMPS
+    ++blk_count;
+#endif
   }
+#ifdef W43_STAMPS
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 2 * 4 * 32) g_w43_stamps[tid] = stamp_lds[tid];
+#endif
 #endif
 }
 
 }  // namespace
+
+#ifdef W43_STAMPS
+void winograd43_read_stamps(long long* out) { OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w43_stamps), sizeof(g_w43_stamps))); }
+#endif
 
 // u: winograd_weights(..., 4) = [36][Cout][Cin] -> [Cout / 64][Cin / 16][36][wave 4][lane 64][4]: element e of lane l of
 // wave w is U[comp][cout = kb * 64 + 16 w + (l & 15)][cin = 16 c + 4 (l >> 4) + e] - what MFMA e of the chunk reads as its B
