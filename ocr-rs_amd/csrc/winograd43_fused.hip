@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
     };
     // (Touching the residual block's lines one chunk ahead - 4 bytes per line into a dump area - made the epilogue's loads L2
     // hits but cost more than it gave: 0.212 vs 0.207 ms.)
-    // (peeling chunk 0 to start the accumulators from a constant-zero C operand saves 144 v_mov per block, but the peeled
-    // code made the compiler copy B registers whose inline-asm loads were still in flight - wrong results; kept as a loop)
+    // (starting the accumulators from a constant-zero C operand in chunk 0 - peeled, or as a branch inside the loop - saves
+    // 144 v_mov per block but gave wrong results with this compiler and no speed-up: 0.211 vs 0.208 ms; kept as a loop)
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < NCH; ++c) chunk(c, std::false_type{});

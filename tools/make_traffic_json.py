@@ -31,6 +31,11 @@ def pretty(name: str) -> str:
                "winograd_fused<c256>" if "winograd_fused_kernel<8>" in name else \
                "rec_conv<4>" if "rec_conv_kernel<4>" in name else "rec_conv<2>" if "rec_conv_kernel<2>" in name else \
                "rec_conv<1>" if "rec_conv_kernel<1>" in name else "rec_fc2_softmax_top1" if "rec_fc2_softmax" in name else \
+               "winograd43_fused<c64>" if "winograd43_fused_kernel<4>" in name else \
+               "winograd43_fused<c128>" if "winograd43_fused_kernel<8>" in name else \
+               "winograd43_input_transform" if "winograd43_input" in name else \
+               "winograd43_output_transform" if "winograd43_output" in name else \
+               "rec_conv_small" if "rec_conv_small" in name else "rec_fc1_small" if "rec_fc1_small" in name else \
                "winograd_input_transform" if "winograd_input" in name else \
                "winograd_output_transform" if "winograd_output" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
