@@ -199,6 +199,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 16 waves); conv2: wave w owns the 16 x 16 tile (pixel rows 2 (w >> 2), 2 (w >> 2) + 1 of the 8 x 8 output = four
 // pool windows, output channels 16 (w & 3) .. + 15).  Tile row 4 slot + sub is sub-pixel `sub` of window `slot`:
 // a lane's four accumulator registers are one window, the pool is a max over them.
+#ifdef REC_STAMPS
+__device__ long long g_rec_stamps[16];
+#define REC_STAMP(k) do { if (blockIdx.x == 0 && tid == 0) g_rec_stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define REC_STAMP(k) do {} while (0)
+#endif
 __global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __restrict__ crops, int n, const float* __restrict__ w1f,
                                                               const float* __restrict__ b1, const float* __restrict__ w2s,
                                                               const float* __restrict__ b2, float* __restrict__ feat) {
@@ -207,12 +213,14 @@ __global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int crop = blockIdx.x;
+  REC_STAMP(0);
   if (tid < IMG / 4) *reinterpret_cast<f32x4*>(img + tid * 4) = *reinterpret_cast<const f32x4*>(crops + (size_t)crop * IMG + tid * 4);
   float w1r[13];
 #pragma unroll
   for (int s = 0; s < 13; ++s) w1r[s] = w1f[s * 64 + lane];
   const float bias1 = b1[lane & 31];
   __syncthreads();
+  REC_STAMP(1);
   for (int tile = wave; tile < 18; tile += 16) {
     const int i = lane & 31, h = lane >> 5, j = lane & 31;
     const int wi = tile * 8 + (i >> 2);
@@ -232,7 +240,9 @@ __global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __res
     for (int g = 0; g < 4; ++g)
       p1[p1_index(tile * 8 + 2 * g + h, j)] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias1;
   }
+  REC_STAMP(2);
   __syncthreads();
+  REC_STAMP(3);
   // conv2: 16 x 16 x 4 MFMA, lane (row r = lane & 15, k slot q = lane >> 4)
   const int r = lane & 15, q = lane >> 4;
   const int rt = wave >> 2, ct = wave & 3;
@@ -272,12 +282,14 @@ __global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __res
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[2 * (g & 1) + 1], acc, 0, 0, 0);
     }
   }
+  REC_STAMP(4);
   // C/D map of 16x16x4: column = lane & 15, rows 4 q .. 4 q + 3 in the four registers = window q of this tile.
   // feat goes out in the operand order of rec_fc1_small_kernel (see there): k = co * 16 + p of crop `crop`
   const int co = 16 * ct + r;
   const float v = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + b2[co];
   const int kk = co * 16 + 4 * rt + q;
   feat[((((size_t)(crop >> 4) * 128 + (kk >> 3)) * 2 + ((kk >> 2) & 1)) * 16 + (crop & 15)) * 4 + (kk & 3)] = v;
+  REC_STAMP(5);
 }
 
 // fc1 + bias + ReLU for small batches: wave = one 16 crops x 16 outputs tile over the whole K = 1024 as 256 dependent
@@ -407,6 +419,10 @@ __global__ __launch_bounds__(1024) void rec_fc2_softmax_kernel(const float* __re
 }
 
 }  // namespace
+
+#ifdef REC_STAMPS
+void rec_read_stamps(long long* out) { OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rec_stamps), sizeof(g_rec_stamps))); }
+#endif
 
 // conv1 [32][1][5][5] -> [13 steps][64 lanes]: lane (j = l & 31, h = l >> 5) of step s holds w[j][k = 2 s + h] (0 for k = 25)
 std::vector<float> rec_conv1_fragments(const float* w) {
