@@ -89,6 +89,9 @@ def launch_ranks(n: int, argv) -> int:
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            # N ranks share one host: keep each rank's OpenMP / ATen pool small (torch.distributed.run does the same); the
+            # library's own post-processing pool is capped at 16 threads per detector
+            env.setdefault("OMP_NUM_THREADS", "4")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                           stdout=out0 if r == 0 else subprocess.DEVNULL))
         # a rank that dies leaves the others waiting in a rendezvous or a collective: end them (these exact
