@@ -54,7 +54,7 @@ struct W43Args {
   const float* bias;
   const float* residual;  // [N][H][W][K], may be null
   float* y;               // [N][H][W][K]
-  unsigned x_bytes, u_bytes;
+  unsigned x_bytes, u_bytes, y_bytes;
   int H, W, bh, bw;       // block grid: bh x bw blocks of 16 x 16 pixels per image
   int C, K, kblocks;      // channels in / out, K / 64
   int relu;
@@ -143,6 +143,12 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ufrag), 0, p.u_bytes, 0x00020000);
+  // result and residual through buffer descriptors as well: the row part of an address is scalar, the column / channel part
+  // one register per lane (out-of-range columns carry an out-of-range voffset: loads return zero, stores are dropped), no
+  // per-access VALU address arithmetic and no divergent branches.  No residual = an empty descriptor: every load reads zero.
+  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : p.x), 0,
+                                                        p.residual ? p.y_bytes : 0u, 0x00020000);
   const unsigned lds0 = (unsigned)(size_t)(lds_void*)lds;
 
   // block -> (image, pixel block, output-channel block); innermost kb: the K / 64 workgroups of a pixel block share its
@@ -342,21 +348,24 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
       if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + kb * 64 + c4);
+      // this lane's pixel column (tid >> 4) and channels c4 .. c4 + 3 of the block, as a byte offset inside an image row
+      const int ep_xx = x0 + (tid >> 4);
+      const unsigned ep_v = ep_xx < p.W ? (unsigned)((ep_xx * p.K + kb * 64 + c4) * 4) : OOB;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         // residual of this half, requested before the transform so that its latency hides behind it
         f32x4 res[8];
-        auto out_index = [&](int k, bool& ok) -> unsigned {   // element index of item k of this thread (y < 2^31 bytes)
-          const int yy = y0 + 8 * h + k, xx = x0 + (tid >> 4);  // pixel k * 16 + (tid >> 4) of the half: row k, column tid >> 4
-          ok = yy < p.H && xx < p.W;
-          return (unsigned)(((n * p.H + yy) * p.W + xx) * p.K + kb * 64 + c4);
+        auto row_offset = [&](int k, bool& ok) -> unsigned {   // byte offset of image row y0 + 8 h + k (scalar; y < 2^31 bytes)
+          const int yy = y0 + 8 * h + k;
+          ok = yy < p.H;
+          return (unsigned)(((n * p.H + yy) * p.W * p.K) * 4);
         };
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           bool ok;
-          const unsigned o = out_index(k, ok);
+          const unsigned so = row_offset(k, ok);
           res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (p.residual && ok) res[k] = *reinterpret_cast<const f32x4*>(p.residual + o);
+          if (ok) res[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ep_v, __builtin_amdgcn_readfirstlane(so), 0));
         }
         W43_STAMP(17 + 4 * h);
         __syncthreads();  // h = 0: every wave is done with V; h = 1: the first half has been read
@@ -396,8 +405,9 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           bool ok;
-          const unsigned o = out_index(k, ok);
-          if (ok && !W43_DBG(p, 8)) *reinterpret_cast<f32x4*>(p.y + o) = v;
+          const unsigned so = row_offset(k, ok);
+          if (ok && !W43_DBG(p, 8))
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, ep_v, __builtin_amdgcn_readfirstlane(so), 0);
         }
       }
     }
@@ -454,6 +464,7 @@ void launch_winograd43_fused(const float* x, const float* ufrag, const float* sc
   a.residual = residual;
   a.y = y;
   a.x_bytes = (unsigned)xb;
+  a.y_bytes = (unsigned)((long long)N * H * W * K * 4);
   a.u_bytes = (unsigned)ub;
   a.H = H;
   a.W = W;
