@@ -585,8 +585,8 @@ static void check(const ConvDesc& d) {
   if (d.src_mode == SRC_PYR4) {
     // rows = cells of the p5 grid (Hin x Win), output [N][8 Hin][8 Win][64], four 64-channel sources in ONE allocation
     if (!phase2 || d.up != 8 || d.ks != 3 || d.stride != 1 || d.pad != 0 || d.Cin != 64 || d.Cout != 64 || d.Ho != d.Hin ||
-        d.Wo != d.Win || d.out2 || d.residual || !d.out || d.in_bf16 || d.out_bf16 || d.batch > 1)
-      fail(OCR_ERR_INVALID, "%s: PYR4 needs the f32 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
+        d.Wo != d.Win || d.out2 || d.residual || !d.out || (d.out_bf16 && !d.in_bf16) || d.batch > 1)
+      fail(OCR_ERR_INVALID, "%s: PYR4 needs the 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
     if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large", d.name);
     if ((long long)d.wgt_bytes != 64ll * d.Cout * 21 * 64 * eb) fail(OCR_ERR_INVALID, "%s: PYR4 weight bytes", d.name);
     if ((long long)d.src_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: sources must be < 2^31 bytes; split the batch", d.name);
@@ -662,7 +662,7 @@ static Tile pick_tile(const ConvDesc& d) {
   const long long M = (long long)d.N * d.Ho * d.Wo;
   const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : (d.batch > 1 ? d.batch : 1);
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
-  if (d.src_mode == SRC_PYR4) return T64x64;
+  if (d.src_mode == SRC_PYR4) return T64x64;  // bf16 too: 0.254 vs 0.265 ms with 128x64
   if (d.in_bf16 && d.ks > 1) return (d.Cout % 128 == 0 && d.Cin >= 256) ? T128x128 : T128x64;
   if ((d.ks > 1 || d.batch > 1) && d.src_mode == SRC_PLAIN) return T64x64;
   if (d.Cout % 128 == 0 && blocks(128, 128) >= 2048) return T128x128;
@@ -698,6 +698,8 @@ static void launch_tiles(const ConvDesc& d, hipStream_t s) {
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
   if (d.in_bf16) {
+    if (d.src_mode == SRC_PYR4 && !d.out_bf16) return launch_inst<__bf16, float, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
+    if (d.src_mode == SRC_PYR4) return launch_inst<__bf16, __bf16, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
     if (d.store_mode == STORE_PHASE && !d.out_bf16) return launch_tiles<__bf16, float, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
     if (d.store_mode == STORE_PHASE) return launch_tiles<__bf16, __bf16, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
     if (d.ks == 3 && d.stride == 1 && !d.out_bf16 && d.src_mode == SRC_PLAIN) return launch_tiles<__bf16, float, 3, 1, SRC_PLAIN, STORE_NHWC>(d, s);

@@ -438,6 +438,7 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   if (fpn_composed_) {
     for (int l = 0; l < 3; ++l) all_convs_.push_back(&bin_up_[l]);
     all_convs_.push_back(&bin_p2_);
+    if (bin_pyr_on_) all_convs_.push_back(&bin_pyr_);
   }
   if (opt_bf16_) set_precision(1);
 }
@@ -946,13 +947,16 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
   }
   // fuse = cat[p5 x8, p4 x4, p3 x2, p2]; bin_conv1 + bin_bn1 + relu, model.rs:140-145
-  if (fpn_composed_ && !bf && bin_pyr_on_) {
+  if (fpn_composed_ && bin_pyr_on_ && (!bf || fused_tail_)) {
     // one launch: per output phase (y mod 8, x mod 8) the taps that phase needs from p5, p4, p3 and p2
     Extra py;
     py.pyr4 = true;
     py.store = STORE_PHASE;
-    py.f32_out = true;
-    if (bin_p2_.wino_fused) {
+    py.f32_out = !bf;  // bf16 precision: the fused head reads bf16
+    if (bf) {
+      // all four sources in the one phase launch (112.8 GF instead of the gathered conv's 241.6), bias + ReLU in its epilogue
+      conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+    } else if (bin_p2_.wino_fused) {
       // the three upsampled sources in the phase launch, p2's 3x3 term on top as a fused Winograd conv (+ bias, ReLU)
       py.pyr_nsrc = 3;
       ConvW up3 = bin_pyr_;
@@ -964,8 +968,8 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     }
   } else if (fpn_composed_ && !bf) {
     // the p2 quarter as a plain 3x3 conv and the three upsampled quarters as phase convs on their own grids;
-    // partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more
-    // HBM time than the skipped MFMA work saves, so that precision keeps the single gathered conv)
+    // partial sums live in b1.  (f32 only: in bf16 the f32 partial sums cost more HBM time than the skipped MFMA work
+    // saves; that precision takes all four sources in the one phase launch above, or the single gathered conv)
     for (int l = 1; l <= 2; ++l) {  // p4, then p5 with bias + ReLU (the p2 and p3 terms are in b1 already)
       Extra up;
       up.store = STORE_PHASE;
