@@ -285,9 +285,13 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       nt = pyr_taps(s, pa) * nw;
     }
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t)
+    for (int t = 0; t < NTAP; ++t) {
+      // PYR4: an upsampled source has at most 2 x 2 taps at a phase - the offsets of the others are never used, and this
+      // integer arithmetic (per source and tile: taps x rows x ~15 VALU) is time taken from the matrix pipe
+      if (SRC == SRC_PYR4 && t >= nt) continue;  // wave-uniform
 #pragma unroll
       for (int i = 0; i < AI; ++i) avoff[t][i] = tap_offset(s, t, i);
+    }
   };
   prep_source(0);
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds + (unsigned)(8 * wave * ROWB);
