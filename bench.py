@@ -496,6 +496,46 @@ def main():
                          "detect_postprocess_gather_note": "per step and rank: forward of its 32 frames, get_boxes_and_box_scores over 32 "
                                                            "text-like maps, all-gather of the polygon lists; sequential on one stream"})
 
+    # ---- configs[3] end to end at its best: every rank runs the library's pipelined detect (forward of batch k+1 under the
+    # post-processing of batch k) on synthetic pages with text-following weights, and the polygon lists of the batch that just
+    # came back are all-gathered each step.  Set-up may fail on a rank; the collective loop runs only if it worked on all.
+    if dist is not None and gathered is not None and not a.no_extras:
+        dt = xp = None
+        try:
+            dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local)
+            dt.set_stream(stream.cuda_stream)
+            pages, _ = W.synth_text_pages(77 + rank, n, s, s)
+            xp = torch.from_numpy(pages).to(x.device)
+            pr2 = [torch.empty_like(xp), torch.empty_like(xp)]
+            adj1 = np.ones((n, 2))
+            params = capi.default_params(skip_degenerate=True)
+            torch.cuda.synchronize()
+        except Exception as e:
+            post["detect_pipelined_gather_error"] = f"{type(e).__name__}: {e}"
+            dt = None
+        ok2 = torch.tensor([0.0 if dt is None else 1.0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+        if float(ok2.item()) > 0:
+            k = max(4, a.steps // 4)
+            images = 0
+            for it in range(2):                      # warm-up, then timed
+                fence()
+                t1 = time.perf_counter()
+                for j in range(k + 1):               # k batches in, one flush: k result blocks come back
+                    r = (dt.detect_pipelined(xp.data_ptr(), n, s, s, pr2[j & 1].data_ptr(), adj1, params) if j < k
+                         else dt.detect_pipelined(0, 0, 0, 0, 0))
+                    if r is not None:
+                        ap, _ = P.all_gather_results(r[0], r[1], comm_dev)
+                        images = len(ap)
+                fence()
+                e2e = max_over_ranks(time.perf_counter() - t1)
+            post["detect_pipelined_gather_images_per_s"] = round(n * world * k / e2e, 1)
+            post["detect_pipelined_gather_note"] = ("per rank: ocr_det_detect_pipelined over its 32 synthetic pages (forward of batch k+1 under "
+                                                    "the post-processing of batch k), all-gather of each returned polygon block "
+                                                    f"({images} images per gather)")
+        if dt is not None:
+            dt.close()
+
     # ---- detection END TO END on one GPU: forward + get_boxes_and_box_scores of the forward's own maps, software-
     # pipelined inside the library (ocr_det_detect_pipelined).  Random weights give noise maps, so this leg runs the
     # text-following synthetic weights on synthetic pages (weights.make_det_weights_text / synth_text_pages): same graph,
