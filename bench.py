@@ -276,6 +276,7 @@ def c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, loca
             emit(line)
         os._exit(0)
 
+    dist.barrier()  # rank 0 arrives last (it ran the extras): the deadline counts from the moment everyone is here
     timer = threading.Timer(deadline_s, expire)
     timer.daemon = True
     timer.start()
