@@ -84,8 +84,16 @@ __device__ long long g_w43_stamps[2 * 4 * 32];
     if (blockIdx.x == 0 && wave < 2 && lane == 0 && blk_count < 4)                                       \
       stamp_lds[(wave * 4 + blk_count) * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime();            \
   } while (0)
+// ... and inside the matrix phases of its third block: before / after the B wait of every step (W43_STEP(c, 2 t [+ 1]))
+__device__ long long g_w43_steps[2 * 4 * 26];
+#define W43_STEP(c, k)                                                                                   \
+  do {                                                                                                   \
+    if (blockIdx.x == 0 && wave < 2 && lane == 0 && blk_count == 2)                                      \
+      step_lds[(wave * 4 + (c)) * 26 + (k)] = (long long)__builtin_amdgcn_s_memtime();                   \
+  } while (0)
 #else
 #define W43_STAMP(k) do {} while (0)
+#define W43_STEP(c, k) do {} while (0)
 #endif
 static_assert(128 * 64 * 4 <= V_BYTES, "half of the staged result block fits the V space");
 
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 #ifdef W43_STAMPS
   __shared__ long long stamp_lds[2 * 4 * 32];
+  __shared__ long long step_lds[2 * 4 * 26];
   int blk_count = 0;
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
@@ -294,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
             issue_patch(n, y0, c + 1, (c + 1) & 1);
           }
         }
+        W43_STEP(c, 2 * t);
 #ifdef W43_SAFE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
@@ -310,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #endif
+        W43_STEP(c, 2 * t + 1);
         f32x4(&b)[3] = ring[t & 3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) settle(b[q]);
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
 #ifdef W43_STAMPS
   __syncthreads();
   if (blockIdx.x == 0 && tid < 2 * 4 * 32) g_w43_stamps[tid] = stamp_lds[tid];
+  if (blockIdx.x == 0 && tid < 2 * 4 * 26) g_w43_steps[tid] = step_lds[tid];
 #endif
 #endif
 }
@@ -426,7 +438,10 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
 }  // namespace
 
 #ifdef W43_STAMPS
-void winograd43_read_stamps(long long* out) { OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w43_stamps), sizeof(g_w43_stamps))); }
+void winograd43_read_stamps(long long* out) {
+  OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w43_stamps), sizeof(g_w43_stamps)));
+  OCR_HIP(hipMemcpyFromSymbol(out + 2 * 4 * 32, HIP_SYMBOL(g_w43_steps), sizeof(g_w43_steps)));
+}
 #endif
 
 // u: winograd_weights(..., 4) = [36][Cout][Cin] -> [Cout / 64][Cin / 16][36][wave 4][lane 64][4]: element e of lane l of

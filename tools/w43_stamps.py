@@ -19,9 +19,10 @@ wg = (rng.standard_normal((64, 9, 64), dtype=np.float32) / 24).astype(np.float32
 res = rng.standard_normal((32, 160, 160, 64), dtype=np.float32)
 for _ in range(2):
     det.debug_winograd_conv(x, wg, None, None, res, True, unfused=4)
-out = (ctypes.c_longlong * (2 * 4 * 32))()
+out = (ctypes.c_longlong * (2 * 4 * 32 + 2 * 4 * 26))()
 capi.test_lib().ocr_test_w43_stamps(out)
-a = np.array(out[:]).reshape(2, 4, 32)
+a = np.array(out[:2 * 4 * 32]).reshape(2, 4, 32)
+steps = np.array(out[2 * 4 * 32:]).reshape(2, 4, 26)
 names = {0: "block start"}
 for c in range(4):
     names[1 + 4 * c] = f"c{c} before top barrier"
@@ -45,3 +46,13 @@ for wv in range(2):
                 continue
             print(f"  {names[k]:40s} +{t - t0:6d}  (d {t - prev:5d})")
             prev = t
+
+print("--- matrix phases of block 2: per step, cycles waiting for B | cycles from the wait to the next step's wait")
+for wv in range(2):
+    for c in range(4):
+        st = steps[wv, c]
+        if st[0] == 0:
+            continue
+        waits = [int(st[2 * t + 1] - st[2 * t]) for t in range(12)]
+        body = [int(st[2 * (t + 1)] - st[2 * t + 1]) for t in range(11)]
+        print(f"  wave {wv} chunk {c}: wait {waits}  body {body}")
