@@ -74,6 +74,12 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches
  *   overlap=0|1|2        (0)    second stream for small independent launches (1) and the FPN branch (2)
+ *   mfma=split_bf16|f32  (split_bf16)  how the f32 precision multiplies in the MFMA-bound convs that have no Winograd kernel
+ *                               of their own (stride-2 3x3, FPN phase convs, bin_conv1 over the pyramid, the Winograd GEMMs of
+ *                               layer3 / layer4).  split_bf16: every f32 operand as the exact sum of three bf16 terms, six partial
+ *                               products per pair on v_mfma_f32_32x32x16_bf16, f32 accumulation - the error of an f32 FMA chain
+ *                               (dropped terms <= 2^-23 of a product; profiles/r03_bf16x3_accuracy.txt), the same parity bars, up to
+ *                               2.67 x the f32 matrix rate.  f32: every conv on v_mfma_f32_32x32x2_f32 (exact f32 FMA chain).
  *   precision=f32|bf16   (f32)  same as ocr_det_set_precision */
 int ocr_det_create_with_options(const void* weights, size_t weights_bytes, int device, const char* options,
                                 ocr_det_t** out);

@@ -51,6 +51,11 @@ enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_PHASE = 2 };
 // Activations are NHWC f32, weights [Cout][ks*ks][Cin] f32.
 struct ConvDesc {
   int in_bf16, out_bf16;  // element types: operands (src, wgt) and results (out, out2, residual, up_residual); 0 = f32
+  // f32 conv on the bf16 matrix cores: every f32 operand is the exact sum of three bf16 terms (hi + mid + lo, 3 x 8
+  // significant bits); six of the nine partial products (all but mid.lo, lo.mid, lo.lo: <= 2^-23 of the product) are
+  // accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Activations stay f32 in HBM and are split in registers; wgt holds
+  // split3_weights() of the f32 layout (three bf16 planes, wgt_bytes = 6 per weight).  f32 PLAIN / PYR4 convs only.
+  int x3;
   const void* src[4];     // PLAIN: src[0]; CAT4: p5,p4,p3,p2 (all inside ONE allocation starting at src_base)
   const void* src_base;   // CAT4: start of the allocation holding the four sources (else unused)
   size_t src_bytes;       // bytes addressable from src[0] (PLAIN) / src_base (CAT4); must be < 2^31
@@ -80,8 +85,12 @@ struct ConvDesc {
 };
 
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s);
+// hi / mid / lo bf16 planes of an f32 weight array whose rows are multiples of 16 long ([3][count] bf16; inside every
+// aligned group of 16 the k order is the one the split-bf16 kernel's A fragments have: 0-3, 8-11, 4-7, 12-15)
+std::vector<uint16_t> split3_weights(const float* w, size_t count);
 const char* conv_igemm_kernel_name(const ConvDesc& d);
 void set_conv_tile_override(int t);  // tuning aid: 0 = automatic
+void set_conv_debug(int d);          // ablation bits, effective in -DIGEMM_DEBUG builds only
 
 // stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
 void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,

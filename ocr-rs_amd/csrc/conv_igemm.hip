@@ -35,10 +35,14 @@
 // v_mfma_f32_32x32x16_bf16 (one 16-byte fragment = one MFMA instead of four).  The default (and the
 // benchmarked BASELINE config 1) is f32 throughout; bf16 is the opt-in precision of config 5.
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "common.hpp"
 
 namespace ocr {
+static int g_conv_debug = 0;  // -DIGEMM_DEBUG builds: ablation bits of the X3 kernel
+void set_conv_debug(int d) { g_conv_debug = d; }
 namespace igemm {  // named (not anonymous): the kernel stubs are referenced from templates below
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,6 +83,8 @@ template <> struct Elem<__bf16> {
 // its own, so it is not preserved.
 template <typename R>
 __device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("" : "+s"(soff));  // a folded constant outside the inline range is not a valid soffset: keep it in an SGPR
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
@@ -109,7 +115,15 @@ struct ConvArgs {
   int pyr_chunked;  // PYR4 tile order (see the kernel)
   int pyr_nsrc;     // PYR4: 4 = p5, p4, p3, p2; 3 = without p2
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
+  int debug;    // builds with -DIGEMM_DEBUG only (ocr_test_set_conv_debug): X3 ablations - 1 no A DMA, 2 no B DMA, 4 no split, 8 no MFMA
 };
+#if defined(IGEMM_ABL)   // compile-time ablation (make EXTRA=-DIGEMM_ABL=<bits>): no run-time cost, for timing what is left
+#define IGEMM_DBG(p, bit) ((IGEMM_ABL & (bit)) != 0)
+#elif defined(IGEMM_DEBUG)
+#define IGEMM_DBG(p, bit) ((p).debug & (bit))
+#else
+#define IGEMM_DBG(p, bit) false
+#endif
 
 // x / d for 0 <= x < 2^31 with host-computed (magic, shift): 5 instructions instead of ~25
 __device__ __forceinline__ int fast_div(int x, unsigned magic, unsigned shift) {
@@ -130,23 +144,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 [[maybe_unused]] constexpr int ROWB = 128;                 // bytes of K per LDS row (one cache line): 32 f32 or 64 bf16
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;     // voffset beyond any tensor (< 2^31 bytes): reads as zero
 
-template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
+template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources, LDS address space):
                                      // the host pass only needs the launch stub
-  constexpr int WM = BM / 2, WN = BN / 2;
+  // X3: waves stacked along M (each owns 32 rows x all BN columns: every A element is split exactly once)
+  constexpr int WGM = X3 ? 4 : 2, WGN = X3 ? 1 : 2;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int AI = BM / 32, BI = BN / 32;
-  constexpr int EB = sizeof(TI);              // bytes per operand element
+  constexpr int AI = BM / 32;
+  constexpr int BSUB = BN / 64;               // X3: 64-row groups of a B plane (one DMA instruction per wave each)
+  constexpr int BI = X3 ? 3 * BSUB : BN / 32; // B DMA instructions per wave and stage
+  constexpr int EB = sizeof(TI);              // bytes per activation element
+  constexpr int EBW = X3 ? 2 : EB;            // bytes per weight element (X3: bf16 planes)
   constexpr int BK = ROWB / EB;               // K elements per LDS row / K-step
   constexpr bool BF16 = EB == 2;
-  constexpr int STAGE = (BM + BN) * ROWB;     // bytes per LDS stage
+  constexpr int A_BYTES = BM * ROWB;
+  constexpr int B_BYTES = X3 ? 3 * BN * 64 : BN * ROWB;   // X3: three bf16 planes of BN rows x 32 k (64-byte rows)
+  constexpr int STAGE = A_BYTES + B_BYTES;    // bytes per LDS stage
+  static_assert(!X3 || (BM == 128 && EB == 4 && (BN == 64 || BN == 128) && MT == 1), "X3 tile shapes");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = X3 ? wave : wave >> 1, wn = X3 ? 0 : wave & 1;
 
   const int bid = xcd_remap(blockIdx.x, p.nblk);
   const int tile_n = bid % p.nblk_n;
@@ -157,15 +179,16 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // the grid.
   int ph = 0, pa = 0, pb = 0;
   if constexpr (SRC == SRC_PYR4) {
-    if ((p.nblk_m & 7) == 0 && p.pyr_chunked) {
-      // order (phase row a | chunk of 8 cell blocks | phase column b | block in chunk): an XCD's contiguous run of
-      // tiles is one phase row; the 8 x 8 tiles of a chunk share the source lines they gather (3 MB, L2-sized)
-      // and each weight set is used by 8 consecutive tiles.  Phase-major order fetched 3.5 GB for 280 MB of sources.
-      const int j = tile_m & 7;
-      pb = (tile_m >> 3) & 7;
-      const int rest = tile_m >> 6, nchunk = p.nblk_m >> 3;
+    constexpr int CHS = BM == 128 ? 2 : 3, CH = 1 << CHS;   // cell blocks per chunk: 512 cells of the p5 grid
+    if ((p.nblk_m & (CH - 1)) == 0 && p.pyr_chunked) {
+      // order (phase row a | chunk of CH cell blocks | phase column b | block in chunk): an XCD's contiguous run of
+      // tiles is one phase row; the 8 x CH tiles of a chunk share the source lines they gather (3 MB, L2-sized)
+      // and each weight set is used by CH consecutive tiles.  Phase-major order fetched 3.5 GB for 280 MB of sources.
+      const int j = tile_m & (CH - 1);
+      pb = (tile_m >> CHS) & 7;
+      const int rest = tile_m >> (CHS + 3), nchunk = p.nblk_m >> CHS;
       pa = rest / nchunk;
-      tile_m = (rest - pa * nchunk) * 8 + j;
+      tile_m = (rest - pa * nchunk) * CH + j;
       ph = pa * 8 + pb;
     } else {
       ph = tile_m / p.nblk_m;
@@ -178,6 +201,12 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     tile_m -= ph * p.nblk_m;
     pa = ph >> p.up_shift;
     pb = ph & ((1 << p.up_shift) - 1);
+  }
+  if constexpr (SRC == SRC_PYR4) {  // block coordinates are wave-uniform: say so (SGPRs, scalar branches)
+    tile_m = __builtin_amdgcn_readfirstlane(tile_m);
+    pa = __builtin_amdgcn_readfirstlane(pa);
+    pb = __builtin_amdgcn_readfirstlane(pb);
+    ph = __builtin_amdgcn_readfirstlane(ph);
   }
   // batched GEMM: slice bz of the grid is problem bz (own A, B and output blocks)
   int bz = 0;
@@ -202,8 +231,15 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
-  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
-  const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+  // descriptor inputs through readfirstlane: provably wave-uniform, so the descriptors stay in SGPRs however the
+  // allocator treats the other kernel arguments (the inline-asm DMA needs them there)
+  auto uniform_ptr = [](const void* q) {
+    const unsigned long long u = (unsigned long long)q;
+    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+  };
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.src), 0, __builtin_amdgcn_readfirstlane((int)p.src_bytes), 0x00020000);
+  const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.wgt), 0, __builtin_amdgcn_readfirstlane((int)p.wgt_bytes), 0x00020000);
 
   // ---- DMA coordinates: this lane fills LDS slot q of rows r + 32 i with global chunk q ^ f(r)
   const int r = tid >> 3;
@@ -233,11 +269,20 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       abase[i] = 0;
     }
   }
-  unsigned bvoff[BI];
+  unsigned bvoff[X3 ? BSUB : BI];
   constexpr int PYR_TAPS = 21;  // weight row of SRC_PYR4: 4 + 4 + 4 tap slots of p5, p4, p3 and 9 of p2
   const int wrow = SRC == SRC_PYR4 ? PYR_TAPS * 64 : KS * KS * p.Cin;
+  if constexpr (X3) {
+    // a DMA instruction fills 16 rows x 64 B of one plane: lane l -> row l >> 2, slot l & 3 holding global chunk
+    // slot ^ f(row), f(row) = (row >> 2) & 3 (= (l >> 4) & 3: the wave's rows start at a multiple of 16)
 #pragma unroll
-  for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + r + 32 * i) * wrow * EB + gq * 16);
+    for (int i = 0; i < BSUB; ++i)
+      bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + 64 * i + 16 * wave + (lane >> 2)) * wrow * EBW + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+  } else {
+#pragma unroll
+    for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + r + 32 * i) * wrow * EB + gq * 16);
+  }
+  const unsigned plane_bytes = p.wgt_bytes / 3;  // X3: byte distance between the hi / mid / lo planes
 
   // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
   // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
@@ -293,14 +338,25 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       for (int i = 0; i < AI; ++i) avoff[t][i] = tap_offset(s, t, i);
     }
   };
-  prep_source(0);
+  if constexpr (!(X3 && SRC == SRC_PYR4)) prep_source(0);
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds + (unsigned)(8 * wave * ROWB);
   auto issue_plain = [&](int stage, const unsigned (&av)[AI], int tap, int c, int kbase) {
     const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE));
 #pragma unroll
-    for (int i = 0; i < AI; ++i) dma16(a_rsrc, st + 32 * i * ROWB, av[i], c * ROWB);
+    for (int i = 0; i < AI; ++i)
+      if (!IGEMM_DBG(p, 1)) dma16(a_rsrc, st + 32 * i * ROWB, av[i], c * ROWB);
+    if constexpr (X3) {
+      if (IGEMM_DBG(p, 2)) return;
+      const unsigned sb = __builtin_amdgcn_readfirstlane(lds_base - (unsigned)(8 * wave * ROWB) + (unsigned)(stage * STAGE + A_BYTES + 16 * wave * 64));
 #pragma unroll
-    for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (BM + 32 * i) * ROWB, bvoff[i], (tap * p.Cin + kbase) * EB + c * ROWB);
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < BSUB; ++i)
+          dma16(b_rsrc, sb + (unsigned)(pl * BN * 64 + i * 64 * 64), bvoff[i], (int)(pl * plane_bytes) + (tap * p.Cin + kbase) * EBW + c * 64);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (BM + 32 * i) * ROWB, bvoff[i], (tap * p.Cin + kbase) * EB + c * ROWB);
+    }
   };
 
   f32x16 acc[MT][NT];
@@ -324,6 +380,9 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   const int a_row = (wm * WM + frow) * ROWB;
   const int b_row = (BM + wn * WN + frow) * ROWB;
 
+  // X3 B fragment: row (lane & 31) of column tile j, chunk 2 kk + (lane >> 5) in slot chunk ^ f(row)
+  const int bx_row = A_BYTES + frow * 64;
+  const int bx_f = (frow >> 2) & 3;
   auto compute = [&](int stage) {
     const unsigned char* st = lds + stage * STAGE;
 #pragma unroll
@@ -357,6 +416,260 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   const int NSRC = SRC == SRC_PYR4 ? p.pyr_nsrc : MULTI ? 4 : 1;  // PYR4 may leave p2 (its last source) to another kernel
   const int pass_chunks = MULTI ? 64 / BK : csteps;
   int par = 0;  // LDS stage holding the K-step about to be multiplied
+  if constexpr (X3) {
+    // ---- split-bf16 main loop.  The K-steps form one flat sequence (source, channel chunk, tap); the DMA side walks it two
+    // steps ahead of the multiplier with its own iterator.  A K-step is two MFMA groups (kk = 0, 1: sixteen k each); the
+    // operand fragments of a group are read from LDS and split (VALU) during the MFMAs of the group before it, and the
+    // barrier sits BETWEEN the two groups of a step:
+    //   phase 1: MFMAs (k, 0) | read + split (k, 1) from stage par              ... wait for DMA k+1, barrier ...
+    //   phase 2: DMA k+2 -> stage par | MFMAs (k, 1) | read + split (k+1, 0) from stage par ^ 1
+    // so every MFMA group has the next group's LDS latency and ~44 split instructions to cover and no group starts cold.
+    struct Frag {
+      bf16x8 ah, am, al;
+      bf16x8 bh[NT], bm[NT], bl[NT];
+    };
+    struct Raw { f32x4 a0, a1; };
+    // LDS reads of one fragment set: the f32 A chunks (split later, in pieces, between the MFMAs) and the bf16 B planes
+    auto read_frag = [&](int stage, int kk, Raw& r, Frag& f) {
+      const unsigned char* st = lds + stage * STAGE;
+      if (IGEMM_DBG(p, 32)) {   // no LDS reads: operands from whatever the registers hold
+        asm volatile("" : "+v"(r.a0), "+v"(r.a1));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(f.bh[j]), "+v"(f.bm[j]), "+v"(f.bl[j]));
+        return;
+      }
+      // eight k of this lane: chunks g = 2 kk, 2 kk + 1 -> k = 16 kk + 4 h + e and 16 kk + 8 + 4 h + e (the weights' k order
+      // inside a 16-group is permuted to match on the host, split3_weights)
+      r.a0 = *reinterpret_cast<const f32x4*>(st + a_row + xoff[2 * kk]);
+      r.a1 = *reinterpret_cast<const f32x4*>(st + a_row + xoff[2 * kk + 1]);
+      const int boff = bx_row + (((2 * kk + (lane >> 5)) ^ bx_f) * 16);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f.bh[j] = *reinterpret_cast<const bf16x8*>(st + boff + j * 32 * 64);
+        f.bm[j] = *reinterpret_cast<const bf16x8*>(st + boff + j * 32 * 64 + BN * 64);
+        f.bl[j] = *reinterpret_cast<const bf16x8*>(st + boff + j * 32 * 64 + 2 * BN * 64);
+      }
+    };
+    // elements [E0, E1) of the A fragment: x = hi + mid + lo, round to nearest even at every level (the remainders are
+    // exact in f32, the third term has at most 8 significant bits left)
+    auto split_part = [&](const Raw& r, Frag& f, auto e0c, auto e1c) {
+      constexpr int E0 = decltype(e0c)::value, E1 = decltype(e1c)::value;
+      if (IGEMM_DBG(p, 4)) {
+        f.ah = __builtin_bit_cast(bf16x8, r.a0);
+        f.am = __builtin_bit_cast(bf16x8, r.a1);
+        f.al = __builtin_bit_cast(bf16x8, r.a0 + r.a1);
+        return;
+      }
+#pragma unroll
+      for (int e = E0; e < E1; ++e) {
+        const float x = e < 4 ? r.a0[e] : r.a1[e - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        f.ah[e] = h;
+        f.am[e] = m;
+        f.al[e] = (__bf16)r2;
+      }
+    };
+    // six of the nine partial products of column tile j (mid.lo, lo.mid, lo.lo are below 2^-23 of the product), small terms first
+    auto mfma6 = [&](const Frag& f, int j) {
+      if (IGEMM_DBG(p, 8)) {
+        asm volatile("" ::"v"(f.al), "v"(f.ah), "v"(f.am), "v"(f.bh[j]), "v"(f.bm[j]), "v"(f.bl[j]));
+        return;
+      }
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am, f.bm[j], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am, f.bh[j], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bm[j], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[0][j], 0, 0, 0);
+    };
+    // total K-steps and the DMA iterator
+    int total = 0;
+    if constexpr (SRC == SRC_PYR4) {
+      for (int s = 0; s < 3; ++s) total += pass_chunks * pyr_taps(s, pa) * pyr_taps(s, pb);   // the three upsampled sources
+    } else {
+      total = pass_chunks * nt;
+    }
+    int it_s = 0, it_c = 0, it_t = 0;
+    // PYR4 (three upsampled sources, at most 2 x 2 taps each at a phase): the tap tables of all sources up front, slot
+    // 4 s + t = the weight row's tap slot - no table is rebuilt inside the K loop and no source index is dynamic
+    constexpr bool PYRX = SRC == SRC_PYR4;
+    unsigned avx[PYRX ? 12 : 1][AI];
+    int nts[3] = {0, 0, 0};
+    if constexpr (PYRX) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        nts[s] = pyr_taps(s, pa) * pyr_taps(s, pb);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t < nts[s]) {   // wave-uniform
+#pragma unroll
+            for (int i = 0; i < AI; ++i) avx[4 * s + t][i] = tap_offset(s, t, i);
+          }
+      }
+    }
+    // the step the iterator points at: its A offsets (one static row of the tap table, picked by a wave-uniform switch)
+    // and scalar parts; then advance
+    unsigned cur_av[AI];
+    int cur_soff_a = 0, cur_soff_b = 0;
+    auto select_next = [&] {
+      if constexpr (PYRX) {
+        const int flat = 4 * it_s + it_t;
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+          if (flat == t) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) cur_av[i] = avx[t][i];
+          }
+        cur_soff_a = it_c * ROWB;
+        cur_soff_b = (flat * p.Cin) * EBW + it_c * 64;
+        const int ntc = it_s == 0 ? nts[0] : it_s == 1 ? nts[1] : nts[2];
+        if (++it_t == ntc) {
+          it_t = 0;
+          if (++it_c == pass_chunks) {
+            it_c = 0;
+            ++it_s;
+          }
+        }
+        return;
+      }
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+        if (it_t == t) {
+#pragma unroll
+          for (int i = 0; i < AI; ++i) cur_av[i] = avoff[t][i];
+        }
+      cur_soff_a = it_c * ROWB;
+      cur_soff_b = (it_t * p.Cin) * EBW + it_c * 64;
+      if (++it_t == nt) {
+        it_t = 0;
+        ++it_c;
+      }
+    };
+    constexpr int NP = AI + 3 * BSUB;   // DMA instructions per wave and step: A row groups, then B planes
+    auto dma_piece = [&](int stage, auto piece_c) {
+      constexpr int P = decltype(piece_c)::value;
+      if constexpr (P < AI) {
+        if (!IGEMM_DBG(p, 1)) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE + 32 * P * ROWB)), cur_av[P], cur_soff_a);
+      } else {
+        constexpr int pl = (P - AI) / BSUB, i = (P - AI) % BSUB;
+        if (!IGEMM_DBG(p, 2))
+          dma16(b_rsrc, __builtin_amdgcn_readfirstlane(lds_base - (unsigned)(8 * wave * ROWB) + (unsigned)(stage * STAGE + A_BYTES + 16 * wave * 64 + pl * BN * 64 + i * 64 * 64)),
+                bvoff[i], (int)(pl * plane_bytes) + cur_soff_b);
+      }
+    };
+    auto dma_all = [&](int stage) {
+      dma_piece(stage, std::integral_constant<int, 0>{});
+      dma_piece(stage, std::integral_constant<int, 1>{});
+      dma_piece(stage, std::integral_constant<int, 2>{});
+      dma_piece(stage, std::integral_constant<int, 3>{});
+      dma_piece(stage, std::integral_constant<int, 4>{});
+      dma_piece(stage, std::integral_constant<int, 5>{});
+      dma_piece(stage, std::integral_constant<int, 6>{});
+      if constexpr (NP > 7) {
+        dma_piece(stage, std::integral_constant<int, 7>{});
+        dma_piece(stage, std::integral_constant<int, 8>{});
+        dma_piece(stage, std::integral_constant<int, 9>{});
+      }
+    };
+    // one MFMA group (six per column tile) with, behind each column tile, its share of the next fragment's split and (phase 2)
+    // of the DMA instructions: the matrix pipe works on the tile just issued while the wave issues them
+    auto phase = [&](const Frag& cur, const Raw& nraw, Frag& nxt, int dma_stage) {   // dma_stage < 0: no DMA in this phase
+      if constexpr (NT == 2) {
+        mfma6(cur, 0);
+        split_part(nraw, nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_stage >= 0) {
+          dma_piece(dma_stage, std::integral_constant<int, 0>{});
+          dma_piece(dma_stage, std::integral_constant<int, 1>{});
+          dma_piece(dma_stage, std::integral_constant<int, 2>{});
+          dma_piece(dma_stage, std::integral_constant<int, 3>{});
+        }
+        mfma6(cur, 1);
+        split_part(nraw, nxt, std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_stage >= 0) {
+          dma_piece(dma_stage, std::integral_constant<int, 4>{});
+          dma_piece(dma_stage, std::integral_constant<int, 5>{});
+          dma_piece(dma_stage, std::integral_constant<int, 6>{});
+        }
+      } else {
+        static_assert(NT == 4 && NP == 10, "phase(): NT is 2 or 4");
+        mfma6(cur, 0);
+        split_part(nraw, nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_stage >= 0) {
+          dma_piece(dma_stage, std::integral_constant<int, 0>{});
+          dma_piece(dma_stage, std::integral_constant<int, 1>{});
+          dma_piece(dma_stage, std::integral_constant<int, 2>{});
+        }
+        mfma6(cur, 1);
+        split_part(nraw, nxt, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_stage >= 0) {
+          dma_piece(dma_stage, std::integral_constant<int, 3>{});
+          dma_piece(dma_stage, std::integral_constant<int, 4>{});
+        }
+        mfma6(cur, 2);
+        split_part(nraw, nxt, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_stage >= 0) {
+          dma_piece(dma_stage, std::integral_constant<int, 5>{});
+          dma_piece(dma_stage, std::integral_constant<int, 6>{});
+          dma_piece(dma_stage, std::integral_constant<int, 7>{});
+        }
+        mfma6(cur, 3);
+        split_part(nraw, nxt, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_stage >= 0) {
+          dma_piece(dma_stage, std::integral_constant<int, 8>{});
+          dma_piece(dma_stage, std::integral_constant<int, 9>{});
+        }
+      }
+    };
+#ifdef IGEMM_DEBUG
+    if (IGEMM_DBG(p, 16) && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) __builtin_amdgcn_s_sleep(12);  // stagger the two workgroups of a CU
+#endif
+    select_next();
+    dma_all(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (total > 1) {
+      select_next();
+      dma_all(1);
+    }
+    Frag fx = {}, fy = {};
+    Raw rw = {};
+    read_frag(0, 0, rw, fx);
+    split_part(rw, fx, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+    if (IGEMM_DBG(p, 256)) total = 1;
+    for (int k = 0; k < total; ++k) {
+      read_frag(par, 1, rw, fy);
+      phase(fx, rw, fy, -1);
+      // this wave's reads of stage par are complete and its share of DMA k+1 has landed; after the barrier so is everyone's
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (!IGEMM_DBG(p, 64)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = k + 2 < total;
+      if (more) select_next();
+      read_frag(par ^ 1, 0, rw, fx);   // (after the last step: reads of a stale stage, never used)
+      phase(fy, rw, fx, more ? par : -1);
+      par ^= 1;
+    }
+    __syncthreads();
+  } else {
   issue_plain(0, avoff[0], 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -391,6 +704,15 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     }
   }
 
+  }
+
+  if (IGEMM_DBG(p, 128)) {   // no epilogue: keep the accumulators alive, store nothing
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   // ---- epilogue A (plain NHWC store, the MFMA-bound convs): straight from the accumulators.
   // C/D map of a 32x32 MFMA tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); one store
   // instruction writes 2 rows x 128 contiguous bytes.  Residual rows are all requested before use.
@@ -535,7 +857,7 @@ static void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
   *shift = L == 0 ? 0xFFFFFFFFu : L - 1;  // d == 1: identity
 }
 
-template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE>
+template <typename TI, typename TO, int BM, int BN, int KS, int STRIDE, int SRC, int STORE, bool X3 = false>
 void launch_inst(const ConvDesc& d, hipStream_t s) {
   ConvArgs a{};
   const bool multi = d.src_mode == SRC_CAT4 || d.src_mode == SRC_PYR4;
@@ -568,10 +890,11 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.batch = d.batch > 1 ? d.batch : 1;
   a.pyr_chunked = 1;
   a.pyr_nsrc = d.pyr_nsrc == 3 ? 3 : 4;
+  a.debug = g_conv_debug;
   a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
-  hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE>), dim3(a.nblk), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE, X3>), dim3(a.nblk), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
 
@@ -583,6 +906,11 @@ using namespace igemm;
 static void check(const ConvDesc& d) {
   const int eb = d.in_bf16 ? 2 : 4;
   const int bk = 128 / eb;
+  // x3: f32 activations, weights as three bf16 planes (hi, mid, lo) of the f32 layout -> 6 bytes per weight
+  const int ebw = d.x3 ? 6 : eb;
+  if (d.x3 && d.src_mode == SRC_PYR4 && d.pyr_nsrc != 3) fail(OCR_ERR_INVALID, "%s: the split-bf16 PYR4 form takes the three upsampled sources only", d.name);
+  if (d.x3 && (d.in_bf16 || d.out_bf16 || d.src_mode == SRC_CAT4 || d.store_mode == STORE_SHUFFLE2 || d.out2))
+    fail(OCR_ERR_INVALID, "%s: the split-bf16 form exists for f32 PLAIN / PYR4 convs with NHWC or PHASE stores", d.name);
   if (d.Cin % bk != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, bk);
   if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
   const bool phase2 = d.store_mode == STORE_PHASE;
@@ -592,7 +920,7 @@ static void check(const ConvDesc& d) {
         d.Wo != d.Win || d.out2 || d.residual || !d.out || (d.out_bf16 && !d.in_bf16) || d.batch > 1)
       fail(OCR_ERR_INVALID, "%s: PYR4 needs the 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
     if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large", d.name);
-    if ((long long)d.wgt_bytes != 64ll * d.Cout * 21 * 64 * eb) fail(OCR_ERR_INVALID, "%s: PYR4 weight bytes", d.name);
+    if ((long long)d.wgt_bytes != 64ll * d.Cout * 21 * 64 * ebw) fail(OCR_ERR_INVALID, "%s: PYR4 weight bytes", d.name);
     if ((long long)d.src_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: sources must be < 2^31 bytes; split the batch", d.name);
     for (int i = 0; i < 4; ++i) {
       const long long need = (long long)d.N * (d.Hin << i) * (d.Win << i) * 64 * eb;
@@ -627,7 +955,7 @@ static void check(const ConvDesc& d) {
   const long long in_bytes = d.src_mode == SRC_CAT4 ? (long long)d.src_bytes : (long long)nb * d.N * d.Hin * d.Win * d.Cin * eb;
   if (in_bytes >= (1ll << 31) || (long long)d.src_bytes >= (1ll << 31) || (long long)d.src_bytes < in_bytes)
     fail(OCR_ERR_INVALID, "%s: input of %lld bytes (addressable %zu) must be < 2^31 bytes; split the batch", d.name, in_bytes, d.src_bytes);
-  if ((long long)d.wgt_bytes != (long long)(phase2 ? d.up * d.up : nb) * d.Cout * d.ks * d.ks * d.Cin * eb) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
+  if ((long long)d.wgt_bytes != (long long)(phase2 ? d.up * d.up : nb) * d.Cout * d.ks * d.ks * d.Cin * ebw) fail(OCR_ERR_INVALID, "%s: weight bytes", d.name);
   if ((long long)d.wgt_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: weights too large", d.name);
   if (d.src_mode != SRC_PLAIN && d.src_mode != SRC_CAT4) fail(OCR_ERR_INVALID, "%s: source mode %d", d.name, d.src_mode);
   if (d.src_mode == SRC_CAT4) {
@@ -660,6 +988,13 @@ enum Tile { T128x128, T128x64, T64x64 };
 static int g_tile_override = 0;  // tuning aid (ocr_test_set_conv_tile): 1 = 128x128, 2 = 128x64, 3 = 64x64
 void set_conv_tile_override(int t) { g_tile_override = t; }
 static Tile pick_tile(const ConvDesc& d) {
+  if (d.x3) {  // the split-bf16 kernels exist as 128 x 128 and 128 x 64 only
+    const long long M = (long long)d.N * d.Ho * d.Wo;
+    const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : (d.batch > 1 ? d.batch : 1);
+    if (g_tile_override == 2 || d.Cout % 128 || d.src_mode == SRC_PYR4) return T128x64;
+    if (g_tile_override == 1) return T128x128;
+    return ((M + 127) / 128) * (d.Cout / 128) * reps >= 1024 ? T128x128 : T128x64;
+  }
   if (g_tile_override == 1 && d.Cout % 128 == 0) return T128x128;
   if (g_tile_override == 2) return T128x64;
   if (g_tile_override == 3) return T64x64;
@@ -678,7 +1013,7 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
-  snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
+  snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.x3 ? "x3" : d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
            d.src_mode == SRC_CAT4 ? "CAT4" : d.src_mode == SRC_PYR4 ? "PYR4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8")
            : d.batch > 1 ? ",BATCHED" : "");
   // names must outlive the call: intern them
@@ -699,8 +1034,53 @@ static void launch_tiles(const ConvDesc& d, hipStream_t s) {
   }
 }
 
+// f32 -> bf16, round to nearest even (weights are finite)
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+std::vector<uint16_t> split3_weights(const float* w, size_t count) {
+  if (count % 16) fail(OCR_ERR_INTERNAL, "split3_weights: %zu weights are not whole groups of 16", count);
+  std::vector<uint16_t> out(3 * count);
+  static const int perm[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};  // position -> k inside the group
+  for (size_t g = 0; g < count; g += 16)
+    for (int pos = 0; pos < 16; ++pos) {
+      const float x = w[g + perm[pos]];
+      const uint16_t h = bf16_rne(x);
+      const float r1 = x - bf16_f32(h);      // exact
+      const uint16_t m = bf16_rne(r1);
+      const float r2 = r1 - bf16_f32(m);     // exact, at most 8 significant bits left
+      out[g + pos] = h;
+      out[count + g + pos] = m;
+      out[2 * count + g + pos] = bf16_rne(r2);
+    }
+  return out;
+}
+
+template <int KS, int STRIDE, int SRC, int STORE>
+static void launch_x3(const ConvDesc& d, hipStream_t s) {
+  if (pick_tile(d) == T128x128) launch_inst<float, float, 128, 128, KS, STRIDE, SRC, STORE, true>(d, s);
+  else launch_inst<float, float, 128, 64, KS, STRIDE, SRC, STORE, true>(d, s);
+}
+
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
+  if (d.x3) {
+    if (d.src_mode == SRC_PYR4) return launch_inst<float, float, 128, 64, 3, 1, SRC_PYR4, STORE_PHASE, true>(d, s);
+    if (d.store_mode == STORE_PHASE) return launch_x3<2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
+    if (d.ks == 3 && d.stride == 1) return launch_x3<3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+    if (d.ks == 3 && d.stride == 2) return launch_x3<3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
+    if (d.ks == 1 && d.stride == 1) return launch_x3<1, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+    fail(OCR_ERR_INVALID, "%s: no split-bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
+  }
   if (d.in_bf16) {
     if (d.src_mode == SRC_PYR4 && !d.out_bf16) return launch_inst<__bf16, float, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
     if (d.src_mode == SRC_PYR4) return launch_inst<__bf16, __bf16, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);

@@ -45,6 +45,15 @@ float* DeviceArena::upload(const std::vector<float>& host) {
   return p;
 }
 
+void* DeviceArena::upload_u16(const std::vector<uint16_t>& host) {
+  const size_t bytes = (host.size() * 2 + 255) / 256 * 256;
+  if (used_ + bytes > cap_) fail(OCR_ERR_INTERNAL, "weight arena overflow");
+  void* p = base_ + used_;
+  OCR_HIP(hipMemcpy(p, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+  used_ += bytes;
+  return p;
+}
+
 // eval batch norm (tch batch_norm2d default eps 1e-5) -> y = x*scale + bias
 static void fold_bn(const WeightBlob& wb, const std::string& p, int c, std::vector<float>& scale, std::vector<float>& bias) {
   const float* g = wb.get(p + ".weight", {c}).data;
@@ -143,6 +152,7 @@ void Detector::add_winograd_weights(ConvW& cw) {
   const std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin, cw.wino_tile);
   cw.wino = arena_.upload(u);
   cw.wino_bytes = u.size() * sizeof(float);
+  if (split_bf16_ && cw.cin % 32 == 0) cw.wino_x3 = arena_.upload_u16(split3_weights(u.data(), u.size()));
 }
 
 void Detector::add_winograd_fused_weights(ConvW& cw) {
@@ -160,6 +170,11 @@ void Detector::add_winograd_fused_weights(ConvW& cw) {
   }
   for (size_t i = (size_t)12 * cw.cout * cw.cin; i < u.size(); ++i) u[i] = -u[i];  // row i = 3 enters the output transform negated
   cw.wino_fused = arena_.upload(u);
+}
+
+// hi / mid / lo bf16 planes of a conv's f32 weights (and of its Winograd form): what conv_igemm's split-bf16 kernels read
+void Detector::add_split_weights(ConvW& cw) {
+  if (!cw.host.empty() && !cw.w_x3 && cw.cin % 32 == 0) cw.w_x3 = arena_.upload_u16(split3_weights(cw.host.data(), cw.host.size()));
 }
 
 // A_k = out_k o in_k
@@ -240,6 +255,11 @@ void Detector::parse_options(const char* options) {
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") overlap_ = num();
+    else if (key == "mfma") {
+      if (val == "split_bf16") split_bf16_ = true;
+      else if (val == "f32") split_bf16_ = false;
+      else fail(OCR_ERR_INVALID, "detector option mfma: '%s' (split_bf16 or f32)", val.c_str());
+    }
     else if (key == "precision") {
       if (val == "bf16") opt_bf16_ = true;
       else if (val == "f32") opt_bf16_ = false;
@@ -269,7 +289,9 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   }
   // 12.2 M parameters = 48.7 MB f32, the Winograd forms (F(4x4): 36 matrices per 3x3 conv of layer3/4, 113 MB; fused F(2x2): 16),
   // composed FPN weights, 24.4 MB of bf16 copies and fragments on demand, padding
-  arena_.reserve((size_t)384 << 20);
+  // ... and with mfma=split_bf16 the bf16 planes (6 bytes per weight) of the convs that run that way: 170 MB for layer4's
+  // Winograd matrices, 57 MB for layer3's, 33 MB for bin_conv1's phase weights
+  arena_.reserve((size_t)(split_bf16_ ? 768 : 384) << 20);
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -439,6 +461,14 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     for (int l = 0; l < 3; ++l) all_convs_.push_back(&bin_up_[l]);
     all_convs_.push_back(&bin_p2_);
     if (bin_pyr_on_) all_convs_.push_back(&bin_pyr_);
+  }
+  if (split_bf16_) {
+    for (int l = 1; l < 4; ++l) add_split_weights(layer_[l][0][0]);   // the stride-2 3x3 convs
+    if (fpn_composed_) {
+      for (int l = 0; l < 2; ++l) add_split_weights(fpn_b_[l]);       // phase convs of p2 / p3
+      for (int l = 0; l < 3; ++l) add_split_weights(bin_up_[l]);
+      if (bin_pyr_on_) add_split_weights(bin_pyr_);
+    }
   }
   if (opt_bf16_) set_precision(1);
 }
@@ -732,6 +762,11 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.Wo = ex.store == STORE_PHASE ? win : (win + 2 * d.pad - cw.ks) / stride + 1;
     d.Cout = cw.cout;
     d.wgt = in_bf ? cw.w_bf16 : static_cast<const void*>(cw.w);
+    if (!bf && split_bf16_ && cw.w_x3 && !ex.cat4 && !ex.out2 && ex.store != STORE_SHUFFLE2 && !(ex.pyr4 && ex.pyr_nsrc != 3)) {
+      d.x3 = 1;
+      d.wgt = cw.w_x3;
+      d.wgt_bytes = cw.w_bytes / 4 * 6;
+    }
     d.scale = cw.scale;
     d.bias = cw.bias;
     d.residual = ex.residual;
@@ -817,6 +852,11 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     d.src_bytes = wa * T * cw.cin * 4;
     d.wgt = cw.wino;
     d.wgt_bytes = cw.wino_bytes;
+    if (split_bf16_ && cw.wino_x3) {
+      d.x3 = 1;
+      d.wgt = cw.wino_x3;
+      d.wgt_bytes = cw.wino_bytes / 4 * 6;
+    }
     d.batch = (int)wa;
     d.N = 1;
     d.Hin = d.Ho = 1;

@@ -24,6 +24,7 @@ class DeviceArena {  // bump allocator over one hipMalloc (weights)
   ~DeviceArena();
   void reserve(size_t bytes);
   float* upload(const std::vector<float>& host);
+  void* upload_u16(const std::vector<uint16_t>& host);
  private:
   char* base_ = nullptr;
   size_t cap_ = 0, used_ = 0;
@@ -36,6 +37,8 @@ struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
   size_t w_bytes = 0;
   void* w_bf16 = nullptr;  // same layout in bf16 (filled by Detector::set_precision)
+  void* w_x3 = nullptr;    // same layout as three bf16 planes hi / mid / lo (split3_weights): the f32 conv on the bf16 matrix cores
+  void* wino_x3 = nullptr; // ... of the Winograd weights `wino`
   void* w_bf16_c64 = nullptr;  // 3x3 64 -> 64 convs: bf16 MFMA fragments for conv3x3_bf16_c64.hip
   std::vector<float> host; // the f32 layout, kept for the bf16 conversion
   std::vector<float> host_scale;  // folded batch norm scale (empty: none), kept for weight composition
@@ -146,6 +149,12 @@ class Detector {
   void add_winograd_fused_weights(ConvW& cw);
   bool winograd_ws_ = false;     // option winograd_ws=1: the wave-specialised fused Winograd kernel instead of winograd_fused
   bool winograd_fused_ = true;   // option winograd_fused=0: direct convs instead of the fused Winograd kernel
+  // option mfma=split_bf16 (default) | f32: the MFMA-bound f32 convs without a Winograd kernel of their own (stride-2 3x3,
+  // composed FPN phase convs, bin_conv1 over the pyramid, the 36 Winograd GEMMs of layer3 / layer4) run on the bf16 matrix
+  // cores from operands split into three bf16 terms, six partial products, f32 accumulate (conv_igemm.hip, X3): f32-level
+  // accuracy (profiles/r03_bf16x3_accuracy.txt) at up to 2.67x the f32 MFMA rate.  f32 keeps every conv on v_mfma_f32_32x32x2_f32.
+  bool split_bf16_ = true;
+  void add_split_weights(ConvW& cw);
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;

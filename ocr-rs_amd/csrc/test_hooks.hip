@@ -211,6 +211,17 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
       down(out, d_out, out_e, true);
       return;
     }
+    if (variant == 2) {  // the split-bf16 form of the f32 conv: weights as three bf16 planes
+      if (in_bf16 || out_bf16 || cat4) fail(OCR_ERR_INVALID, "variant 2 (split bf16) takes f32 tensors");
+      const std::vector<uint16_t> planes = split3_weights(wgt, w_e);
+      void* d_pl = nullptr;
+      OCR_HIP(hipMalloc(&d_pl, planes.size() * 2));
+      allocs.push_back(d_pl);
+      OCR_HIP(hipMemcpy(d_pl, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+      d.x3 = 1;
+      d.wgt = d_pl;
+      d.wgt_bytes = planes.size() * 2;
+    }
     launch_conv_igemm(d, s);
     OCR_HIP(hipStreamSynchronize(s));
     down(out, d_out, out_e, out_bf16);
@@ -286,6 +297,10 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
   });
 }
+int ocr_test_set_conv_debug(int d) {
+  ocr::set_conv_debug(d);
+  return OCR_OK;
+}
 int ocr_test_set_conv_tile(int t) {
   ocr::set_conv_tile_override(t);
   return OCR_OK;
@@ -317,13 +332,25 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
       for (size_t i = 0; i < w_e; ++i) h[i] = 0.05f * rnd();
       OCR_HIP(hipMemcpy(wt, h.data(), w_e * 4, hipMemcpyHostToDevice));
     }
+    const int x3 = (src_mode & 64) ? 1 : 0;  // split-bf16 form: the weight buffer is reinterpreted as three bf16 planes
+    src_mode &= ~64;
+    if (x3) {
+      (void)hipFree(wt);
+      OCR_HIP(hipMalloc(reinterpret_cast<void**>(&wt), w_e * 6));
+      std::vector<float> hw(w_e);
+      uint32_t st = 777u;
+      for (size_t i = 0; i < w_e; ++i) { st = st * 1664525u + 1013904223u; hw[i] = 0.05f * (((st >> 8) & 0xffff) / 32768.0f - 1.0f); }
+      const std::vector<uint16_t> planes = split3_weights(hw.data(), w_e);
+      OCR_HIP(hipMemcpy(wt, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    }
     ConvDesc d{};
+    d.x3 = x3;
     d.src[0] = in;
     d.src_mode = SRC_PLAIN;
     const int bf = src_mode == 16 ? 1 : 0;  // src_mode 16: bf16 operands and output (the buffers are just reinterpreted)
     d.in_bf16 = d.out_bf16 = bf;
     d.src_bytes = in_e * (bf ? 2 : 4);
-    d.wgt_bytes = w_e * (bf ? 2 : 4); d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
+    d.wgt_bytes = w_e * (x3 ? 6 : bf ? 2 : 4); d.N = n; d.Hin = h; d.Win = w; d.Cin = cin; d.Ho = ho; d.Wo = wo; d.Cout = cout;
     d.ks = ks; d.stride = stride; d.pad = pad; d.wgt = wt; d.relu = 1; d.store_mode = STORE_NHWC; d.out = out;
     d.name = "bench";
     hipEvent_t e0, e1;

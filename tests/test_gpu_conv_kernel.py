@@ -105,6 +105,54 @@ def test_conv_matches_aten(det, case, bf16):
         _check(out2, ref2, bf16)
 
 
+X3_CASES = [
+    # n, h, w, cin, cout, ks, stride, bn, residual, relu
+    (2, 18, 22, 64, 128, 3, 2, True, False, True),      # strided conv1 of layer2.0, odd output grid, ragged M (128 x 128 tile)
+    (1, 10, 14, 64, 64, 3, 1, True, True, True),        # 128 x 64 tile, residual, M < one tile
+    (3, 40, 40, 256, 512, 3, 2, True, False, True),     # layer4.0 conv1: K = 2304
+    (1, 9, 7, 256, 64, 3, 1, False, False, False),      # out2..5 shape, no epilogue terms
+    (36, 10, 10, 512, 512, 1, 1, False, False, False),  # the Winograd GEMMs of layer4 (K = 512), M = 3600: partial last tile
+    (4, 128, 128, 128, 256, 3, 2, True, False, True),   # many tiles: XCD remap, both tile shapes by Cout
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_conv_split_bf16_matches_aten(det, case):
+    """The f32 conv on the bf16 matrix cores (operands split into three bf16 terms, six partial products, f32
+    accumulate) is held to the SAME bar as the exact-f32 MFMA kernel: 2e-5 of the layer's scale
+    against ATen's f32 conv on the same f32 operands."""
+    n, h, w, cin, cout, ks, stride, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:7]) & 0xFFFF)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wg = (rng.standard_normal((cout, ks * ks, cin), dtype=np.float32) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    pad = (ks - 1) // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+    out, _ = det.debug_conv_run(x, wg, stride, scale, bias, res, None, relu, None, False, False, True, False, variant=2)
+    ref, _ = _ref(x, wg, stride, scale, bias, res, None, relu)
+    _check(out, ref, False)
+    # and against the exact-f32 MFMA kernel on the same operands: the two agree far inside the bar
+    out32, _ = det.debug_conv_run(x, wg, stride, scale, bias, res, None, relu, None, False, False, True, False)
+    assert float(np.abs(out - out32).max()) / (float(np.abs(ref).max()) + 1e-12) < 5e-6
+
+
+def test_conv_split_bf16_wide_exponents(det):
+    """Operands spread over 24 binades and values that need all 24 significand bits: the three-term split is exact
+    (no term under- or overflows in bf16's f32-sized exponent range), so the bar does not move."""
+    rng = np.random.default_rng(11)
+    n, h, w, cin, cout = 1, 16, 16, 64, 64
+    x = (rng.standard_normal((n, h, w, cin)) * np.exp2(rng.integers(-12, 12, (n, h, w, cin)))).astype(np.float32)
+    wg = (rng.standard_normal((cout, 9, cin)) * np.exp2(rng.integers(-12, 12, (cout, 9, cin))) / 24.0).astype(np.float32)
+    out, _ = det.debug_conv_run(x, wg, 1, None, None, None, None, False, None, False, False, True, False, variant=2)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wt = torch.from_numpy(wg).double().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xt, wt, None, 1, 1).permute(0, 2, 3, 1).numpy()
+    mag = F.conv2d(xt.abs(), wt.abs(), None, 1, 1).permute(0, 2, 3, 1).numpy()   # sum |a b|: the scale f32 rounding works on
+    assert float((np.abs(out - ref) / mag).max()) < 4e-6
+
+
 @pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
 def test_cat4_conv_matches_aten(det, bf16):
     """bin_conv1 over the virtual concat [up8(p5), up4(p4), up2(p3), p2] (model.rs:139-146): the kernel

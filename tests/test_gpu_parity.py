@@ -361,6 +361,8 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
     "overlap=1", "overlap=2",                                      # second-stream schedules
     "winograd_ws=1",                                               # wave-specialised fused Winograd kernel
+    "mfma=f32",                                                    # every conv on the exact-f32 MFMA (no split-bf16 kernels)
+    "mfma=f32;bin_pyr=0",
 ])
 def test_engine_modes_agree(det, det_w, options):
     """Every graph-level option of the engine (ocr_det_create_with_options) computes the same
