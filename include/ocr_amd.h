@@ -74,6 +74,9 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches
  *   overlap=0|1|2        (0)    second stream for small independent launches (1) and the FPN branch (2)
+ *   post_threads=<n>     (0)    host threads of the post-processing stages (contours, unclip), the calling thread included;
+ *                               0 = min(16, CPU share of the process: cgroup quota or online cores).  One process per GPU on a
+ *                               shared host should pass its share (cores / ranks)
  *   mfma=split_bf16|f32  (split_bf16)  how the f32 precision multiplies in the MFMA-bound convs that have no Winograd kernel
  *                               of their own (stride-2 3x3, FPN phase convs, bin_conv1 over the pyramid, the Winograd GEMMs of
  *                               layer3 / layer4).  split_bf16: every f32 operand as the exact sum of three bf16 terms, six partial
@@ -108,6 +111,17 @@ int ocr_det_set_precision(ocr_det_t* det, int precision);
  * normalisation - text_detection/mod.rs:46-54), prob is N x 1 x H x W f32 in
  * (0,1).  H and W must be multiples of 32.  Blocking. */
 int ocr_det_forward(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, int mem_kind);
+
+/* The same from the u8 image itself: the reference's frame IS u8 luma, turned into the f32 tensor without scaling
+ * (image_ops.rs:350-364, text_detection/mod.rs:46-51); here that conversion happens inside the first kernel, so a host
+ * batch crosses PCIe as 1 byte per pixel instead of 4.  Bit-identical to ocr_det_forward on (float)x.  Blocking. */
+int ocr_det_forward_u8(ocr_det_t* det, const uint8_t* x, int n, int h, int w, float* prob, int mem_kind);
+
+/* Pinned (page-locked) host memory for frames and maps: host-memory entry points copy from / to such buffers
+ * asynchronously at PCIe speed; ordinary pageable memory also works, at the runtime's staging speed, and makes the
+ * copy part of a call synchronous. */
+int ocr_host_alloc(size_t bytes, void** out);
+void ocr_host_free(void* p);
 
 /* Same, device pointers only, returns after enqueueing on the handle's stream.
  * If bitmap != NULL it also receives binarize(prob, thresh) (metrics.rs:129-131)
@@ -187,6 +201,19 @@ void ocr_polygons_free(ocr_polygons_t* p);
  * batch's polygons come back.  Results are exactly those of ocr_det_forward + ocr_det_postprocess per batch. */
 int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, int w, float* prob_dev,
                              const double* adj_xy, const ocr_postproc_params_t* params, ocr_polygons_t** prev_out);
+
+/* The same pipeline for frames in HOST memory - the form the reference's call sites have (CPU tensors in,
+ * text_detection/mod.rs:46-67).  x_host: N x 1 x H x W frames, OCR_ELEM_F32 or OCR_ELEM_U8 (raw luma, 1/4 of the
+ * bytes).  The call copies them into a double-buffered device staging area on a copy stream (asynchronous for
+ * ocr_host_alloc'ed memory) - beside the forward of the previous batch -, enqueues this batch's forward behind that copy,
+ * and post-processes the previous batch while the GPU works.  The probability map stays on the device unless
+ * prob_host != NULL, which then holds this batch's map once the NEXT call (the one returning its polygons) has returned.
+ * x_host may be reused as soon as the call returns only if it is pageable; a pinned buffer must stay untouched until
+ * the next call returns.  Finish with x_host = NULL. */
+#define OCR_ELEM_F32 0
+#define OCR_ELEM_U8 1
+int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem, int n, int h, int w, float* prob_host,
+                                  const double* adj_xy, const ocr_postproc_params_t* params, ocr_polygons_t** prev_out);
 
 /* Detect -> recognise link (BUILD-DEFINED: the reference never implemented its "Character
  * Segmentation" step, README.md:20-26, so there is no reference rule to match).  For every polygon

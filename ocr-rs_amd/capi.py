@@ -17,12 +17,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCR_AMD_LIB") or os.path.join(_HERE, "lib", "libocr_amd.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
+ELEM_F32, ELEM_U8 = 0, 1
 PRECISION_F32, PRECISION_BF16 = 0, 1
 
 EXPORTS = [
     "ocr_last_error", "ocr_version", "ocr_device_count",
     "ocr_varstore_to_blob", "ocr_blob_free", "ocr_det_create_from_varstore", "ocr_rec_create_from_varstore",
     "ocr_det_create", "ocr_det_create_with_options", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
+    "ocr_det_forward_u8", "ocr_host_alloc", "ocr_host_free", "ocr_det_detect_pipelined_host",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_det_detect_pipelined", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
@@ -81,6 +83,13 @@ def lib() -> C.CDLL:
         L.ocr_det_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.ocr_det_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.ocr_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ocr_det_forward_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ocr_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ocr_host_free.argtypes = [C.c_void_p]
+        L.ocr_host_free.restype = None
+        L.ocr_det_detect_pipelined_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                    C.POINTER(C.c_double), C.POINTER(PostprocParams),
+                                                    C.POINTER(C.POINTER(Polygons))]
         L.ocr_det_forward_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_float]
         L.ocr_det_synchronize.argtypes = [C.c_void_p]
@@ -205,6 +214,30 @@ def default_params(skip_degenerate: bool = False) -> PostprocParams:
     return p
 
 
+class HostBuffer:
+    """Pinned host memory from ocr_host_alloc, viewed as a numpy array (frames / maps of the host-memory entry points)."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        check(lib().ocr_host_alloc(self.nbytes, C.byref(self._p)))
+        buf = (C.c_char * self.nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            lib().ocr_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Detector:
     """Owns an ocr_det_t.  Mirrors `resnet18(&vs.root())` + `vs.load(..)`
     (/root/reference/src/text_detection/mod.rs:35-44)."""
@@ -248,6 +281,42 @@ class Detector:
         prob = np.empty((n, 1, h, w), np.float32)
         check(lib().ocr_det_forward(self._h, _ptr(x), n, h, w, _ptr(prob), MEM_HOST))
         return prob
+
+    def forward_host_u8(self, x: np.ndarray) -> np.ndarray:
+        """ocr_det_forward_u8 on a host batch of raw u8 luma frames (the reference's image type)."""
+        x = np.ascontiguousarray(x, dtype=np.uint8)
+        n, c, h, w = x.shape
+        assert c == 1
+        prob = np.empty((n, 1, h, w), np.float32)
+        check(lib().ocr_det_forward_u8(self._h, _ptr(x), n, h, w, _ptr(prob), MEM_HOST))
+        return prob
+
+    def forward_u8_device(self, x_ptr: int, n: int, h: int, w: int, prob_ptr: int) -> None:
+        """ocr_det_forward_u8 on device pointers (blocking)."""
+        check(lib().ocr_det_forward_u8(self._h, x_ptr, n, h, w, prob_ptr, MEM_DEVICE))
+
+    def detect_pipelined_host(self, x, n: int = 0, h: int = 0, w: int = 0, adjust_values=None, prob_out=None,
+                              params: Optional[PostprocParams] = None, convert: bool = True):
+        """ocr_det_detect_pipelined_host: x is a host array of frames (float32 or uint8, N x 1 x H x W; a HostBuffer view
+        keeps the copy asynchronous) or None to flush.  Returns the PREVIOUS batch's polygons (None on the first call)."""
+        adj_p = None
+        xp, elem = None, ELEM_F32
+        if x is not None:
+            assert x.flags["C_CONTIGUOUS"] and x.dtype in (np.float32, np.uint8)
+            n, _, h, w = x.shape
+            elem = ELEM_U8 if x.dtype == np.uint8 else ELEM_F32
+            xp = _ptr(x)
+            adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+            adj_p = adj.ctypes.data_as(C.POINTER(C.c_double))
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_detect_pipelined_host(self._h, xp, elem, n, h, w, _ptr(prob_out) if prob_out is not None else None, adj_p,
+                                                  C.byref(params) if params is not None else None, C.byref(out)))
+        if not out:
+            return None
+        try:
+            return polygons_to_python(out) if convert else (out.contents.n_polygons, out.contents.n_vertices)
+        finally:
+            lib().ocr_polygons_free(out)
 
     def forward_device(self, x_ptr: int, n: int, h: int, w: int, prob_ptr: int, bitmap_ptr: int = 0,
                        thresh: float = 0.6) -> None:

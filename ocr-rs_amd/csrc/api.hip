@@ -217,7 +217,7 @@ int ocr_det_forward(ocr_det_t* det, const float* x, int n, int h, int w, float* 
     if (mem_kind == OCR_MEM_HOST) {
       if (!x || !prob) ocr::fail(OCR_ERR_INVALID, "det_forward: null tensor");
       if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32) ocr::fail(OCR_ERR_INVALID, "det_forward: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
-      det->impl.forward_host(x, n, h, w, prob);
+      det->impl.forward_host(x, 0, n, h, w, prob);
     } else if (mem_kind == OCR_MEM_DEVICE) {
       det->impl.forward(x, n, h, w, prob, nullptr, 0.f, nullptr);
       det->impl.synchronize();
@@ -225,6 +225,33 @@ int ocr_det_forward(ocr_det_t* det, const float* x, int n, int h, int w, float* 
       ocr::fail(OCR_ERR_INVALID, "mem_kind %d", mem_kind);
     }
   });
+}
+
+int ocr_det_forward_u8(ocr_det_t* det, const uint8_t* x, int n, int h, int w, float* prob, int mem_kind) {
+  return guard([&] {
+    if (!det) ocr::fail(OCR_ERR_INVALID, "null handle");
+    if (!x || !prob) ocr::fail(OCR_ERR_INVALID, "det_forward_u8: null tensor");
+    if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32) ocr::fail(OCR_ERR_INVALID, "det_forward_u8: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
+    if (mem_kind == OCR_MEM_HOST) {
+      det->impl.forward_host(x, 1, n, h, w, prob);
+    } else if (mem_kind == OCR_MEM_DEVICE) {
+      det->impl.forward(x, n, h, w, prob, nullptr, 0.f, nullptr, 1);
+      det->impl.synchronize();
+    } else {
+      ocr::fail(OCR_ERR_INVALID, "mem_kind %d", mem_kind);
+    }
+  });
+}
+
+int ocr_host_alloc(size_t bytes, void** out) {
+  return guard([&] {
+    if (!out) ocr::fail(OCR_ERR_INVALID, "ocr_host_alloc: out is null");
+    *out = nullptr;
+    OCR_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  });
+}
+void ocr_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int ocr_det_forward_async(ocr_det_t* det, const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh) {
@@ -418,6 +445,51 @@ int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, i
     if (prev.valid) {
       hipStream_t ps = d.post_stream();
       OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
+    }
+  });
+}
+
+int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem, int n, int h, int w, float* prob_host,
+                                  const double* adj_xy, const ocr_postproc_params_t* params, ocr_polygons_t** prev_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !prev_out) fail(OCR_ERR_INVALID, "detect_pipelined_host: null argument");
+    *prev_out = nullptr;
+    Detector& d = det->impl;
+    OCR_HIP(hipSetDevice(d.device()));
+    Detector::Pending next;
+    if (x_host) {
+      if (!adj_xy) fail(OCR_ERR_INVALID, "detect_pipelined_host: null adjust values");
+      if (x_elem != OCR_ELEM_F32 && x_elem != OCR_ELEM_U8) fail(OCR_ERR_INVALID, "detect_pipelined_host: element kind %d", x_elem);
+      if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32) fail(OCR_ERR_INVALID, "detect_pipelined_host: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
+      const size_t es = x_elem == OCR_ELEM_U8 ? 1 : 4, px = (size_t)n * h * w;
+      d.ensure_staging(px * es, px);
+      // this batch's frames into the free input slot (the slot's previous forward was awaited when ITS polygons came back),
+      // the forward behind the copy; the map stays on the device
+      const int slot = d.next_stage_slot();
+      hipEvent_t arrived;
+      const void* xd = d.stage_input(slot, x_host, px * es, &arrived);
+      d.forward(xd, n, h, w, d.stage_prob(slot), nullptr, 0.f, nullptr, x_elem == OCR_ELEM_U8 ? 1 : 0, arrived);
+      OCR_HIP(hipEventRecord(d.forward_done_event(slot), d.stream()));
+      d.stage_used();
+      next.prob = d.stage_prob(slot);
+      next.prob_host = prob_host;
+      next.n = n;
+      next.h = h;
+      next.w = w;
+      next.adj.assign(adj_xy, adj_xy + 2 * (size_t)n);
+      ocr_postproc_default_params(&next.params);
+      if (params) next.params = *params;
+      next.event = d.forward_done_event(slot);
+      next.valid = true;
+    }
+    Detector::Pending prev = d.swap_pending(next);
+    if (prev.valid) {
+      hipStream_t ps = d.post_stream();
+      OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
+      if (prev.prob_host)   // the caller asked for the map too: it leaves on the same stream, ahead of the bit image
+        OCR_HIP(hipMemcpyAsync(prev.prob_host, prev.prob, (size_t)prev.n * prev.h * prev.w * 4, hipMemcpyDeviceToHost, ps));
       postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
     }
   });

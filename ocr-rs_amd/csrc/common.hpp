@@ -93,12 +93,18 @@ void set_conv_tile_override(int t);  // tuning aid: 0 = automatic
 void set_conv_debug(int d);          // ablation bits, effective in -DIGEMM_DEBUG builds only
 
 // stem: conv7x7 s2 p3 (Cin=1) + BN + ReLU + maxpool3x3 s2 p1 -> NHWC 64 channels at H/4
-void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias,
+// x: N x H x W frames, f32 or (x_u8 != 0) u8 raw luma - the reference's u8 image converted to f32 without scaling
+void launch_stem(const void* x, int x_u8, const float* w49x64, const float* scale, const float* bias,
                  void* out, int out_bf16, int N, int H, int W, hipStream_t s);
 // bf16 precision: the same stem with conv1 on v_mfma_f32_32x32x16_bf16 (weights as fragments from stem_bf16_fragments)
 std::vector<uint16_t> stem_bf16_fragments(const float* w64x49);
-void launch_stem_bf16(const float* x, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
+void launch_stem_bf16(const void* x, int x_u8, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
                       hipStream_t s);
+// f32 precision on the bf16 matrix cores (mfma=split_bf16): frame and weights as three bf16 terms each, six partial products,
+// f32 accumulate and f32 output (weights from stem_x3_fragments)
+std::vector<uint16_t> stem_x3_fragments(const float* w64x49);
+void launch_stem_x3(const void* x, int x_u8, const void* wfrag3, const float* scale, const float* bias, float* out, int N, int H, int W,
+                    hipStream_t s);
 // bf16 precision: 3x3 s1 p1 conv 64 -> 64 with the input patch staged once in LDS and register-resident weights
 // (conv3x3_bf16_c64.hip); wfrag from conv3x3_bf16_c64_fragments([Cout 64][9][Cin 64] f32)
 std::vector<uint16_t> conv3x3_bf16_c64_fragments(const float* ohwi);

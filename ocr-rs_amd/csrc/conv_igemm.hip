@@ -991,9 +991,12 @@ static Tile pick_tile(const ConvDesc& d) {
   if (d.x3) {  // the split-bf16 kernels exist as 128 x 128 and 128 x 64 only
     const long long M = (long long)d.N * d.Ho * d.Wo;
     const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : (d.batch > 1 ? d.batch : 1);
+    (void)M;
+    (void)reps;
+    // 128 x 128 wherever Cout allows it, however few tiles that leaves (measured on every launch shape of the detector,
+    // tools/profile_layers.py with the tile override: operand DMA per MFMA is what the wide tile saves)
     if (g_tile_override == 2 || d.Cout % 128 || d.src_mode == SRC_PYR4) return T128x64;
-    if (g_tile_override == 1) return T128x128;
-    return ((M + 127) / 128) * (d.Cout / 128) * reps >= 1024 ? T128x128 : T128x64;
+    return T128x128;
   }
   if (g_tile_override == 1 && d.Cout % 128 == 0) return T128x128;
   if (g_tile_override == 2) return T128x64;

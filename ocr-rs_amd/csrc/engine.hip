@@ -255,6 +255,10 @@ void Detector::parse_options(const char* options) {
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") overlap_ = num();
+    else if (key == "post_threads") {
+      post_threads_ = num();
+      if (post_threads_ < 0 || post_threads_ > 256) fail(OCR_ERR_INVALID, "detector option post_threads: %d (0 = automatic, at most 256)", post_threads_);
+    }
     else if (key == "mfma") {
       if (val == "split_bf16") split_bf16_ = true;
       else if (val == "f32") split_bf16_ = false;
@@ -304,6 +308,7 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     fold_bn(wb, "bn1", 64, s, b);
     stem_scale_ = arena_.upload(s);
     stem_bias_ = arena_.upload(b);
+    if (split_bf16_) stem_wx3_ = arena_.upload_u16(stem_x3_fragments(w));
   }
   int cin = 64;
   for (int l = 0; l < 4; ++l) {
@@ -431,6 +436,7 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     tr1_.cin = 64;
     tr1_.cout = 256;
     tr1_.ks = 1;
+    if (split_bf16_) tr1_.w_x3 = arena_.upload_u16(split3_weights(tr1_.host.data(), tr1_.host.size()));
   }
   {  // bin_conv_tr2 [64][1][2][2] -> [4][64]
     const float* w = wb.get("bin_conv_tr2.weight", {64, 1, 2, 2}).data;
@@ -539,16 +545,42 @@ Detector::~Detector() {
   free_workspace();
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
-  if (stage_in_) (void)hipFree(stage_in_);
-  if (stage_out_) (void)hipFree(stage_out_);
+  for (int i = 0; i < 2; ++i) {
+    if (stage_in_[i]) (void)hipFree(stage_in_[i]);
+    if (stage_out_[i]) (void)hipFree(stage_out_[i]);
+    if (ev_in_[i]) (void)hipEventDestroy(ev_in_[i]);
+    if (ev_fwd_[i]) (void)hipEventDestroy(ev_fwd_[i]);
+    if (ev_out_[i]) (void)hipEventDestroy(ev_out_[i]);
+  }
+  if (copy_stream_) {
+    (void)hipStreamSynchronize(copy_stream_);
+    (void)hipStreamDestroy(copy_stream_);
+    (void)hipStreamSynchronize(out_stream_);
+    (void)hipStreamDestroy(out_stream_);
+  }
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
-ThreadPool& Detector::pool() {
-  if (!pool_) {
-    const unsigned hc = std::thread::hardware_concurrency();
-    pool_ = std::make_unique<ThreadPool>((int)std::min(15u, hc > 1 ? hc - 1 : 0u));  // + the calling thread
+// CPU share of this process: the cgroup quota where there is one (a container on a big host), else the online cores
+static int host_cpu_share() {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    long long period = 0;
+    if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+      const long long q = std::atoll(quota) / period;
+      if (q >= 1 && (unsigned)q < n) n = (unsigned)q;
+    }
+    std::fclose(f);
   }
+  return (int)n;
+}
+
+int Detector::post_threads() const { return post_threads_ > 0 ? post_threads_ : std::min(16, host_cpu_share()); }
+
+ThreadPool& Detector::pool() {
+  if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread
   return *pool_;
 }
 
@@ -678,8 +710,8 @@ struct Recorder {
 };
 }  // namespace
 
-void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
-                       std::vector<ProfileEntry>* prof) {
+void Detector::forward(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+                       std::vector<ProfileEntry>* prof, int x_u8, hipEvent_t wait_for) {
   if (!x || !prob) fail(OCR_ERR_INVALID, "det_forward: null tensor");
   if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32)
     fail(OCR_ERR_INVALID, "det_forward: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
@@ -692,12 +724,13 @@ void Detector::forward(const float* x, int n, int h, int w, float* prob, uint8_t
   for (int b = 0; b < n; b += max_n) {
     const int nb = std::min(max_n, n - b);
     const size_t off = (size_t)b * h * w;
-    forward_chunk(x + off, nb, h, w, prob + off, bitmap ? bitmap + off : nullptr, thresh, prof);
+    if (wait_for && b == 0) OCR_HIP(hipStreamWaitEvent(stream_, wait_for, 0));   // e.g. the copy that brings x in
+    forward_chunk(static_cast<const char*>(x) + off * (x_u8 ? 1 : 4), nb, h, w, prob + off, bitmap ? bitmap + off : nullptr, thresh, prof, x_u8);
   }
 }
 
-void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
-                             std::vector<ProfileEntry>* prof) {
+void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+                             std::vector<ProfileEntry>* prof, int x_u8) {
   ensure_workspace(n, h, w);
   Recorder rec(prof, stream_);
 
@@ -795,10 +828,11 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
 
   const int h4 = h / 4, w4 = w / 4;
   rec.begin();
-  if (bf) launch_stem_bf16(x, stem_wb_, stem_scale_, stem_bias_, s_, n, h, w, stream_);
-  else launch_stem(x, stem_w_, stem_scale_, stem_bias_, s_, 0, n, h, w, stream_);
-  rec.end("stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
-          (double)n * h * w * 4 + (double)n * h4 * w4 * 64 * (double)es);
+  if (bf) launch_stem_bf16(x, x_u8, stem_wb_, stem_scale_, stem_bias_, s_, n, h, w, stream_);
+  else if (stem_wx3_) launch_stem_x3(x, x_u8, stem_wx3_, stem_scale_, stem_bias_, reinterpret_cast<float*>(s_), n, h, w, stream_);
+  else launch_stem(x, x_u8, stem_w_, stem_scale_, stem_bias_, s_, 0, n, h, w, stream_);
+  rec.end(!bf && stem_wx3_ ? "stem_x3_conv7x7_bn_relu_maxpool" : "stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
+          (double)n * h * w * (x_u8 ? 1 : 4) + (double)n * h4 * w4 * 64 * (double)es);
 
   // 3x3 s1 conv + BN (+ residual) + ReLU of the deep layers as Winograd F(2x2,3x3): input transform, sixteen
   // [tiles x Cin] x [Cin x Cout] GEMMs in one batched launch, output transform with the epilogue (f32 only)
@@ -1026,9 +1060,10 @@ void Detector::forward_chunk(const float* x, int n, int h, int w, float* prob, u
     // bin_conv_tr1 + bias + bin_bn2 + relu + bin_conv_tr2 + bias + sigmoid (+ binarize) in one kernel:
     // the 64-channel H/2 x W/2 intermediate never reaches HBM.  model.rs:146-150
     rec.begin();
-    launch_tail_fused(b1_, bf ? tr1_.w_bf16 : static_cast<const void*>(tr1_.w), bf ? 1 : 0, tr1_.scale, tr1_.bias, tr2_wt_, tr2_bias_,
-                      prob, bitmap, thresh, n, h4, w4, stream_);
-    rec.end("tail_convt1_bn_relu_convt2_sigmoid", 2.0 * n * h4 * w4 * 64.0 * 256 + 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
+    const bool tail_x3 = !bf && split_bf16_ && tr1_.w_x3;
+    launch_tail_fused(b1_, bf ? tr1_.w_bf16 : tail_x3 ? tr1_.w_x3 : static_cast<const void*>(tr1_.w), bf ? 1 : tail_x3 ? 2 : 0, tr1_.scale, tr1_.bias,
+                      tr2_wt_, tr2_bias_, prob, bitmap, thresh, n, h4, w4, stream_);
+    rec.end(tail_x3 ? "tail_x3_convt1_bn_relu_convt2_sigmoid" : "tail_convt1_bn_relu_convt2_sigmoid", 2.0 * n * h4 * w4 * 64.0 * 256 + 2.0 * n * (h / 2) * (w / 2) * 64 * 4,
             (double)n * h4 * w4 * 64 * (double)es + (double)n * h * w * 4);
   } else {
     // bin_conv_tr1 + bias + bin_bn2 + relu, model.rs:146-148
@@ -1064,22 +1099,71 @@ const float* Detector::stage(int id, size_t* elems) const {
   fail(OCR_ERR_INVALID, "unknown stage %d", id);
 }
 
-void Detector::forward_host(const float* x, int n, int h, int w, float* prob) {
-  OCR_HIP(hipSetDevice(device_));
-  const size_t elems = (size_t)n * h * w;
-  if (elems > stage_elems_) {
-    OCR_HIP(hipStreamSynchronize(stream_));
-    if (stage_in_) OCR_HIP(hipFree(stage_in_));
-    if (stage_out_) OCR_HIP(hipFree(stage_out_));
-    stage_in_ = stage_out_ = nullptr;
-    stage_elems_ = 0;
-    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&stage_in_), elems * 4));
-    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&stage_out_), elems * 4));
-    stage_elems_ = elems;
+// ---- host-memory entry points.  The reference hands CPU tensors to forward_t (text_detection/mod.rs:46-54); here the
+// frames cross PCIe into a double-buffered device staging area on a copy stream while the previous piece computes.
+// Pinned host memory (ocr_host_alloc) makes those copies asynchronous and full speed; pageable memory works too (the HIP
+// runtime stages it itself and the call blocks for the duration of each copy).
+void Detector::ensure_staging(size_t in_bytes, size_t prob_elems) {
+  if (!copy_stream_) {
+    OCR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    OCR_HIP(hipStreamCreateWithFlags(&out_stream_, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      OCR_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&ev_fwd_[i], hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&ev_out_[i], hipEventDisableTiming));
+    }
   }
-  OCR_HIP(hipMemcpyAsync(stage_in_, x, elems * 4, hipMemcpyHostToDevice, stream_));
-  forward(stage_in_, n, h, w, stage_out_, nullptr, 0.f, nullptr);
-  OCR_HIP(hipMemcpyAsync(prob, stage_out_, elems * 4, hipMemcpyDeviceToHost, stream_));
+  if (in_bytes > stage_in_bytes_ || prob_elems > stage_elems_) {
+    OCR_HIP(hipStreamSynchronize(stream_));
+    OCR_HIP(hipStreamSynchronize(copy_stream_));
+    OCR_HIP(hipStreamSynchronize(out_stream_));
+    for (int i = 0; i < 2; ++i) {
+      if (stage_in_[i]) OCR_HIP(hipFree(stage_in_[i]));
+      if (stage_out_[i]) OCR_HIP(hipFree(stage_out_[i]));
+      stage_in_[i] = nullptr;
+      stage_out_[i] = nullptr;
+    }
+    stage_in_bytes_ = std::max(in_bytes, stage_in_bytes_);
+    stage_elems_ = std::max(prob_elems, stage_elems_);
+    for (int i = 0; i < 2; ++i) {
+      OCR_HIP(hipMalloc(&stage_in_[i], stage_in_bytes_));
+      OCR_HIP(hipMalloc(reinterpret_cast<void**>(&stage_out_[i]), stage_elems_ * 4));
+    }
+    stage_uses_ = 0;
+  }
+}
+
+// frames of the host batch -> staging slot (asynchronous when x is pinned); returns the device pointer and the event
+// that marks their arrival.  The slot's previous user (two pieces ago) must have finished its forward: ev_fwd_.
+const void* Detector::stage_input(int slot, const void* x_host, size_t bytes, hipEvent_t* arrived) {
+  if (stage_uses_ >= 2) OCR_HIP(hipStreamWaitEvent(copy_stream_, ev_fwd_[slot], 0));
+  OCR_HIP(hipMemcpyAsync(stage_in_[slot], x_host, bytes, hipMemcpyHostToDevice, copy_stream_));
+  OCR_HIP(hipEventRecord(ev_in_[slot], copy_stream_));
+  *arrived = ev_in_[slot];
+  return stage_in_[slot];
+}
+
+void Detector::forward_host(const void* x, int x_u8, int n, int h, int w, float* prob) {
+  OCR_HIP(hipSetDevice(device_));
+  const size_t es = x_u8 ? 1 : 4, frame = (size_t)h * w;
+  // pieces of at least 8 frames, at most four of them: the copy in of piece i + 1 and the copy out of piece i - 1 run
+  // beside the forward of piece i
+  const int piece = std::max(8, (n + 3) / 4);
+  ensure_staging((size_t)piece * frame * es, (size_t)piece * frame);
+  int k = 0;
+  for (int b = 0; b < n; b += piece, ++k) {
+    const int nb = std::min(piece, n - b), slot = k & 1;
+    hipEvent_t arrived;
+    const void* xd = stage_input(slot, static_cast<const char*>(x) + (size_t)b * frame * es, (size_t)nb * frame * es, &arrived);
+    if (stage_uses_ >= 2) OCR_HIP(hipStreamWaitEvent(stream_, ev_out_[slot], 0));   // the slot's previous map has left
+    forward(xd, nb, h, w, stage_out_[slot], nullptr, 0.f, nullptr, x_u8, arrived);
+    OCR_HIP(hipEventRecord(ev_fwd_[slot], stream_));
+    OCR_HIP(hipStreamWaitEvent(out_stream_, ev_fwd_[slot], 0));
+    OCR_HIP(hipMemcpyAsync(prob + (size_t)b * frame, stage_out_[slot], (size_t)nb * frame * 4, hipMemcpyDeviceToHost, out_stream_));
+    OCR_HIP(hipEventRecord(ev_out_[slot], out_stream_));
+    ++stage_uses_;
+  }
+  OCR_HIP(hipStreamSynchronize(out_stream_));
   OCR_HIP(hipStreamSynchronize(stream_));
 }
 

@@ -68,9 +68,21 @@ class Detector {
   void set_precision(int precision);
   int precision() const { return bf16_ ? 1 : 0; }
   // device pointers; enqueues on stream().  prof != null -> per-launch events.
-  void forward(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
-               std::vector<ProfileEntry>* prof);
-  void forward_host(const float* x, int n, int h, int w, float* prob);
+  // x: N x 1 x H x W frames, f32 or (x_u8 != 0) u8 raw luma; wait_for: an event the first launch waits for (the
+  // copy that brings x in), may be null
+  void forward(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+               std::vector<ProfileEntry>* prof, int x_u8 = 0, hipEvent_t wait_for = nullptr);
+  // host tensors in and out, blocking; copies and forward pipelined over pieces of the batch
+  void forward_host(const void* x, int x_u8, int n, int h, int w, float* prob);
+  // device staging of the host-memory entry points: two input slots and two map slots, a copy-in and a copy-out stream
+  void ensure_staging(size_t in_bytes, size_t prob_elems);
+  const void* stage_input(int slot, const void* x_host, size_t bytes, hipEvent_t* arrived);
+  float* stage_prob(int slot) { return stage_out_[slot]; }
+  hipStream_t out_stream() { return out_stream_; }
+  hipEvent_t forward_done_event(int slot) { return ev_fwd_[slot]; }
+  int next_stage_slot() { return (int)(stage_uses_ & 1); }
+  void stage_used() { ++stage_uses_; }
+  int post_threads() const;      // host threads of the post-processing stages (option post_threads, default min(16, CPU share))
   // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
@@ -80,6 +92,7 @@ class Detector {
   struct Pending {
     bool valid = false;
     const float* prob = nullptr;
+    float* prob_host = nullptr;   // host-memory variant: where the caller wants the map as well (may be null)
     int n = 0, h = 0, w = 0;
     std::vector<double> adj;
     ocr_postproc_params_t params{};
@@ -117,6 +130,7 @@ class Detector {
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
   std::vector<float> stem_w_host_;  // conv1 [64][49], kept for the bf16 fragments
   void* stem_wb_ = nullptr;         // conv1 as bf16 MFMA fragments (stem_bf16_fragments), filled by set_precision
+  void* stem_wx3_ = nullptr;        // conv1 as three bf16 fragment sets (stem_x3_fragments): mfma=split_bf16
   ConvW layer_[4][2][2];  // [layer][block][conv1|conv2]
   ConvW down_[4];         // [layer] (layer 0 unused)
   ConvW in_[4];           // in2..in5
@@ -173,8 +187,8 @@ class Detector {
   float *b1_ = nullptr, *tr1buf_ = nullptr;
   std::vector<ConvW*> all_convs_;
   size_t pcat_bytes_ = 0;
-  void forward_chunk(const float* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
-                     std::vector<ProfileEntry>* prof);
+  void forward_chunk(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
+                     std::vector<ProfileEntry>* prof, int x_u8);
   std::unique_ptr<ThreadPool> pool_;
   Pending pending_;
   hipStream_t post_stream_ = nullptr;
@@ -182,8 +196,13 @@ class Detector {
   int pipe_ev_next_ = 0;
   void* scratch_[2] = {nullptr, nullptr};
   size_t scratch_bytes_[2] = {0, 0};
-  float *stage_in_ = nullptr, *stage_out_ = nullptr;
-  size_t stage_elems_ = 0;
+  void* stage_in_[2] = {nullptr, nullptr};
+  float* stage_out_[2] = {nullptr, nullptr};
+  size_t stage_in_bytes_ = 0, stage_elems_ = 0;
+  unsigned long long stage_uses_ = 0;   // pieces staged since the buffers were (re)allocated
+  hipStream_t copy_stream_ = nullptr, out_stream_ = nullptr;
+  hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_fwd_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};
+  int post_threads_ = 0;   // option post_threads: 0 = automatic
 };
 
 class Recognizer {

@@ -4,6 +4,7 @@
 //   tail : bin_conv_tr2 convT 2x2 s2 (64->1) + bias + sigmoid, optional fused
 //          binarize(pred, thresh)      model.rs:149-150, metrics.rs:129-131
 #include <cstring>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -41,8 +42,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // A read feeds two MFMAs, every wave does the same amount of work).  BN + ReLU on the accumulators, conv tile
 // to LDS, then the 3x3 s2 max pool.
 constexpr int NT = 64 * MTILES;
-template <typename TO>
-__global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w49x64,
+// TX: element type of the frames - float, or uint8_t (the reference's image IS u8, image_ops.rs:350-364: raw 0..255 luma
+// converted to f32 without scaling; the cast here is that conversion, exact)
+template <typename TO, typename TX>
+__global__ __launch_bounds__(NT) void stem_kernel(const TX* __restrict__ x, const float* __restrict__ w49x64,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
                                                    TO* __restrict__ out, int H, int W) {
   __shared__ __attribute__((aligned(16))) float in_s[2 * PLANE];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, c
   const int Hc = H >> 1, Wc = W >> 1, Hp = H >> 2, Wp = W >> 2;
   const int cr0 = 2 * ph0 - 1;
   const int ir0 = 2 * cr0 - 3;
-  const float* xin = x + (size_t)n * H * W;
+  const TX* xin = x + (size_t)n * H * W;
   const int half = lane >> 5, l31 = lane & 31;
   // B operand: weight of tap 2s + half for channel 32 ct + (lane & 31); the padded tap 49 is zero
   float wreg[2][KSTEPS];
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(NT) void stem_kernel(const float* __restrict__ x, c
     const int rr = i / ICP, cc = i - rr * ICP;
     const int ih = ir0 + rr, iw = ic0 + cc;
     float v = 0.f;  // zero padding of conv1 (and the pad column)
-    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[(size_t)ih * W + iw];
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = (float)xin[(size_t)ih * W + iw];
     in_s[(cc & 1) * PLANE + rr * PW + (cc >> 1)] = v;
   }
   __syncthreads();  // also: every wave has left the previous tile's pool phase (conv_s is free)
@@ -155,10 +158,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int IRB = IR + 1;      // one more row: window row 7 of the last conv row (zero weight, must be finite)
 constexpr int PWB = 36;          // bf16 per image row (72 bytes): 32 used
-__global__ __launch_bounds__(NT) void stem_bf16_kernel(const float* __restrict__ x, const u32x4* __restrict__ wfrag,
+// X3: the f32 stem on the bf16 matrix cores - the input tile as three bf16 images (pixel = hi + mid + lo exactly), the
+// weights as three fragment sets, six partial products per window (mid.lo, lo.mid, lo.lo are below 2^-23 of a product),
+// f32 accumulate, f32 output: 48 MFMAs of 32 cycles per wave and tile where the exact-f32 kernel above issues 56 of 64.
+template <bool X3, typename TX>
+__global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x, const u32x4* __restrict__ wfrag,
                                                        const float* __restrict__ scale, const float* __restrict__ bias,
-                                                       __bf16* __restrict__ out, int H, int W) {
-  __shared__ __attribute__((aligned(16))) unsigned in_s[IRB * PWB / 2];   // two bf16 per word
+                                                       std::conditional_t<X3, float, __bf16>* __restrict__ out, int H, int W) {
+  constexpr int NPL = X3 ? 3 : 1;                       // bf16 images of the input tile / weight fragment sets
+  constexpr int IMG = IRB * PWB / 2;                    // words per image (two bf16 per word)
+  __shared__ __attribute__((aligned(16))) unsigned in_s[NPL * IMG];
   __shared__ __attribute__((aligned(16))) float conv_s[32 * MTILES][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,16 +176,18 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const float* __restrict__
   const int Hc = H >> 1, Wc = W >> 1, Hp = H >> 2, Wp = W >> 2;
   const int cr0 = 2 * ph0 - 1;
   const int ir0 = 2 * cr0 - 3;
-  const float* xin = x + (size_t)n * H * W;
+  const TX* xin = x + (size_t)n * H * W;
   const int half = lane >> 5, l31 = lane & 31;
   // B operand of step s, channel tile ct: weights of window row 2 s + half, columns 0..7, channel 32 ct + (lane & 31)
-  bf16x8 wreg[2][4];
+  bf16x8 wreg[NPL][2][4];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wreg[ct][s] = __builtin_bit_cast(bf16x8, wfrag[(ct * 4 + s) * 64 + lane]);
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wreg[pl][ct][s] = __builtin_bit_cast(bf16x8, wfrag[((pl * 2 + ct) * 4 + s) * 64 + lane]);
   const float sc0 = scale[l31], bi0 = bias[l31], sc1 = scale[32 + l31], bi1 = bias[32 + l31];
-  for (int i = tid; i < PWB / 2; i += NT) in_s[(IRB - 1) * (PWB / 2) + i] = 0u;  // the extra row
+  for (int i = tid; i < NPL * (PWB / 2); i += NT) in_s[(i / (PWB / 2)) * IMG + (IRB - 1) * (PWB / 2) + i % (PWB / 2)] = 0u;  // the extra row
   for (int tl = 0; tl < TL; ++tl) {
     const int pw0 = (blockIdx.x * TL + tl) * TPW;
     if (pw0 >= Wp) break;
@@ -187,12 +198,19 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const float* __restrict__
       const int ih = ir0 + rr, iw = ic0 + 2 * cp;
       float v0 = 0.f, v1 = 0.f;  // zero padding of conv1
       if ((unsigned)ih < (unsigned)H) {
-        if ((unsigned)iw < (unsigned)W) v0 = xin[(size_t)ih * W + iw];
-        if ((unsigned)(iw + 1) < (unsigned)W) v1 = xin[(size_t)ih * W + iw + 1];
+        if ((unsigned)iw < (unsigned)W) v0 = (float)xin[(size_t)ih * W + iw];
+        if ((unsigned)(iw + 1) < (unsigned)W) v1 = (float)xin[(size_t)ih * W + iw + 1];
       }
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const bf16x2 pk = {(__bf16)v0, (__bf16)v1};
       in_s[rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pk);
+      if constexpr (X3) {   // remainders are exact in f32; round to nearest even at every level
+        const float r0 = v0 - (float)pk[0], r1 = v1 - (float)pk[1];
+        const bf16x2 pm = {(__bf16)r0, (__bf16)r1};
+        const bf16x2 pl = {(__bf16)(r0 - (float)pm[0]), (__bf16)(r1 - (float)pm[1])};
+        in_s[IMG + rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pm);
+        in_s[2 * IMG + rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pl);
+      }
     }
     __syncthreads();
     {
@@ -205,12 +223,25 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const float* __restrict__
       for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        u32x4 a;
+        bf16x8 af[NPL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = row[2 * s * (PWB / 2) + k];
-        const bf16x8 af = __builtin_bit_cast(bf16x8, a);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[1][s], acc1, 0, 0, 0);
+        for (int pl = 0; pl < NPL; ++pl) {
+          u32x4 a;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[k] = row[pl * IMG + 2 * s * (PWB / 2) + k];
+          af[pl] = __builtin_bit_cast(bf16x8, a);
+        }
+        if constexpr (X3) {   // small terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], wreg[PB[q]][0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], wreg[PB[q]][1][s], acc1, 0, 0, 0);
+          }
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wreg[0][0][s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wreg[0][1][s], acc1, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -236,9 +267,14 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
           }
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        const bf16x4 hv = {(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
-        *reinterpret_cast<bf16x4*>(out + (((size_t)n * Hp + ph) * Wp + pw) * 64 + c4) = hv;
+        auto* dst = out + (((size_t)n * Hp + ph) * Wp + pw) * 64 + c4;
+        if constexpr (X3) {
+          *reinterpret_cast<f32x4*>(dst) = m;
+        } else {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          const bf16x4 hv = {(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+          *reinterpret_cast<bf16x4*>(dst) = hv;
+        }
       }
     }
   }  // tl
@@ -312,18 +348,55 @@ void launch_binarize_pack(const float* prob, uint32_t* bits, float thresh, int n
   OCR_HIP(hipGetLastError());
 }
 
-void launch_stem(const float* x, const float* w49x64, const float* scale, const float* bias, void* out, int out_bf16, int N,
+void launch_stem(const void* x, int x_u8, const float* w49x64, const float* scale, const float* bias, void* out, int out_bf16, int N,
                  int H, int W, hipStream_t s) {
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
   dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
-  if (out_bf16) hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(NT), 0, s, x, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
-  else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(NT), 0, s, x, w49x64, scale, bias, static_cast<float*>(out), H, W);
+  const float* xf = static_cast<const float*>(x);
+  const uint8_t* xb = static_cast<const uint8_t*>(x);
+  if (out_bf16 && x_u8) hipLaunchKernelGGL((stem_kernel<__bf16, uint8_t>), grid, dim3(NT), 0, s, xb, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
+  else if (out_bf16) hipLaunchKernelGGL((stem_kernel<__bf16, float>), grid, dim3(NT), 0, s, xf, w49x64, scale, bias, static_cast<__bf16*>(out), H, W);
+  else if (x_u8) hipLaunchKernelGGL((stem_kernel<float, uint8_t>), grid, dim3(NT), 0, s, xb, w49x64, scale, bias, static_cast<float*>(out), H, W);
+  else hipLaunchKernelGGL((stem_kernel<float, float>), grid, dim3(NT), 0, s, xf, w49x64, scale, bias, static_cast<float*>(out), H, W);
   OCR_HIP(hipGetLastError());
 }
 
 // conv1 [64][1][7][7] (f32) -> bf16 MFMA B fragments [2 channel tiles][4 steps][64 lanes][8]: element j of lane
 // (co = 32 ct + (l & 31), half = l >> 5) is w[co][kh = 2 s + half][kw = j], zero for kh = 7 or kw = 7
+// the same as three fragment sets hi / mid / lo (w = hi + mid + lo exactly) for the split-bf16 stem
+std::vector<uint16_t> stem_x3_fragments(const float* w64x49) {
+  auto bf = [](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  };
+  auto up = [](uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  const size_t plane = (size_t)2 * 4 * 64 * 8;
+  std::vector<uint16_t> fr(3 * plane, 0);
+  for (int ct = 0; ct < 2; ++ct)
+    for (int s = 0; s < 4; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int co = 32 * ct + (l & 31), kh = 2 * s + (l >> 5);
+          if (kh >= 7 || j >= 7) continue;
+          const float w = w64x49[co * 49 + kh * 7 + j];
+          const uint16_t h = bf(w);
+          const float r1 = w - up(h);
+          const uint16_t m = bf(r1);
+          const size_t o = (((size_t)ct * 4 + s) * 64 + l) * 8 + j;
+          fr[o] = h;
+          fr[plane + o] = m;
+          fr[2 * plane + o] = bf(r1 - up(m));
+        }
+  return fr;
+}
+
 std::vector<uint16_t> stem_bf16_fragments(const float* w64x49) {
   auto bf = [](float f) {
     uint32_t u;
@@ -341,13 +414,27 @@ std::vector<uint16_t> stem_bf16_fragments(const float* w64x49) {
   return fr;
 }
 
-void launch_stem_bf16(const float* x, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
+void launch_stem_bf16(const void* x, int x_u8, const void* wfrag, const float* scale, const float* bias, void* out, int N, int H, int W,
                       hipStream_t s) {
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
   dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
-  hipLaunchKernelGGL(stem_bf16_kernel, grid, dim3(NT), 0, s, x, static_cast<const u32x4*>(wfrag), scale, bias,
-                     static_cast<__bf16*>(out), H, W);
+  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<false, uint8_t>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag),
+                               scale, bias, static_cast<__bf16*>(out), H, W);
+  else hipLaunchKernelGGL((stem_bf16_kernel<false, float>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag), scale, bias,
+                          static_cast<__bf16*>(out), H, W);
+  OCR_HIP(hipGetLastError());
+}
+
+void launch_stem_x3(const void* x, int x_u8, const void* wfrag3, const float* scale, const float* bias, float* out, int N, int H, int W,
+                    hipStream_t s) {
+  if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
+  const int Hp = H / 4, Wp = W / 4;
+  dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
+  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<true, uint8_t>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag3),
+                               scale, bias, out, H, W);
+  else hipLaunchKernelGGL((stem_bf16_kernel<true, float>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag3), scale, bias,
+                          out, H, W);
   OCR_HIP(hipGetLastError());
 }
 

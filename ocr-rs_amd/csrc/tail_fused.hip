@@ -58,15 +58,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // TI = __bf16 (OCR_PRECISION_BF16): v_mfma_f32_32x32x16_bf16, one 128-byte row holds all 64 channels (KC = 1) and a
 // 16-byte fragment is one MFMA operand.  Everything after the accumulators (bias, bin_bn2, ReLU, the second transposed
 // conv, sigmoid) is f32 in both.
-template <typename TI>
+// X3 (TI = float): the f32 head on the bf16 matrix cores - pixels stay f32 in HBM / LDS and are split into three bf16 terms in
+// registers once per workgroup (the four taps share them), the weights arrive as three bf16 planes (split3_weights of
+// [4 taps][64 co][64 ci]); six partial products per pair, f32 accumulate: 48 MFMAs of 32 cycles per tap instead of 64 of 64.
+template <typename TI, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool BF = sizeof(TI) == 2;
   constexpr int KC = BF ? 1 : 2;                 // 128-byte chunks per pixel row
   constexpr int EB = sizeof(TI);
+  constexpr int EBW = X3 ? 2 : EB;               // bytes per weight element
+  constexpr int WKC = (BF || X3) ? 1 : 2;        // 128-byte chunks per weight row
+  constexpr int WPL = X3 ? 3 : 1;                // weight planes
   constexpr int A_FLOATS = KC * TP * 32;         // LDS words: KC chunks of the pixel rows
-  constexpr int W_FLOATS = KC * 64 * 32;         // one tap: KC chunks of 64 output-channel rows
-  __shared__ __attribute__((aligned(1024))) float lds[A_FLOATS + 2 * W_FLOATS];
+  constexpr int W_FLOATS = WPL * WKC * 64 * 32;  // one tap: planes x chunks of 64 output-channel rows
+  // X3: the pixels are only read once (split into registers), after which their 32 KB serve as the second weight buffer:
+  // 56 KB instead of 80, two workgroups per CU
+  static_assert(!X3 || W_FLOATS <= A_FLOATS, "the weight planes of a tap fit the pixel rows' space");
+  constexpr int W_STRIDE = X3 ? -A_FLOATS : W_FLOATS;   // buffer 1 relative to buffer 0 (floats)
+  __shared__ __attribute__((aligned(1024))) float lds[A_FLOATS + (X3 ? 1 : 2) * W_FLOATS];
   __shared__ __attribute__((aligned(16))) float tab_s[256], tab_b[256], tab_w2[256];
   float* As = lds;
   float* Ws = lds + A_FLOATS;
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * TP;
   const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.y), 0, p.y_bytes, 0x00020000);
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt1), 0, 4 * 64 * 64 * EB, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt1), 0, WPL * 4 * 64 * 64 * EBW, 0x00020000);
   tab_s[tid] = p.s4[tid];
   tab_b[tid] = p.b4[tid];
   tab_w2[tid] = p.w2t[tid];
@@ -93,11 +103,13 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
     }
   auto issue_w = [&](int t, int buf) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
+    for (int pl = 0; pl < WPL; ++pl)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        dma16(w_rsrc, __builtin_amdgcn_readfirstlane(lds_w + (unsigned)((buf * W_FLOATS + kc * 64 * 32 + (32 * i + 8 * wave) * 32) * 4)),
-              (unsigned)((r + 32 * i) * 64 * EB + kc * 128 + gq * 16), t * 64 * 64 * EB);
+      for (int kc = 0; kc < WKC; ++kc)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          dma16(w_rsrc, __builtin_amdgcn_readfirstlane(lds_w + (unsigned)((buf * W_STRIDE + (pl * WKC + kc) * 64 * 32 + (32 * i + 8 * wave) * 32) * 4)),
+                (unsigned)((r + 32 * i) * 64 * EBW + kc * 128 + gq * 16), (pl * 4 + t) * 64 * 64 * EBW);
   };
   issue_w(0, 0);
 
@@ -112,11 +124,37 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   __syncthreads();
   // bin_conv_tr2's weights of this lane's 32 channels (co = 32 ct + (e&3) + 8 (e>>2) + 4 half) do not depend on the
   // tap: into registers once.  Read from LDS inside the tap loop they were 32 more dependent round trips per tap.
-  f32x4 w2r[2][16];
+  // (X3: its pixel fragments need 48 registers; it reads these from LDS per tap and channel half instead - the reads
+  // ride under bf16 MFMAs, which leave the vector and LDS pipes free)
+  f32x4 w2r[X3 ? 1 : 2][16];
+  if constexpr (!X3) {
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) w2r[ct][e] = *reinterpret_cast<const f32x4*>(&tab_w2[(32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half) * 4]);
+      for (int e = 0; e < 16; ++e) w2r[ct][e] = *reinterpret_cast<const f32x4*>(&tab_w2[(32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half) * 4]);
+  }
+  // X3: this lane's pixel operand as three bf16 fragments per 16-channel group kk = 2 kc + gp (chunks g = 2 gp, 2 gp + 1 of
+  // row chunk kc: k = 32 kc + 16 gp + 4 half + e and + 8; the weight planes carry the same order inside a 16-group)
+  bf16x8 pxh[X3 ? 4 : 1], pxm[X3 ? 4 : 1], pxl[X3 ? 4 : 1];
+  if constexpr (X3) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float* row = As + (kk >> 1) * TP * 32 + (32 * wave + frow) * 32;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(row + xoff[2 * (kk & 1)]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(row + xoff[2 * (kk & 1) + 1]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? a0[e] : a1[e - 4];
+        const __bf16 h = (__bf16)x;          // round to nearest even at every level: the remainders are exact in f32
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        pxh[kk][e] = h;
+        pxm[kk][e] = m;
+        pxl[kk][e] = (__bf16)(r1 - (float)m);
+      }
+    }
+    __syncthreads();   // every wave has its pixels in registers: their LDS rows become weight buffer 1
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t + 1 < 4) issue_w(t + 1, (t + 1) & 1);
@@ -125,7 +163,25 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
-    const float* wb = Ws + (t & 1) * W_FLOATS;
+    const float* wb = Ws + (t & 1) * W_STRIDE;
+    if constexpr (X3) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)     // channel half 0 complete first: its epilogue runs beside the MFMAs of half 1
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float* wr = wb + (32 * ct + frow) * 32 + xoff[kk];   // chunk 2 kk + half of the 64-channel bf16 row
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wr);
+          const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wr + 64 * 32);
+          const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wr + 2 * 64 * 32);
+          // small terms first (mid.lo, lo.mid, lo.lo are below 2^-23 of the product)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, pxh[kk], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pxl[kk], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, pxm[kk], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, pxh[kk], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pxm[kk], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pxh[kk], acc[ct], 0, 0, 0);
+        }
+    } else
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -158,13 +214,18 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
         bv[ct][q] = *reinterpret_cast<const f32x4*>(&tab_b[co0]);
       }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct) {
+      if constexpr (X3) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w2r[0][e] = *reinterpret_cast<const f32x4*>(&tab_w2[(32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half) * 4]);
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float z = fmaxf(acc[ct][e] * sv[ct][e >> 2][e & 3] + bv[ct][e >> 2][e & 3], 0.f);  // + bias, bin_bn2, ReLU
 #pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2r[ct][e][u], part[u]);
+        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2r[X3 ? 0 : ct][e][u], part[u]);
       }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float s = part[u] + __shfl_xor(part[u], 32, 64) + p.bias2;  // the other half holds the other 32 channels
@@ -215,10 +276,11 @@ void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
 
 }  // namespace
 
+// wt1: f32 [4][64][64]; bf16 != 0: the same in bf16 (y bf16 too); bf16 == 2: y f32, wt1 = split3_weights planes (X3)
 void launch_tail_fused(const void* y, const void* wt1, int bf16, const float* s4, const float* b4, const float* w2t, float bias2,
                        float* prob, uint8_t* bitmap, float thresh, int N, int h4, int w4, hipStream_t s) {
   const long long M = (long long)N * h4 * w4;
-  const int eb = bf16 ? 2 : 4;
+  const int eb = bf16 == 1 ? 2 : 4;
   if (M * 64 * eb >= (1ll << 31)) fail(OCR_ERR_INVALID, "tail: input exceeds 2^31 bytes; split the batch");
   if (w4 < 1 || h4 < 1) fail(OCR_ERR_INVALID, "tail: bad grid");
   TailArgs a{};
@@ -237,7 +299,8 @@ void launch_tail_fused(const void* y, const void* wt1, int bf16, const float* s4
   a.w4 = w4;
   make_magic((unsigned)(h4 * w4), &a.mg_hw, &a.sh_hw);
   make_magic((unsigned)w4, &a.mg_w, &a.sh_w);
-  if (bf16) hipLaunchKernelGGL(tail_fused_kernel<__bf16>, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
+  if (bf16 == 2) hipLaunchKernelGGL((tail_fused_kernel<float, true>), dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
+  else if (bf16) hipLaunchKernelGGL(tail_fused_kernel<__bf16>, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(tail_fused_kernel<float>, dim3((unsigned)((M + TP - 1) / TP)), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
