@@ -61,15 +61,11 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
 /* The same with explicit engine options, "key=value;key=value" (NULL or "" = the defaults).  The library never reads
  * the environment: which schedule runs is the caller's choice.  Every combination computes the same graph and is
  * held to the same parity bars (tests/test_gpu_parity.py::test_engine_modes_agree); they exist for A/B measurements.
- *   winograd_fused=0|1   (1)    fused Winograd F(2x2,3x3) kernel for the 3x3 s1 convs of the large grids
- *   winograd_ws=0|1      (0)    the wave-specialised form of that kernel (multiplier waves fed by helper waves)
+ *   winograd_fused=0|1   (1)    fused Winograd F(4x4,3x3) kernel (winograd43_fused.hip) for the 3x3 s1 convs with 64, 128 (trunk,
+ *                               FPN lateral terms) or 256 (out4) input channels; 0 = direct / unfused-Winograd convs
  *   winograd=<cin>|0     (256)  unfused Winograd for 3x3 s1 trunk convs with Cin >= cin that have no fused form; 0 = off
  *   winograd43=<cin>|0   (256)  of those, the layers with Cin >= cin use F(4x4,3x3) (36 products per 16 outputs) instead of
  *                               F(2x2,3x3) (16 per 4); 0 = F(2x2) everywhere
- *   winograd43_fused=<cin>|0 (128)  convs of the fused family with Cin <= cin run the fused F(4x4,3x3) kernel
- *                               (winograd43_fused.hip); 0 = the fused F(2x2,3x3) kernel everywhere
- *   winograd_fused_max_cin=<cin> (128)  trunk layers with more channels than this leave the fused kernel to the unfused path
- *                               (256 puts layer3 back on the fused F(2x2) kernel)
  *   fpn_unfused=0|1      (0)    1 = layer-by-layer FPN (laterals, top-down sums, out_k, gathered bin_conv1) as model.rs writes it
  *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches

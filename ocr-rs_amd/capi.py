@@ -143,10 +143,11 @@ TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libocr_amd_test.so")
 
 def test_lib() -> C.CDLL:
     """libocr_amd_test.so: the ocr_test_* hooks (kernel-level parity, host geometry, tuning aids).  A separate
-    library on top of the product one - nothing of it ships in libocr_amd.so."""
+    library built from the same objects plus test_hooks.o - nothing of it ships in libocr_amd.so, whose internals are
+    not exported.  Hooks take the handles the product library created (same classes, same process)."""
     global _test_lib
     if _test_lib is None:
-        lib()                                   # the product library first: the hooks link against it
+        lib()
         if not os.path.exists(TEST_LIB_PATH):
             raise OcrError(-1, f"{TEST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(TEST_LIB_PATH)
@@ -171,7 +172,21 @@ def test_lib() -> C.CDLL:
 
 def check(code: int) -> None:
     if code != 0:
-        raise OcrError(code, lib().ocr_last_error().decode())
+        msg = lib().ocr_last_error().decode()
+        if not msg and _test_lib is not None:   # the failure came from a test hook: that library keeps its own message
+            _test_lib.ocr_last_error.restype = C.c_char_p
+            msg = _test_lib.ocr_last_error().decode()
+        raise OcrError(code, msg)
+
+
+def use_test_library() -> None:
+    """Tuning tools whose hooks change library-wide state (tile override, ablation bits, stamp buffers) must run the
+    detector from the SAME library the hooks live in: call this before the first lib() - libocr_amd_test.so carries the
+    whole C ABI besides the hooks (it is built from the same objects)."""
+    global LIB_PATH
+    if _lib is not None:
+        raise OcrError(-1, "use_test_library() must come before the first library call")
+    LIB_PATH = TEST_LIB_PATH
 
 
 def _ptr(a) -> int:

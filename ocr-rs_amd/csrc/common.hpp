@@ -116,19 +116,10 @@ void launch_conv3x3_bf16_c64(const void* x, const void* wfrag, const float* scal
 void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, hipStream_t s);
 void launch_winograd_output(const float* mm, const float* scale, const float* bias, const float* residual, int relu,
                             float* y, int N, int H, int W, int K, int m, hipStream_t s);
-// The same conv with both transforms fused into the GEMM kernel (winograd_fused.hip): C = 64 or 128 input
-// channels, K a multiple of 64.  u_neg3: winograd weights [16][K][C] with the components of row i = 3 (12..15) negated.
-void launch_winograd_fused(const float* x, const float* u_neg3, const float* scale, const float* bias, const float* residual,
-                           int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
-// Fused F(4x4,3x3) (winograd43_fused.hip): C = 64 or 128, K a multiple of 64.  ufrag: winograd43_fragments(winograd_weights(.., 4)).
+// The same conv with both transforms fused into the GEMM kernel, F(4x4,3x3) (winograd43_fused.hip): C = 64, 128 or 256, K a multiple of 64.  ufrag: winograd43_fragments(winograd_weights(.., 4)).
 std::vector<float> winograd43_fragments(const std::vector<float>& u, int cout, int cin);
 void launch_winograd43_fused(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual,
                              int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
-// The wave-specialised form of the same conv (winograd_ws.hip): multiplier waves fed by helper waves through LDS.
-// ufrag: winograd_ws_fragments(winograd_weights(...)) - no negated components.
-std::vector<float> winograd_ws_fragments(const std::vector<float>& u, int cout, int cin);
-void launch_winograd_ws(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual, int relu,
-                        float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
 // tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);

@@ -157,19 +157,7 @@ void Detector::add_winograd_weights(ConvW& cw) {
 
 void Detector::add_winograd_fused_weights(ConvW& cw) {
   if ((cw.cin != 64 && cw.cin != 128 && cw.cin != 256) || cw.cout % 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd: unsupported conv shape");
-  if (cw.cin <= winograd43_fused_max_cin_ && (cw.cin == 64 || cw.cin == 128)) {
-    cw.wino43_fused = arena_.upload(winograd43_fragments(winograd_weights(cw.host.data(), cw.cout, cw.cin, 4), cw.cout, cw.cin));
-    cw.wino_fused = cw.wino43_fused;  // "has a fused form"
-    return;
-  }
-  std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin);
-  if (winograd_ws_) {
-    cw.wino_ws = arena_.upload(winograd_ws_fragments(u, cw.cout, cw.cin));
-    cw.wino_fused = cw.wino_ws;  // "has a fused form": the schedule tests this pointer
-    return;
-  }
-  for (size_t i = (size_t)12 * cw.cout * cw.cin; i < u.size(); ++i) u[i] = -u[i];  // row i = 3 enters the output transform negated
-  cw.wino_fused = arena_.upload(u);
+  cw.wino43_fused = arena_.upload(winograd43_fragments(winograd_weights(cw.host.data(), cw.cout, cw.cin, 4), cw.cout, cw.cin));
 }
 
 // hi / mid / lo bf16 planes of a conv's f32 weights (and of its Winograd form): what conv_igemm's split-bf16 kernels read
@@ -246,10 +234,7 @@ void Detector::parse_options(const char* options) {
       return (int)v;
     };
     if (key == "winograd_fused") winograd_fused_ = num() != 0;
-    else if (key == "winograd_ws") winograd_ws_ = num() != 0;
     else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
-    else if (key == "winograd_fused_max_cin") winograd_fused_max_cin_ = num();
-    else if (key == "winograd43_fused") winograd43_fused_max_cin_ = num();
     else if (key == "winograd43") winograd43_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
@@ -335,13 +320,8 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     add_winograd_fused_weights(layer_[1][0][1]);
     add_winograd_fused_weights(layer_[1][1][0]);
     add_winograd_fused_weights(layer_[1][1][1]);
-    // layer3's (256 -> 256 at H/16): fused F(2x2) 0.335 ms, unfused F(2x2) 0.36 ms, unfused F(4x4) 0.233 ms - the default
-    // leaves layer3 and layer4 (20 x 20 grids, 0.286 -> 0.184 ms) to the unfused F(4x4,3x3) path below
-    if (winograd_fused_max_cin_ >= 256) {
-      add_winograd_fused_weights(layer_[2][0][1]);
-      add_winograd_fused_weights(layer_[2][1][0]);
-      add_winograd_fused_weights(layer_[2][1][1]);
-    }
+    // layer3 (256 -> 256 at H/16) and layer4 (20 x 20 grids) stay on the unfused F(4x4,3x3) path below: their 36-component
+    // tensors are small enough to live in L2 / Infinity Cache and the GEMMs run as large split-bf16 tiles
   }
   for (int l = 0; l < 4; ++l) {
     if ((64 << l) < winograd_min_cin_) continue;
@@ -838,28 +818,16 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   // [tiles x Cin] x [Cin x Cout] GEMMs in one batched launch, output transform with the epilogue (f32 only)
   auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual,
                      bool relu = true) {
-    if (!bf && cw.wino_fused) {  // 64 -> 64: transforms fused into the GEMM kernel
-      if (cw.wino43_fused) {
+    if (!bf && cw.wino43_fused) {  // transforms fused into the GEMM kernel
+      {
         rec.begin();
         launch_winograd43_fused(static_cast<const float*>(src), cw.wino43_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
                                 relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
         const double px43 = (double)n * hh * ww;
-        rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : "winograd43_fused<c128>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
+        rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : cw.cin == 128 ? "winograd43_fused<c128>" : "winograd43_fused<c256>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
                 px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 4);
         return;
       }
-      rec.begin();
-      if (cw.wino_ws)
-        launch_winograd_ws(static_cast<const float*>(src), cw.wino_ws, cw.scale, cw.bias, static_cast<const float*>(residual),
-                           relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
-      else
-        launch_winograd_fused(static_cast<const float*>(src), cw.wino_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
-                              relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
-      const double px = (double)n * hh * ww;
-      rec.end(cw.wino_ws ? (cw.cin == 64 ? "winograd_ws<c64>" : cw.cin == 128 ? "winograd_ws<c128>" : "winograd_ws<c256>")
-                         : (cw.cin == 64 ? "winograd_fused<c64>" : cw.cin == 128 ? "winograd_fused<c128>" : "winograd_fused<c256>"), 2.0 * 16.0 * (px / 4.0) * cw.cin * cw.cout,
-              px * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 16.0 * cw.cin * cw.cout * 4);
-      return;
     }
     if (bf && cw.w_bf16_c64 && (long long)n * hh * ww * 128 < (1ll << 31)) {  // bf16 64 -> 64: patch staged once, weights in registers
       rec.begin();
@@ -921,7 +889,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     Extra up;
     up.store = STORE_PHASE;
     conv("fpn.upsampled", fpn_b_[lv], x_[lv + 1], h >> (3 + lv), w >> (3 + lv), 1, p_[lv], false, up);
-    if ((fpn_a_[lv].wino_fused && !bf) || (bf && fpn_a_[lv].w_bf16_c64)) {
+    if ((fpn_a_[lv].wino43_fused && !bf) || (bf && fpn_a_[lv].w_bf16_c64)) {
       conv3x3("fpn.lateral", fpn_a_[lv], x_[lv], h >> (2 + lv), w >> (2 + lv), p_[lv], p_[lv], false);
     } else {
       Extra lat;
@@ -1030,7 +998,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     if (bf) {
       // all four sources in the one phase launch (112.8 GF instead of the gathered conv's 241.6), bias + ReLU in its epilogue
       conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
-    } else if (bin_p2_.wino_fused) {
+    } else if (bin_p2_.wino43_fused) {
       // the three upsampled sources in the phase launch, p2's 3x3 term on top as a fused Winograd conv (+ bias, ReLU)
       py.pyr_nsrc = 3;
       ConvW up3 = bin_pyr_;

@@ -45,8 +45,6 @@ struct ConvW {
   float* wino = nullptr;   // Winograd F(2x2,3x3) weights U = G g G^T as [16][Cout][Cin] (3x3 s1 convs of the deep layers)
   size_t wino_bytes = 0;
   int wino_tile = 2;       // ... or F(4x4,3x3), [36][Cout][Cin], where the option winograd43 asks for it
-  float* wino_fused = nullptr;  // 64 -> 64 convs: the same with components 12..15 negated (winograd_fused.hip)
-  float* wino_ws = nullptr;     // ... or as MFMA B fragments for the wave-specialised kernel (winograd_ws.hip)
   float* wino43_fused = nullptr;  // F(4x4,3x3) weights as MFMA B fragments for winograd43_fused.hip (Cin 64 / 128)
   int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
   float* scale = nullptr;  // folded eval batch norm, may stay null
@@ -155,14 +153,11 @@ class Detector {
   bool fpn_composed_ = true;
   // Winograd for 3x3 s1 trunk convs with Cin >= this (f32 precision only); option winograd=0 disables, =<cin> overrides
   int winograd_min_cin_ = 256;
-  int winograd_fused_max_cin_ = 128;  // trunk layers up to this many channels run the fused F(2x2,3x3) kernel (256 adds layer3)
-  int winograd43_fused_max_cin_ = 128; // convs of the fused family with at most this many input channels use the F(4x4,3x3) fused kernel
   int winograd43_min_cin_ = 256;      // unfused Winograd layers with at least this many channels use F(4x4,3x3)
   float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [(m+2)^2][T][C] and [(m+2)^2][T][K] scratch of the layer in flight
   void add_winograd_weights(ConvW& cw);
   void add_winograd_fused_weights(ConvW& cw);
-  bool winograd_ws_ = false;     // option winograd_ws=1: the wave-specialised fused Winograd kernel instead of winograd_fused
-  bool winograd_fused_ = true;   // option winograd_fused=0: direct convs instead of the fused Winograd kernel
+  bool winograd_fused_ = true;   // option winograd_fused=0: direct / unfused-Winograd convs instead of the fused F(4x4,3x3) kernel
   // option mfma=split_bf16 (default) | f32: the MFMA-bound f32 convs without a Winograd kernel of their own (stride-2 3x3,
   // composed FPN phase convs, bin_conv1 over the pyramid, the 36 Winograd GEMMs of layer3 / layer4) run on the bf16 matrix
   // cores from operands split into three bf16 terms, six partial products, f32 accumulate (conv_igemm.hip, X3): f32-level

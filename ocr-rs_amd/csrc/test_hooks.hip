@@ -17,7 +17,6 @@ namespace ocr { void winograd43_read_stamps(long long* out); }
 namespace ocr { void rec_read_stamps(long long* out); }
 #endif
 #ifdef WS_STAMPS
-namespace ocr { void winograd_ws_read_stamps(long long* out); }
 #endif
 
 extern "C" {
@@ -237,7 +236,7 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     if (!det || !x || !wgt || !out) fail(OCR_ERR_INVALID, "null argument");
     OCR_HIP(hipSetDevice(det->impl.device()));
     hipStream_t s = det->impl.stream();
-    const size_t wm = unfused >= 3 ? 4 : 2, wa = (wm + 2) * (wm + 2);   // unfused == 3: F(4x4,3x3), unfused; 4: its fused kernel
+    const size_t wm = unfused >= 3 ? 4 : 2, wa = (wm + 2) * (wm + 2);   // unfused: 1 = F(2x2,3x3), 3 = F(4x4,3x3), both unfused; 4 = the fused F(4x4,3x3) kernel
     const size_t th = (h + wm - 1) / wm, tw = (w + wm - 1) / wm, T = (size_t)n * th * tw;
     const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
     const std::vector<float> u = winograd_weights(wgt, cout, cin, (int)wm);
@@ -261,22 +260,6 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     if (unfused == 4) {  // fused F(4x4,3x3)
       float* d_uf = dev(winograd43_fragments(u, cout, cin).data(), u.size());
       launch_winograd43_fused(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
-      OCR_HIP(hipStreamSynchronize(s));
-      OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
-      return;
-    }
-    if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && unfused == 2) {  // the wave-specialised fused kernel
-      float* d_uf = dev(winograd_ws_fragments(u, cout, cin).data(), u.size());
-      launch_winograd_ws(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
-      OCR_HIP(hipStreamSynchronize(s));
-      OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
-      return;
-    }
-    if ((cin == 64 || cin == 128 || cin == 256) && cout % 64 == 0 && !unfused) {  // the fused kernel
-      std::vector<float> un = u;
-      for (size_t i = (size_t)12 * cout * cin; i < un.size(); ++i) un[i] = -un[i];
-      float* d_un = dev(un.data(), un.size());
-      launch_winograd_fused(d_x, d_un, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
       OCR_HIP(hipStreamSynchronize(s));
       OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
       return;
@@ -410,7 +393,6 @@ int ocr_test_rec_stamps(long long* out) { ocr::rec_read_stamps(out); return 0; }
 #endif
 int ocr_test_w43_debug(int d) { ocr::winograd43_set_debug(d); return 0; }
 #ifdef WS_STAMPS
-int ocr_test_ws_stamps(long long* out) { ocr::winograd_ws_read_stamps(out); return 0; }
 #endif
 
 }  // extern "C"

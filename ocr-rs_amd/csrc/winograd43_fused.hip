@@ -59,6 +59,7 @@ struct W43Args {
   int C, K, kblocks;      // channels in / out, K / 64
   int relu;
   int nblocks;
+  int xcd_chunks;         // 1: every XCD (blockIdx & 7) walks its own contiguous run of blocks (launcher: grid % (8 kblocks) == 0)
   int debug;              // builds with -DW43_DEBUG only (ocr_test_w43_debug): 1 skip B loads, 2 skip the input transform, 4 skip patch DMA, 8 skip stores
 };
 
@@ -169,7 +170,19 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
     y0_ = 16 * (bb % p.bh);
     n_ = bb / p.bh;
   };
-  const int kb = blockIdx.x % p.kblocks;
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx & 7 labels the L2 a workgroup sits behind).  Each XCD gets
+  // ONE contiguous run of blocks - whole images, or bands of one - and its workgroups walk that run together, `stride`
+  // blocks per round in raster order: the 18 x 18 patches of neighbouring blocks (27 % halo) and the K / 64 siblings of a
+  // pixel block meet in the same L2 instead of being fetched by eight.  Placement is a speed matter only.
+  int first = 0, count = p.nblocks, q = blockIdx.x, stride = gridDim.x;
+  if (p.xcd_chunks) {
+    const int j = blockIdx.x & 7, sb = p.nblocks / p.kblocks, c = sb >> 3, rem = sb & 7;
+    q = blockIdx.x >> 3;
+    stride = gridDim.x >> 3;
+    first = (j * c + min(j, rem)) * p.kblocks;
+    count = (c + (j < rem ? 1 : 0)) * p.kblocks;
+  }
+  const int kb = q % p.kblocks;   // constant over a workgroup's blocks: stride is a multiple of kblocks
 
   // ---- patch DMA, one patch row (18 pixels x 64 B = 1152 B) in two pieces: 16 pixels (a full 1 KB instruction; waves 0, 2)
   // and 2 pixels (lanes 0..7 only; waves 1, 3).  36 pieces, nine per wave = rows (wave >> 1) + 2 m.  The row part of the
@@ -219,11 +232,12 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
   const unsigned char* a_ptr = lds + V_OFF + (lane >> 4) * 256 + ((lane & 15) ^ (((lane >> 4) & 1) << 2)) * 16;
 
   bool patch_in_flight = false;  // chunk 0 of this block's patch was requested during the previous block
-  for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
+  for (int lb = q; lb < count; lb += stride) {
+    const int blk = first + lb;
     int n, y0, x0;
     coords(blk, n, y0, x0);
     W43_STAMP(0);
-    const bool has_next_block = blk + (int)gridDim.x < p.nblocks;
+    const bool has_next_block = lb + stride < count;
     if (!patch_in_flight) {
       patch_columns(x0);
       issue_patch(n, y0, 0, 0);
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         if (t == 0 && has_patch) {
           if (last_chunk) {
             int nn, ny0, nx0;
-            coords(blk + (int)gridDim.x, nn, ny0, nx0);
+            coords(blk + stride, nn, ny0, nx0);
             patch_columns(nx0);
             issue_patch(nn, ny0, 0, 0);
             patch_in_flight = true;
@@ -467,7 +481,7 @@ void winograd43_set_debug(int d) { g_w43_debug = d; }
 
 void launch_winograd43_fused(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual,
                              int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s) {
-  if (N <= 0 || H <= 0 || W <= 0 || (C != 64 && C != 128) || K % 64)
+  if (N <= 0 || H <= 0 || W <= 0 || (C != 64 && C != 128 && C != 256) || K % 64)
     fail(OCR_ERR_INVALID, "fused Winograd F(4x4): bad shape N=%d H=%d W=%d C=%d K=%d", N, H, W, C, K);
   const long long xb = (long long)N * H * W * C * 4, ub = (long long)36 * C * K * 4;
   if (xb >= (1ll << 31) || (long long)N * H * W * K * 4 >= (1ll << 31)) fail(OCR_ERR_INVALID, "fused Winograd F(4x4): tensor too large");
@@ -493,11 +507,19 @@ void launch_winograd43_fused(const float* x, const float* ufrag, const float* sc
   if (blocks >= (1ll << 31)) fail(OCR_ERR_INVALID, "fused Winograd F(4x4): too many blocks");
   a.nblocks = (int)blocks;
   a.debug = g_w43_debug;
-  // persistent workgroups, two per CU, a multiple of kblocks so that each keeps its output-channel block
+  // persistent workgroups, two per CU; a multiple of kblocks so that each keeps its output-channel block, and of 8 kblocks
+  // (when there are that many blocks) so that the eight XCDs can each walk a contiguous run of blocks
   long long grid = std::min<long long>(blocks, 2ll * (num_cus > 0 ? num_cus : 256));
-  grid = std::max<long long>(a.kblocks, grid / a.kblocks * a.kblocks);
+  const long long unit = 8ll * a.kblocks;
+  if (grid >= unit && !(g_w43_debug & 16)) {   // (bit 16 of the test hook's word: plain linear order, for A/B timing)
+    grid = grid / unit * unit;
+    a.xcd_chunks = 1;
+  } else {
+    grid = std::max<long long>(a.kblocks, grid / a.kblocks * a.kblocks);
+  }
   if (C == 64) hipLaunchKernelGGL(winograd43_fused_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(winograd43_fused_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (C == 128) hipLaunchKernelGGL(winograd43_fused_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(winograd43_fused_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
 

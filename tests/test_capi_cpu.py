@@ -37,15 +37,15 @@ def test_header_symbols_exported():
 
 
 def test_product_library_ships_no_test_hooks():
-    """The ocr_test_* hooks live in libocr_amd_test.so (on top of the product library), never in libocr_amd.so."""
+    """libocr_amd.so exports the C ABI of include/ocr_amd.h and NOTHING else: no ocr_test_* hook, no C++ internal
+    (exports.map).  The hooks live in libocr_amd_test.so, a library of its own built from the same objects."""
     import subprocess
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
-        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
-    prod = {n for n in exported(capi.LIB_PATH) if n.startswith("ocr_")}
-    assert prod == set(capi.EXPORTS)                                   # exactly the header's surface, nothing else
-    hooks = {n for n in exported(capi.TEST_LIB_PATH) if n.startswith("ocr_")}
-    assert hooks and all(n.startswith("ocr_test_") for n in hooks)
+        return {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TWVBDR"}
+    assert exported(capi.LIB_PATH) == set(capi.EXPORTS)                # exactly the header's surface, nothing else
+    hooks = {n for n in exported(capi.TEST_LIB_PATH) if n.startswith("ocr_test_")}
+    assert hooks
 
 
 def test_no_cpu_fallback_without_gpu():

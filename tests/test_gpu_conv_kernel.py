@@ -180,7 +180,7 @@ WINO_CASES = [
     (1, 25, 25, 256, 256, True, True, True),     # odd grid (800x800 frames: layer4 is 25x25)
     (3, 3, 5, 256, 512, False, False, False),    # smaller than a tile row, ragged both ways, Cin != Cout
     (1, 1, 1, 256, 256, True, True, False),      # a single pixel: every tap but the centre is padding
-    # 64 -> 64: the fused-transform kernel (winograd_fused.hip), 8 x 16 pixel blocks
+    # few channels
     (2, 16, 32, 64, 64, True, True, True),       # whole blocks
     (1, 9, 21, 64, 64, True, False, True),       # ragged blocks, odd sizes
     (3, 1, 1, 64, 64, False, False, False),      # single pixels
@@ -245,6 +245,10 @@ W43F_CASES = [
     (1, 13, 37, 128, 64, False, True, False),    # p3 lateral term (128 -> 64), ragged
     (1, 8, 16, 64, 128, True, False, True),      # 64 -> 128
     (5, 24, 40, 64, 64, True, True, False),
+    (1, 40, 40, 256, 64, False, False, False),   # out4 (256 -> 64): sixteen channel chunks
+    (2, 24, 48, 256, 128, True, True, True),     # 256 input channels, two output-channel blocks share a patch
+    (40, 16, 16, 64, 64, True, True, True),      # 40 blocks: the eight XCD runs of 5, several rounds on a small grid
+    (1, 64, 272, 64, 64, True, True, False),     # 68 blocks in one image: runs that split image rows
 ]
 
 
@@ -262,30 +266,6 @@ def test_winograd43_fused_conv_matches_aten(det, case):
     ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
     err = float(np.abs(got - ref).max()) / (float(np.abs(ref).max()) + 1e-12)
     assert err < 1e-4, err
-
-
-WS_CASES = [c for c in WINO_CASES if c[3] in (64, 128, 256) and c[4] % 64 == 0] + [
-    (1, 40, 40, 256, 64, False, False, False),   # out4 (256 -> 64): eight channel chunks
-    (2, 24, 48, 256, 256, True, True, True),     # layer3-like, four output-channel blocks share a patch
-    (5, 8, 16, 64, 64, True, True, True),        # fewer blocks than workgroups
-    (1, 64, 272, 64, 64, True, True, False),     # many blocks per image row, several per workgroup on a small grid
-]
-
-
-@pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
-def test_winograd_ws_conv_matches_aten(det, case):
-    """The wave-specialised fused Winograd kernel (winograd_ws.hip: multiplier waves fed by helper waves) against
-    ATen's direct conv2d on the same operands, same bar as the other Winograd forms."""
-    n, h, w, cin, cout, bn, has_res, relu = case
-    rng = np.random.default_rng(hash(case[:5]) & 0xFFFF)
-    x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
-    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
-    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
-    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
-    res = rng.standard_normal((n, h, w, cout), dtype=np.float32) if has_res else None
-    got = det.debug_winograd_conv(x, wg, scale, bias, res, relu, unfused=2)
-    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
-    _check(got, ref, False)
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 9, 21), (3, 1, 1), (2, 160, 160), (1, 8, 16), (5, 24, 40), (1, 64, 272)],

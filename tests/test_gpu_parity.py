@@ -360,7 +360,6 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     "fpn_unfused=1",                                               # layer-by-layer FPN
     "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
     "overlap=1", "overlap=2",                                      # second-stream schedules
-    "winograd_ws=1",                                               # wave-specialised fused Winograd kernel
     "mfma=f32",                                                    # every conv on the exact-f32 MFMA (no split-bf16 kernels)
     "mfma=f32;bin_pyr=0",
 ])

@@ -18,13 +18,13 @@ w = W.make_det_weights(0)
 x = W.synth_image_batch(5, n, s, s)
 ref = T.det_forward(w, x)
 for label, options in (("default (composed FPN, fused Winograd, single-launch bin_conv1)", None),
-                       ("winograd43_fused=128 (layer1, layer2, FPN laterals on the fused F(4x4,3x3) kernel)", "winograd43_fused=128"),
-                       ("winograd43=0 (layer4 as F(2x2,3x3))", "winograd43=0"),
-                       ("winograd43=256;winograd_fused_max_cin=128 (layer3 and layer4 as F(4x4,3x3))", "winograd43=256;winograd_fused_max_cin=128"),
+                       ("mfma=f32 (every conv on the exact-f32 matrix instructions, no split-bf16 kernels)", "mfma=f32"),
+                       ("winograd43=0 (layer3 / layer4 as F(2x2,3x3))", "winograd43=0"),
                        ("winograd_fused=0", "winograd_fused=0"),
                        ("direct convs, composed FPN", "winograd=0;winograd_fused=0"),
                        ("fpn_unfused=1", "fpn_unfused=1"),
-                       ("layer-by-layer direct convs (the graph as model.rs writes it)", "winograd=0;winograd_fused=0;fpn_unfused=1;tail_unfused=1")):
+                       ("layer-by-layer direct convs (the graph as model.rs writes it)", "winograd=0;winograd_fused=0;fpn_unfused=1;tail_unfused=1"),
+                       ("the same, exact-f32 matrix instructions only", "mfma=f32;winograd=0;winograd_fused=0;fpn_unfused=1;tail_unfused=1")):
     det = capi.Detector(W.pack_blob(w), 0, options=options)
     d = np.abs(det.forward_host(x) - ref)
     det.close()

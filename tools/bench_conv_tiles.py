@@ -6,7 +6,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ocr_rs_amd  # noqa: E402,F401
-from ocr_rs_amd import capi, weights as W  # noqa: E402
+from ocr_rs_amd import capi, weights as W
+capi.use_test_library()   # the hooks below set library-wide state: detector and hooks from one library  # noqa: E402
 
 bf = len(sys.argv) > 1 and sys.argv[1] == "bf16"
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)

@@ -19,27 +19,24 @@ TILE = {"128, 128": "128x128", "128, 64": "128x64", "64, 64": "64x64"}
 def pretty(name: str) -> str:
     # "void ocr::igemm::conv_igemm<float, float, 64, 64, 3, 1, 0, 0>(...)" -> bench.py's kernel label
     if "conv_igemm<" not in name:
-        return "stem_conv7x7_bn_relu_maxpool" if "stem_kernel" in name else \
+        return "stem_x3_conv7x7_bn_relu_maxpool" if "stem_bf16_kernel<true" in name else \
+               "stem_conv7x7_bn_relu_maxpool" if ("stem_kernel" in name or "stem_bf16_kernel" in name) else \
                "convt2x2_sigmoid" if "convt2_sigmoid" in name else \
+               "tail_x3_convt1_bn_relu_convt2_sigmoid" if "tail_fused_kernel<float, true>" in name else \
                "tail_convt1_bn_relu_convt2_sigmoid" if "tail_fused" in name else \
-               "stem_conv7x7_bn_relu_maxpool" if "stem_bf16_kernel" in name else \
-               "winograd_ws<c64>" if "winograd_ws_kernel<2>" in name else \
-               "winograd_ws<c128>" if "winograd_ws_kernel<4>" in name else \
-               "winograd_ws<c256>" if "winograd_ws_kernel<8>" in name else \
-               "winograd_fused<c64>" if "winograd_fused_kernel<2>" in name else \
-               "winograd_fused<c128>" if "winograd_fused_kernel<4>" in name else \
-               "winograd_fused<c256>" if "winograd_fused_kernel<8>" in name else \
                "rec_conv<4>" if "rec_conv_kernel<4>" in name else "rec_conv<2>" if "rec_conv_kernel<2>" in name else \
                "rec_conv<1>" if "rec_conv_kernel<1>" in name else "rec_fc2_softmax_top1" if "rec_fc2_softmax" in name else \
                "winograd43_fused<c64>" if "winograd43_fused_kernel<4>" in name else \
                "winograd43_fused<c128>" if "winograd43_fused_kernel<8>" in name else \
+               "winograd43_fused<c256>" if "winograd43_fused_kernel<16>" in name else \
                "winograd43_input_transform" if "winograd43_input" in name else \
                "winograd43_output_transform" if "winograd43_output" in name else \
+               "rec_small_fused" if "rec_small_fused" in name else \
                "rec_conv_small" if "rec_conv_small" in name else "rec_fc1_small" if "rec_fc1_small" in name else \
                "winograd_input_transform" if "winograd_input" in name else \
                "winograd_output_transform" if "winograd_output" in name else name.split("(")[0]
     a = [v.strip() for v in name.split("<")[1].split(">")[0].split(",")]
-    ty = "bf16" if "bf16" in a[0] or "__bf16" in a[0] else "f32"
+    ty = "x3" if (len(a) > 8 and a[8] == "true") else "bf16" if "bf16" in a[0] or "__bf16" in a[0] else "f32"
     tile = f"{a[2]}x{a[3]}"
     store = {"0": "", "1": ",SHUFFLE2", "2": ",PHASE"}[a[7]]
     if a[7] == "2":   # bench.py's label carries the upsampling factor; the 3x3 PYR4 form is up 8, the 2x2 forms are told apart by dispatch order

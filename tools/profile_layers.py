@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import ocr_rs_amd  # noqa: E402,F401
-from ocr_rs_amd import capi, weights as W  # noqa: E402
+from ocr_rs_amd import capi, weights as W
+capi.use_test_library()   # the hooks below set library-wide state: detector and hooks from one library  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 s = int(sys.argv[2]) if len(sys.argv) > 2 else 640

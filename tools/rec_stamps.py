@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ocr_rs_amd
 from ocr_rs_amd import capi, weights as W
+capi.use_test_library()   # the hooks below set library-wide state: detector and hooks from one library
 rec = capi.Recognizer(W.pack_blob(W.make_rec_weights(0)), 0)
 nc = 256
 crops = torch.from_numpy(W.synth_crops(2, nc)).cuda()

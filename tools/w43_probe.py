@@ -9,9 +9,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import ocr_rs_amd  # noqa: E402,F401
-from ocr_rs_amd import capi, weights as W  # noqa: E402
+from ocr_rs_amd import capi, weights as W
+capi.use_test_library()   # the hooks below set library-wide state: detector and hooks from one library  # noqa: E402
 
-opts = sys.argv[1] if len(sys.argv) > 1 else "winograd43_fused=128"
+opts = sys.argv[1] if len(sys.argv) > 1 else None
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0, options=opts)
 x = torch.from_numpy(W.synth_image_batch(1, 32, 640, 640)).cuda()
 prob = torch.empty_like(x)

@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 import ocr_rs_amd  # noqa: E402,F401
-from ocr_rs_amd import capi, weights as W  # noqa: E402
+from ocr_rs_amd import capi, weights as W
+capi.use_test_library()   # the hooks below set library-wide state: detector and hooks from one library  # noqa: E402
 
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)
 rng = np.random.default_rng(0)

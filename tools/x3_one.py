@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ocr_rs_amd  # noqa
 from ocr_rs_amd import capi, weights as W
+capi.use_test_library()   # the hooks below set library-wide state: detector and hooks from one library
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)
 capi.test_lib().ocr_test_set_conv_tile(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 mode = 32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else 32 | 64
