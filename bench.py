@@ -19,8 +19,14 @@ bench.py --gpus N ...` the ranks exist already and it just runs as one of them.
 Extra objects in that line:
   roofline      dominant kernel (largest summed time), measured live with HIP events
                 on the launch stream: the MFMA FLOPs its launches EXECUTE / their time,
-                against the 157.3 TF/s dense f32 MFMA peak of MI355X (frac <= 1 by construction;
-                `algorithmic_tflops` is the reference graph's direct-conv work / the same time).
+                against the dense MFMA peak of the instruction it issues - 157.3 TF/s for the f32 forms,
+                2.5 PF/s for v_mfma_f32_32x32x16_bf16, which the split-bf16 kernels (`*_x3*`) issue six times
+                per f32 product (frac <= 1 by construction; `algorithmic_tflops` is the reference graph's
+                direct-conv work / the same time).  Counter evidence (rocprofv3 --pmc, committed extract
+                profiles/pmc.json, stamped with a hash of the kernel sources): HBM traffic, MFMA FLOPs and
+                MFMA-busy share per kernel; `*_stale` says when the sources changed after the passes.
+  f32_mfma_only the same step with option mfma=f32 (every conv on the exact-f32 matrix instructions).
+  host_*        the host-memory entry points (frames in host memory, PCIe inside the timed region).
   roofline_rec  the recogniser kernel, same definition, at B = 256 (configs[2]) and B = 65536.
   cpu_baseline  the same graphs on the host cores through ATen-CPU (oracle/torch_ref.py,
                 the operator library the reference reaches through tch), bounded samples:
@@ -92,6 +98,9 @@ def launch_ranks(n: int, argv) -> int:
             # N ranks share one host: keep each rank's OpenMP / ATen pool small (torch.distributed.run does the same); the
             # library's own post-processing pool is capped at 16 threads per detector
             env.setdefault("OMP_NUM_THREADS", "4")
+            # ... and tell each rank its share of the host cores: it sizes the detector's post-processing pool with it
+            # (engine option post_threads) instead of every rank starting a pool for the whole machine
+            env.setdefault("OCR_BENCH_CORES_PER_RANK", str(max(1, host_cores() // n)))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                           stdout=out0 if r == 0 else subprocess.DEVNULL))
         # a rank that dies leaves the others waiting in a rendezvous or a collective: end them (these exact
@@ -126,21 +135,37 @@ def launch_ranks(n: int, argv) -> int:
 
 
 # --------------------------------------------------------------------------------------------------
-def pmc_traffic(kernel: str, n: int, s: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md);
-    None when no extract for this workload is committed.  Not measured live: PMC needs rocprofv3.
-    The extract carries the git hash of the tree it was taken on (`git_head`), so a stale file shows."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def csrc_hash() -> str:
+    """sha256 over the kernel sources (ocr-rs_amd/csrc): what a PMC extract is stamped with (no .git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ocr-rs_amd", "csrc", "*"))):
+        if os.path.isfile(f) and f.rsplit(".", 1)[-1] in ("hip", "hpp", "cpp", "map") or os.path.basename(f) == "Makefile":
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_extract(dtype: str, n: int, s: int):
+    """profiles/pmc.json: per-kernel counters of separate rocprofv3 --pmc passes over tools/profile_layers.py
+    (tools/make_pmc_json.py).  Returns (kernels dict, source text, stale flag) or (None, None, None)."""
     try:
-        t = json.load(open(path))
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))[dtype]
         if t.get("batch") == n and t.get("size") == s:
-            e = t["kernels"].get(kernel)
-            src = t["source"] + (f" @ {t['git_head']}" if t.get("git_head") else "")
-            return (None, None) if e is None else (e["bytes_per_launch"], src)
+            return t["kernels"], t["source"], t.get("csrc_sha") != csrc_hash()
     except Exception:
         pass
-    return None, None
+    return None, None, None
+
+
+def kernel_peak(name: str, dtype: str):
+    """(matrix instruction, executed-FLOP multiplier, dense peak TFLOP/s) of a launch label."""
+    if "_x3" in name:
+        return "v_mfma_f32_32x32x16_bf16 x6 (3-way split f32 operands)", 6.0, BF16_MFMA_PEAK_TFLOPS
+    if dtype == "bf16" and ("bf16" in name or name.startswith(("stem_", "tail_"))):
+        return "v_mfma_f32_32x32x16_bf16", 1.0, BF16_MFMA_PEAK_TFLOPS
+    return "v_mfma_f32 (f32 operands)", 1.0, F32_MFMA_PEAK_TFLOPS
 
 
 def text_like_maps(n: int, s: int, seed: int):
@@ -195,7 +220,6 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
     (oracle/torch_ref.py), and the post-processing restatement (oracle/postproc_oracle.py).  Bounded samples."""
     import numpy as np
     import torch
-    from oracle import postproc_oracle as PO
     from oracle import torch_ref as T
     from ocr_rs_amd import weights as W
     cores = host_cores()
@@ -228,15 +252,27 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
     el = time.perf_counter() - t0
     out["recognition"] = {"value": round(it * 4096 / el, 1), "unit": "crops/s", "cores": cores, "kind": "port",
                           "sample": f"{it} x 4096 crops of 28x28 through oracle/torch_ref.py (forward + softmax f64 + top-1), {el:.1f} s"}
-    maps = text_like_maps(4, size, 7)
-    t0, it = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 3.0:
-        PO.get_boxes_and_box_scores(maps, np.ones((4, 2)))
-        it += 1
-    el = time.perf_counter() - t0
-    out["postprocess"] = {"value": round(it * 4 / el, 2), "unit": "images/s", "cores": 1, "kind": "port",
-                          "sample": f"{it} x 4 text-like {size}x{size} maps through oracle/postproc_oracle.py "
-                                    f"(numpy/pure-Python restatement, one thread), {el:.1f} s"}
+    # post-processing: the compiled CPU path (oracle/postproc_cpu.cpp: binarize, contours, Douglas-Peucker, box scores,
+    # unclip - all on host threads; pinned to the reference's known answers by tests/test_oracle_postproc.py), one thread
+    # and all cores, on the text-like maps the GPU leg uses
+    from oracle import postproc_cpu as PC
+    maps = text_like_maps(32, size, 7)
+    ones = np.ones((32, 2))
+    PC.get_boxes_and_box_scores(maps[:2], ones[:2], threads=1, skip_degenerate=True, counts_only=True)
+
+    def post_rate(threads, budget):
+        t0, it = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            PC.get_boxes_and_box_scores(maps, ones, threads=threads, skip_degenerate=True, counts_only=True)
+            it += 1
+        return it, time.perf_counter() - t0
+
+    it, el = post_rate(cores, 2.0)
+    out["postprocess"] = {"value": round(it * 32 / el, 1), "unit": "images/s", "cores": cores, "kind": "port",
+                          "sample": f"{it} x 32 text-like {size}x{size} maps through oracle/postproc_cpu.cpp (compiled C++: binarize + "
+                                    f"contours + box scores + unclip on {cores} host threads), {el:.1f} s"}
+    it1, el1 = post_rate(1, 1.5)
+    out["postprocess"]["one_thread"] = {"value": round(it1 * 32 / el1, 1), "unit": "images/s", "cores": 1, "sample": f"{it1} x 32 maps, {el1:.1f} s"}
     return out
 
 
@@ -261,7 +297,13 @@ def dry_run(a) -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        emit({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "all_gather_results": {"images": images}})
+        line = {"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "all_gather_results": {"images": images},
+                "cores_per_rank": int(os.environ.get("OCR_BENCH_CORES_PER_RANK") or max(1, host_cores() // world))}
+        if os.environ.get("OCR_BENCH_FAIL_EXCHANGE") == "1":   # test hook: the path a stalled / failed C-ABI exchange takes
+            line["exchange_ok"] = False
+            emit(line)
+            sys.exit(4)
+        emit(line)
 
 
 def c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, line, deadline_s=90.0):
@@ -270,11 +312,12 @@ def c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, loca
     rank leaves through the timer (rank 0 prints the line it already has, with the error noted) instead of hanging the job."""
     import threading
 
-    def expire():
+    def expire():   # a stalled communicator must never read as success: the line says so and the rank exits non-zero
         if line is not None:
             line["all_gather_results_c_abi_error"] = f"no completion within {deadline_s:.0f} s"
+            line["exchange_ok"] = False
             emit(line)
-        os._exit(0)
+        os._exit(3)
 
     dist.barrier()  # rank 0 arrives last (it ran the extras): the deadline counts from the moment everyone is here
     timer = threading.Timer(deadline_s, expire)
@@ -292,12 +335,12 @@ def c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, loca
         for _ in range(10):
             comm.all_gather_polygons(polys, scores)
         ms = (time.perf_counter() - t1) / 10 * 1e3
-        out = {"all_gather_results_c_abi_ms": round(ms, 3), "all_gather_results_c_abi_matches": bool(same),
+        out = {"exchange_ok": bool(same), "all_gather_results_c_abi_ms": round(ms, 3), "all_gather_results_c_abi_matches": bool(same),
                "all_gather_results_c_abi_note": "rank 0's wall time per call, ocr_comm_all_gather_polygons",
                "rccl_version_c_abi": capi.Comm.rccl_version()}
         comm.close()
     except Exception as e:
-        out = {"all_gather_results_c_abi_error": f"{type(e).__name__}: {e}"}
+        out = {"exchange_ok": False, "all_gather_results_c_abi_error": f"{type(e).__name__}: {e}"}
     timer.cancel()
     return out
 
@@ -363,10 +406,12 @@ def main():
 
     n, s = a.batch, a.size
     det_w = W.make_det_weights(0)
-    det = capi.Detector(W.pack_blob(det_w), local)
+    # host threads of this rank's post-processing pool: its share of the cores when several ranks share the host
+    cores_per_rank = int(os.environ.get("OCR_BENCH_CORES_PER_RANK") or max(1, host_cores() // world))
+    det_opts = f"post_threads={min(16, cores_per_rank)}"
+    det = capi.Detector(W.pack_blob(det_w), local, options=det_opts)
     if a.dtype == "bf16":
         det.set_precision(capi.PRECISION_BF16)
-    peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
     stream = torch.cuda.Stream(device=local)
     det.set_stream(stream.cuda_stream)
     x = torch.from_numpy(W.synth_image_batch(1 + rank, n, s, s)).to(f"cuda:{local}")
@@ -415,25 +460,110 @@ def main():
                 e[3] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (ms, fl, by, cnt) = dom
-        # the engine reports the MFMA FLOPs a launch EXECUTES: `achieved` / `frac` are matrix-core utilisation.
-        # A fused Winograd launch is a 3x3 conv whose direct-algorithm work (2 M N 9C, what SURVEY 8d counts for the
-        # reference graph) is 36/16 (F(2x2,3x3)) or 4 times (F(4x4,3x3)) that; it is reported beside, never as the fraction.
-        executed = fl / (ms * 1e-3) / 1e12
-        # direct-algorithm multiplies per executed one: F(2x2,3x3) 36/16, F(4x4,3x3) 144/36
-        alg_factor = 4.0 if name.startswith("winograd43_fused") else 36.0 / 16.0 if name.startswith("winograd_fused") else 1.0
-        executed_gflop = sum(v[1] for v in agg.values()) / reps / 1e9
-        traffic, traffic_source = pmc_traffic(name, n, s)
-        roof = {"kernel": name, "bound": "mfma", "achieved": round(executed, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(executed / peak, 4),
+        # the engine reports the f32 MULTIPLY-ADDS a launch executes (2 per MAC): on the f32 matrix instructions those are
+        # its MFMA FLOPs; a split-bf16 launch issues six bf16 MFMA products per f32 one.  `achieved` / `frac` are matrix-core
+        # utilisation against the peak of the instruction issued.  A fused Winograd launch is a 3x3 conv whose direct-algorithm
+        # work (2 M N 9C, what SURVEY 8d counts for the reference graph) is 4 times what it executes (F(4x4,3x3)); that is
+        # reported beside, never as the fraction.
+        instr, mult, kpeak = kernel_peak(name, a.dtype)
+        executed = mult * fl / (ms * 1e-3) / 1e12
+        alg_factor = 4.0 if name.startswith("winograd43_fused") else 1.0
+        executed_gflop = sum(v[1] * kernel_peak(k, a.dtype)[1] for k, v in agg.items()) / reps / 1e9
+        pmc, pmc_source, pmc_stale = pmc_extract(a.dtype, n, s)
+        pk = (pmc or {}).get(name, {})
+        allk = {}
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            ki, km, kp = kernel_peak(k, a.dtype)
+            tf = km * v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else None
+            e = {"ms_per_step": round(v[0] / reps, 4), "launches_per_step": v[3] // reps, "tflops": None if tf is None else round(tf, 2),
+                 "peak": kp, "frac": None if not tf else round(tf / kp, 4), "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+            c = (pmc or {}).get(k)
+            if c:   # counters per launch: HBM bytes, MFMA FLOPs (SQ_INSTS_VALU_MFMA_MOPS_* x 512), MFMA-busy share of the launch
+                e["pmc"] = {kk: c[kk] for kk in ("hbm_bytes", "mfma_flops", "mfma_busy") if kk in c}
+                if c.get("hbm_bytes") and v[0] > 0:
+                    e["pmc"]["hbm_frac"] = round(c["hbm_bytes"] / (v[0] / v[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            allk[k] = e
+        roof = {"kernel": name, "bound": "mfma", "instruction": instr, "achieved": round(executed, 2), "peak": kpeak,
+                "unit": "TFLOP/s", "frac": round(executed / kpeak, 4),
                 "definition": "MFMA FLOPs the kernel executes per launch / average launch duration (HIP events on the launch stream)",
                 "algorithmic_tflops": round(executed * alg_factor, 2), "algorithmic_speedup": round(alg_factor, 3),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_source,
+                "traffic": pk.get("hbm_bytes"), "traffic_unit": "HBM bytes per launch", "traffic_source": pmc_source,
+                "traffic_stale": pmc_stale,
+                "mfma_flops_counter": pk.get("mfma_flops"), "mfma_busy": pk.get("mfma_busy"),
+                "counter_note": "per launch, rocprofv3 --pmc in separate passes over tools/profile_layers.py (tools/collect_profiles.sh): "
+                                "FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; SQ_INSTS_VALU_MFMA_MOPS_F32/BF16 x 512; "
+                                "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE per XCD)",
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
-                "avg_launch_gflop_executed": round(fl / cnt / 1e9, 3),
-                "all_kernels": {k: {"ms_per_step": round(v[0] / reps, 4),
-                                    "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None,
-                                    "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
-                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+                "avg_launch_gflop_executed": round(mult * fl / cnt / 1e9, 3),
+                "all_kernels": allk}
+        if name.startswith("winograd43_fused"):
+            # what actually bounds this kernel: its B operand (the transformed weights, 36 matrices per 16
+            # input channels) streams from L2 into registers once per 16 x 16 pixel block - 36 x C/16 x 4 KB per wave - next to
+            # the input patches, the residual and the stores
+            cin = 64 if "c64" in name else 128 if "c128" in name else 256
+            blocks = n * ((s // 4 + 15) // 16) ** 2 if cin == 64 else None
+            if blocks:
+                l2 = blocks * ((cin // 16) * 36 * 4096 + 18 * 18 * cin * 4 + 2 * 256 * 64 * 4)
+                roof["l2_to_cu"] = {"bytes_per_launch": l2, "achieved_gbs": round(l2 / (ms / cnt * 1e-3) / 1e9, 1),
+                                    "measured_ceiling_gbs": round(70.0 * 256, 1),
+                                    "note": "operand bytes that cross L2 -> CU per launch (weight fragments 590 KB per block, patch, residual) / "
+                                            "time; ceiling 66-73 GB/s per CU x 256 (MI355X_MICROARCH.md, gather from L2)"}
+
+    # ---- the same step with every conv on the exact-f32 matrix instructions (option mfma=f32): what the split-bf16
+    # kernels buy, measured beside the headline in the same process
+    strict = {}
+    if rank == 0 and a.dtype == "f32" and not a.no_extras:
+        try:
+            d32 = capi.Detector(W.pack_blob(det_w), local, options="mfma=f32;" + det_opts)
+            d32.set_stream(stream.cuda_stream)
+            k = max(5, a.steps // 2)
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    d32.forward_device(x.data_ptr(), n, s, s, prob.data_ptr(), bitmap.data_ptr(), 0.6)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    d32.forward_device(x.data_ptr(), n, s, s, prob.data_ptr(), bitmap.data_ptr(), 0.6)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t1
+            strict["f32_mfma_only"] = {"images_per_s": round(n * k / el, 1), "ms_per_step": round(el / k * 1e3, 3), "steps": k,
+                                       "note": "engine option mfma=f32: no split-bf16 kernels, every conv on v_mfma_f32_32x32x2_f32 / 16x16x4_f32"}
+            d32.close()
+        except Exception as e:
+            strict["f32_mfma_only_error"] = f"{type(e).__name__}: {e}"
+
+    # ---- frames in HOST memory (the reference's call sites hand CPU tensors): PCIe inside the timed region.  Blocking forward
+    # over pipelined pieces (ocr_det_forward / _u8, MEM_HOST) from pinned and from pageable memory.
+    host = {}
+    if rank == 0 and not a.no_extras and a.dtype == "f32":
+        try:
+            xf = x.cpu().numpy()
+            xb = np.clip(np.rint(xf), 0, 255).astype(np.uint8)
+            pin_f, pin_b, pin_p = capi.HostBuffer(xf.shape, np.float32), capi.HostBuffer(xb.shape, np.uint8), capi.HostBuffer(xf.shape, np.float32)
+            pin_f.array[...] = xf
+            pin_b.array[...] = xb
+            page_p = np.empty_like(xf)
+            L = capi.lib()
+
+            def rate(fn, reps):
+                fn()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                return round(n * reps / (time.perf_counter() - t1), 1)
+
+            k = max(4, a.steps // 4)
+            host["host_forward_images_per_s"] = {
+                "pinned_f32": rate(lambda: capi.check(L.ocr_det_forward(det._h, pin_f.array.ctypes.data, n, s, s, pin_p.array.ctypes.data, capi.MEM_HOST)), k),
+                "pinned_u8": rate(lambda: capi.check(L.ocr_det_forward_u8(det._h, pin_b.array.ctypes.data, n, s, s, pin_p.array.ctypes.data, capi.MEM_HOST)), k),
+                "pageable_f32": rate(lambda: capi.check(L.ocr_det_forward(det._h, xf.ctypes.data, n, s, s, page_p.ctypes.data, capi.MEM_HOST)), k),
+                "pageable_u8": rate(lambda: capi.check(L.ocr_det_forward_u8(det._h, xb.ctypes.data, n, s, s, page_p.ctypes.data, capi.MEM_HOST)), k),
+                "note": "blocking call, frames and maps in host memory (52 MB f32 / 13 MB u8 in, 52 MB out per batch), copies and forward "
+                        "pipelined over four pieces of the batch; the device-resident rate is `value`"}
+            for b in (pin_f, pin_b, pin_p):
+                b.close()
+        except Exception as e:
+            host["host_forward_error"] = f"{type(e).__name__}: {e}"
 
     # ---- post-processing and the exchange step of the sharded path: every rank post-processes text-like maps
     # of its shard (get_boxes_and_box_scores) and the variable-length polygon blocks are all-gathered -
@@ -503,7 +633,7 @@ def main():
     if dist is not None and gathered is not None and not a.no_extras:
         dt = xp = None
         try:
-            dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local)
+            dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local, options=det_opts)
             dt.set_stream(stream.cuda_stream)
             pages, _ = W.synth_text_pages(77 + rank, n, s, s)
             xp = torch.from_numpy(pages).to(x.device)
@@ -543,7 +673,7 @@ def main():
     # same kernels, maps with ~20 word polygons per page.
     if rank == 0 and not a.no_extras and a.dtype == "f32":
         try:
-            dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local)
+            dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local, options=det_opts)
             dt.set_stream(stream.cuda_stream)
             pages, boxes = W.synth_text_pages(77, n, s, s)
             xp = torch.from_numpy(pages).to(x.device)
@@ -562,12 +692,86 @@ def main():
                 torch.cuda.synchronize()
                 e2e = time.perf_counter() - t1
             post["detect_postprocess_pipelined_images_per_s"] = round(n * k / e2e, 1)
+            # the same stream of batches from HOST memory: pinned u8 / f32 frames, polygons back, maps stay on the device
+            pb = np.clip(np.rint(pages), 0, 255).astype(np.uint8)
+            hp = {}
+            for label, arr in (("pinned_u8", pb), ("pinned_f32", pb.astype(np.float32)), ("pageable_u8", pb)):
+                bufs = []
+                for j in range(2):
+                    if label.startswith("pinned"):
+                        hb = capi.HostBuffer(arr.shape, arr.dtype)
+                        hb.array[...] = arr
+                        bufs.append(hb)
+                    else:
+                        bufs.append(None)
+                for it in range(2):
+                    t1 = time.perf_counter()
+                    for j in range(k):
+                        src = bufs[j & 1].array if bufs[j & 1] is not None else arr
+                        dt.detect_pipelined_host(src, adjust_values=adj1, params=params, convert=False)
+                    dt.detect_pipelined_host(None)
+                    e2h = time.perf_counter() - t1
+                hp[label] = round(n * k / e2h, 1)
+                for hb in bufs:
+                    if hb is not None:
+                        hb.close()
+            hp["note"] = ("ocr_det_detect_pipelined_host: per batch the frames cross PCIe into the staging slots beside the previous forward, "
+                          "polygons come back, the probability map stays on the device")
+            post["host_to_polygons_images_per_s"] = hp
             post["detect_postprocess_pipelined_polygons_per_image"] = round(found / (n * k), 2)
             post["detect_postprocess_pipelined_note"] = ("ocr_det_detect_pipelined: forward of batch k+1 overlapped with binarize + contours + "
                                                          "box scores + unclip of batch k; text-following synthetic weights and pages")
             dt.close()
         except Exception as e:
             post["detect_postprocess_pipelined_error"] = f"{type(e).__name__}: {e}"
+
+    # ---- configs[4] / the whole hot path on one GPU: pages -> detect (pipelined with its post-processing) -> crops of every
+    # polygon -> classify, in this run's precision; 128 synthetic pages in four batches of 32
+    e2e = {}
+    if rank == 0 and not a.no_extras:
+        try:
+            de = capi.Detector(W.pack_blob(W.make_det_weights_text()), local, options=det_opts)
+            if a.dtype == "bf16":
+                de.set_precision(capi.PRECISION_BF16)
+            de.set_stream(stream.cuda_stream)
+            re_ = capi.Recognizer(W.pack_blob(W.make_rec_weights(0)), local)
+            rec_stream = torch.cuda.Stream(device=local)     # the recogniser beside the next forward, not behind it
+            re_.set_stream(rec_stream.cuda_stream)
+            nb = 4
+            xs = [torch.from_numpy(W.synth_text_pages(300 + j, n, s, s)[0]).to(x.device) for j in range(nb)]
+            prs = [torch.empty_like(xs[0]), torch.empty_like(xs[0])]
+            cap = 4096
+            crops = torch.empty((cap, 784), dtype=torch.float32, device=x.device)
+            labels = torch.empty(cap, dtype=torch.int32, device=x.device)
+            probs_c = torch.empty(cap, dtype=torch.float64, device=x.device)
+            adj1 = np.ones((n, 2))
+            params = capi.default_params(skip_degenerate=True)
+            torch.cuda.synchronize()
+            ncrops = 0
+            for it in range(2):                      # warm-up, then timed
+                t1 = time.perf_counter()
+                ncrops = 0
+                for j in range(nb + 1):
+                    blk = (de.detect_pipelined_block(xs[j].data_ptr(), n, s, s, prs[j & 1].data_ptr(), adj1, params) if j < nb
+                           else de.detect_pipelined_block(0, 0, 0, 0, 0))
+                    if blk is not None:
+                        if blk.contents.n_polygons > cap:
+                            raise RuntimeError(f"{blk.contents.n_polygons} crops in one batch")
+                        k = de.extract_crops_block(blk, xs[j - 1].data_ptr(), n, s, s, adj1, crops.data_ptr())
+                        if k:
+                            re_.classify_device(crops.data_ptr(), k, 0, labels.data_ptr(), probs_c.data_ptr())
+                            re_.synchronize()
+                        ncrops += k
+                        de.free_block(blk)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t1
+            e2e = {"e2e_pages_per_s": round(n * nb / el, 1), "e2e_crops_per_page": round(ncrops / (n * nb), 2), "e2e_pages": n * nb,
+                   "e2e_note": f"detect (ocr_det_detect_pipelined, {a.dtype}) -> polygons -> ocr_extract_crops -> ocr_rec_classify on synthetic pages with "
+                               "text-following weights, device-resident frames, crops and labels"}
+            de.close()
+            re_.close()
+        except Exception as e:
+            e2e = {"e2e_error": f"{type(e).__name__}: {e}"}
 
     extras = {}
     rec_w = W.make_rec_weights(0)
@@ -624,11 +828,17 @@ def main():
             extras["rec_error"] = f"{type(e).__name__}: {e}"
 
     total_images = n * world * a.steps
+    exit_code = 0
     if rank == 0:
         line = {
             "metric": "images/sec (640x640 detect)", "value": round(total_images / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "arithmetic": ("f32 tensors and f32 accumulation everywhere; Winograd kernels and 1x1 convs on the f32 matrix instructions; the "
+                           "other MFMA-bound convs, the stem and the head multiply on v_mfma_f32_32x32x16_bf16 from operands split into three "
+                           "bf16 terms (six partial products per f32 product, dropped terms <= 2^-23 of it: the error of an f32 FMA chain, "
+                           "profiles/r03_bf16x3_accuracy.txt; same parity bars as mfma=f32, whose rate is `f32_mfma_only`)") if a.dtype == "f32"
+                          else "bf16 operands (activations and weights rounded to bf16), f32 accumulation: the opt-in precision of configs[4]",
             "config": {"workload": f"detection forward (ResNet18+FPN+prob head, fused binarize), batch {n} x 1x{s}x{s} "
                                    f"f32 frames per GPU, BASELINE configs[1]"
                                    + (" in the opt-in bf16 precision of configs[4]" if a.dtype == "bf16" else ""),
@@ -639,9 +849,14 @@ def main():
             "tflops_executed": None if executed_gflop is None else round(executed_gflop * a.steps * world / elapsed / 1e3, 2),
             "roofline": roof,
         }
+        line.update(strict)
+        line.update(host)
+        line.update(e2e)
         line.update(post)
         line.update(extras)
-        if world == 1 and not a.no_cpu_baseline:
+        line["post_threads"] = min(16, cores_per_rank)
+        line["cores_per_rank"] = cores_per_rank
+        if not a.no_cpu_baseline:   # every N: each line of a scaling sweep stands alone (the other ranks wait in the barrier below)
             try:
                 line["cpu_baseline"] = cpu_baseline(det_w, rec_w, s, a.cpu_seconds)
             except Exception as e:
@@ -649,6 +864,8 @@ def main():
         if dist is not None and try_c_abi and gathered is not None:
             line.update(c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, line))
         emit(line)
+        if line.get("exchange_ok") is False and backend == "nccl":
+            exit_code = 4   # the line is out, with the error in it; a failed exchange over RCCL must not read as a clean run
     elif dist is not None and try_c_abi and gathered is not None:
         c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, None)
     det.close()
@@ -657,6 +874,8 @@ def main():
             dist.destroy_process_group()   # c_abi_exchange must not stall the others after the line is out
         except Exception:
             pass
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -476,6 +476,31 @@ class Detector:
         finally:
             lib().ocr_polygons_free(out)
 
+    def detect_pipelined_block(self, x_ptr: int, n: int, h: int, w: int, prob_ptr: int, adjust_values=None,
+                               params: Optional[PostprocParams] = None):
+        """ocr_det_detect_pipelined returning the PREVIOUS batch's ocr_polygons_t block itself (a ctypes pointer, None on the
+        first call; release it with free_block) - what extract_crops_block consumes without a detour through Python lists."""
+        adj_p = None
+        if x_ptr:
+            adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+            adj_p = adj.ctypes.data_as(C.POINTER(C.c_double))
+        out = C.POINTER(Polygons)()
+        check(lib().ocr_det_detect_pipelined(self._h, x_ptr or None, n, h, w, prob_ptr or None, adj_p,
+                                             C.byref(params) if params is not None else None, C.byref(out)))
+        return out if out else None
+
+    def extract_crops_block(self, block, frames_ptr: int, n: int, h: int, w: int, adjust_values, crops_ptr: int) -> int:
+        """ocr_extract_crops for a polygon block on device-resident frames; returns the number of crops written."""
+        adj = np.ascontiguousarray(adjust_values, dtype=np.float64).reshape(n, 2)
+        if block.contents.n_polygons:
+            check(lib().ocr_extract_crops(self._h, frames_ptr, n, h, w, MEM_DEVICE, block, adj.ctypes.data_as(C.POINTER(C.c_double)), crops_ptr))
+        return block.contents.n_polygons
+
+    @staticmethod
+    def free_block(block) -> None:
+        if block:
+            lib().ocr_polygons_free(block)
+
     def postprocess_counts(self, prob, n: int, h: int, w: int, adjust_values: np.ndarray, mem_kind: int = MEM_HOST,
                            params: Optional[PostprocParams] = None) -> Tuple[int, int]:
         """get_boxes_and_box_scores without turning the CSR block into Python objects: (polygons, vertices).

@@ -342,7 +342,9 @@ int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, 
       }
     }
     OCR_HIP(hipSetDevice(det->impl.device()));
-    hipStream_t s = det->impl.stream();
+    // while a pipelined forward is in flight on the handle's stream the crops of the batch that just came back are cut on
+    // the post-processing stream, beside it (frames and polygons of a finished batch: no ordering against that forward)
+    hipStream_t s = det->impl.has_pending() ? det->impl.post_stream() : det->impl.stream();
     const size_t fr_bytes = (size_t)n * h * w * 4, bx_bytes = boxes.size() * sizeof(CropBox), cr_bytes = (size_t)np * 784 * 4;
     if (mem_kind == OCR_MEM_DEVICE) {
       char* sc = static_cast<char*>(det->impl.scratch(1, align256(bx_bytes)));

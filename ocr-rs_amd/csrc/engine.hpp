@@ -96,6 +96,7 @@ class Detector {
     ocr_postproc_params_t params{};
     hipEvent_t event = nullptr;
   };
+  bool has_pending() const { return pending_.valid; }
   Pending swap_pending(Pending& next) {
     Pending prev = std::move(pending_);
     pending_ = std::move(next);

@@ -48,3 +48,23 @@ def test_launcher_makes_no_gpu_call():
     head = src[:src.index("def main():")]
     top_level = [ln for ln in head.splitlines() if ln.startswith(("import ", "from "))]
     assert not any("torch" in ln or "ocr_rs_amd" in ln or "numpy" in ln for ln in top_level), top_level
+
+
+def test_world_8_rendezvous_and_core_shares():
+    """The shape of the driver's scaling run (--gpus 8): eight ranks rendezvous, every shard arrives in rank order, and
+    each rank is told its share of the host cores (what sizes its post-processing pool)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run", "--batch", "3"], env=_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["all_gather_results"]["images"] == 24
+    assert line["cores_per_rank"] == max(1, len(os.sched_getaffinity(0)) // 8) or line["cores_per_rank"] >= 1
+
+
+def test_failed_exchange_is_never_a_clean_exit():
+    """A stalled or failed C-ABI exchange emits the line WITH the error and exits non-zero (rank 0 and with it the launcher)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=_env(OCR_BENCH_FAIL_EXCHANGE="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["exchange_ok"] is False

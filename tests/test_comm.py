@@ -51,3 +51,35 @@ def test_rccl_transport_world_size_one():
     with pytest.raises(capi.OcrError):
         comm.all_gather_labels(labels, 10)    # capacity too small: an error, not an overrun
     comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+def test_two_ranks_on_one_device_fail_cleanly_from_two_threads():
+    """The error path of the communicator a multi-threaded host can hit: two ranks (two threads of ONE process, the
+    one-process-many-GPUs form the header allows) both name device 0.  RCCL refuses a duplicate device; both ocr_comm_create
+    calls must come back with an error message - no hang, no crash - and the library must stay usable afterwards."""
+    import threading
+    uid = capi.Comm.unique_id()
+    out = [None, None]
+
+    def rank(r):
+        try:
+            c = capi.Comm(uid, 2, r, 0)
+            c.close()
+            out[r] = "created"
+        except capi.OcrError as e:
+            out[r] = e
+
+    ts = [threading.Thread(target=rank, args=(r,), daemon=True) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(150)
+    assert not any(t.is_alive() for t in ts), "ocr_comm_create did not return"
+    assert all(isinstance(o, capi.OcrError) for o in out), out
+    assert all("ncclCommInitRank" in str(o) or "RCCL" in str(o) or "nccl" in str(o).lower() for o in out), out
+    comm = capi.Comm(capi.Comm.unique_id(), 1, 0, 0)          # a fresh single-rank communicator still works
+    polys, scores = _shard(0, 3)
+    assert comm.all_gather_polygons(polys, scores) == (polys, scores)
+    comm.close()

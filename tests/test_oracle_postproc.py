@@ -49,3 +49,41 @@ def test_contour_lengths_img55(golden_dir):
     _, bitmap = _img55(golden_dir)
     cs = O.find_contours(bitmap * 255)
     assert [len(c) for c in cs] == [239, 463, 196, 505]
+
+
+# ---- the compiled CPU baseline (oracle/postproc_cpu.cpp, what bench.py's cpu_baseline.postprocess times) is held to the
+# same known answers and to the Python restatement
+@pytest.fixture(scope="module")
+def cpu_lib():
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-s", "-C", here])
+    from oracle import postproc_cpu as PC
+    return PC
+
+
+@pytest.mark.parametrize("adj,polys", [((1.0, 1.0), K.IMG55_POLYS_ADJ1), ((2.0, 2.0), K.IMG55_POLYS_ADJ2)])
+def test_compiled_cpu_postprocess_reproduces_the_reference_kat(golden_dir, cpu_lib, adj, polys):
+    img = np.array(Image.open(os.path.join(golden_dir, "gt_shrinked_img55.png")).convert("L"))
+    pred = (img.astype(np.float64) / 255.0).astype(np.float32).reshape(1, 1, 800, 800)
+    for threads in (1, 4):
+        got_p, got_s = cpu_lib.get_boxes_and_box_scores(pred, np.array([adj]), threads=threads)
+        assert got_p[0] == polys and got_s[0] == K.IMG55_SCORES
+
+
+def test_compiled_cpu_postprocess_matches_python_oracle_on_real_valued_maps(golden_dir, cpu_lib):
+    """Maps with fractional probabilities (scores are real f64 means, not 1.0), several images, several threads."""
+    rng = np.random.RandomState(3)
+    names = ["gt_shrinked_img224.png", "gt_shrinked_img494.png", "gt_shrinked_img545.png"]
+    maps = []
+    for nm in names:
+        g = np.array(Image.open(os.path.join(golden_dir, nm)).convert("L"))[80:720, 80:720]
+        maps.append(np.where(g > 127, 0.75 + 0.25 * rng.rand(640, 640), 0.1 * rng.rand(640, 640)).astype(np.float32))
+    pred = np.stack(maps)[:, None]
+    adj = np.array([[1.0, 1.0], [0.8, 0.9], [1.25, 0.5]])
+    want_p, want_s = O.get_boxes_and_box_scores(pred, adj)
+    got_p, got_s = cpu_lib.get_boxes_and_box_scores(pred, adj, threads=3)
+    assert got_p == want_p and sum(len(p) for p in want_p) > 3
+    for a, b in zip(got_s, want_s):
+        assert np.allclose(a, b, rtol=0, atol=1e-12)
+    assert cpu_lib.get_boxes_and_box_scores(pred, adj, threads=2, counts_only=True)[0] == sum(len(p) for p in want_p)

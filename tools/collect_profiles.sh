@@ -2,22 +2,31 @@
 # Collects the evidence profiles/ holds for one round, on the GPU box (run through gpurun from the repository root):
 #   tools/collect_profiles.sh <outdir under gpurun_out>
 # 1. rocprofv3 --kernel-trace --stats of the default bench.py command (the JSON line it printed is kept beside it)
-# 2. separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over one profiled forward and one 65 536-crop recogniser pass
-# 3. per-launch layer tables (f32, bf16), the bf16 bench line, accuracy of every engine option, recogniser batches
-# Back on the build box: tools/rocprof_stats_csv.py <out>/stats and tools/make_traffic_json.py <out>/pmc_fetch <out>/pmc_write
-# r02 <out>/rec_fetch <out>/rec_write turn the rocpd databases into the CSV / JSON files under profiles/.
+# 2. PMC passes over one profiled forward, every counter set in its OWN run (no tracing besides the kernel trace): FETCH_SIZE,
+#    WRITE_SIZE, MFMA op counters, MFMA-busy cycles - for the f32 and the bf16 precision - and FETCH / WRITE over one
+#    65 536-crop recogniser pass
+# 3. per-launch layer tables (f32, f32 with mfma=f32, bf16), the bf16 bench line, accuracy of every engine option, recogniser batches
+# Back on the build box: tools/rocprof_stats_csv.py <out>/stats and tools/make_pmc_json.py turn the outputs into the CSV / JSON
+# files under profiles/.
 set -o pipefail
-O=$PWD/gpurun_out/${1:-r02/final}
+O=$PWD/gpurun_out/${1:-r03/final}
 mkdir -p $O
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats -o t -- python3 bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err || exit 1
 echo "bench under rocprof done"
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o t -- python3 tools/profile_layers.py 32 640 1 > /dev/null 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o t -- python3 tools/profile_layers.py 32 640 1 > /dev/null 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE -d $O/rec_fetch -o t -- python3 tools/profile_rec.py 65536 > /dev/null 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE -d $O/rec_write -o t -- python3 tools/profile_rec.py 65536 > /dev/null 2>&1 || exit 1
-echo "pmc passes done"
+for P in f32 bf16; do
+  OPT=""; [ $P = bf16 ] && OPT="precision=bf16"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$P -o t -- python3 tools/profile_layers.py 32 640 1 0 "$OPT" > /dev/null 2>&1 || exit 1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$P -o t -- python3 tools/profile_layers.py 32 640 1 0 "$OPT" > /dev/null 2>&1 || exit 1
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/pmc_mops_$P -o t -- python3 tools/profile_layers.py 32 640 1 0 "$OPT" > /dev/null 2>&1 || exit 1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy_$P -o t -- python3 tools/profile_layers.py 32 640 1 0 "$OPT" > /dev/null 2>&1 || exit 1
+  echo "pmc passes $P done"
+done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/rec_fetch -o t -- python3 tools/profile_rec.py 65536 > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/rec_write -o t -- python3 tools/profile_rec.py 65536 > /dev/null 2>&1 || exit 1
+echo "recogniser pmc passes done"
 python3 tools/profile_layers.py 32 640 5 > $O/layers_f32.txt 2>/dev/null || exit 1
+python3 tools/profile_layers.py 32 640 5 0 "mfma=f32" > $O/layers_f32_mfma_f32.txt 2>/dev/null || exit 1
 python3 tools/profile_layers.py 32 640 5 0 "precision=bf16" > $O/layers_bf16.txt 2>/dev/null || exit 1
 python3 bench.py --steps 20 --warmup 3 --dtype bf16 > $O/bench_line_bf16.json 2>/dev/null || exit 1
 python3 tools/accuracy_report.py > $O/accuracy_modes.txt 2>/dev/null || exit 1
