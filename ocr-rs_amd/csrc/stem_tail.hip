@@ -161,10 +161,11 @@ constexpr int PWB = 36;          // bf16 per image row (72 bytes): 32 used
 // X3: the f32 stem on the bf16 matrix cores - the input tile as three bf16 images (pixel = hi + mid + lo exactly), the
 // weights as three fragment sets, six partial products per window (mid.lo, lo.mid, lo.lo are below 2^-23 of a product),
 // f32 accumulate, f32 output: 48 MFMAs of 32 cycles per wave and tile where the exact-f32 kernel above issues 56 of 64.
-template <bool X3, typename TX>
+template <bool X3, typename TX, typename TO>
 __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x, const u32x4* __restrict__ wfrag,
                                                        const float* __restrict__ scale, const float* __restrict__ bias,
-                                                       std::conditional_t<X3, float, __bf16>* __restrict__ out, int H, int W) {
+                                                       TO* __restrict__ out, int H, int W) {
+  static_assert(std::is_same<TO, std::conditional_t<X3, float, __bf16>>::value, "X3 writes f32, the bf16 precision bf16");
   constexpr int NPL = X3 ? 3 : 1;                       // bf16 images of the input tile / weight fragment sets
   constexpr int IMG = IRB * PWB / 2;                    // words per image (two bf16 per word)
   __shared__ __attribute__((aligned(16))) unsigned in_s[NPL * IMG];
@@ -188,19 +189,38 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
       for (int s = 0; s < 4; ++s) wreg[pl][ct][s] = __builtin_bit_cast(bf16x8, wfrag[((pl * 2 + ct) * 4 + s) * 64 + lane]);
   const float sc0 = scale[l31], bi0 = bias[l31], sc1 = scale[32 + l31], bi1 = bias[32 + l31];
   for (int i = tid; i < NPL * (PWB / 2); i += NT) in_s[(i / (PWB / 2)) * IMG + (IRB - 1) * (PWB / 2) + i % (PWB / 2)] = 0u;  // the extra row
+  // the input pixels of a tile are requested one tile ahead (two pixel pairs per thread, in registers): their HBM latency
+  // runs under the previous tile's MFMAs and pooling instead of in front of every tile
+  constexpr int NLD = (IR * (ICP / 2) + NT - 1) / NT;
+  float pre[NLD][2];
+  auto request = [&](int tl) {
+    const int pw0 = (blockIdx.x * TL + tl) * TPW;
+    const int ic0 = 2 * (2 * pw0 - 1) - 3;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * NT;
+      const int rr = i / (ICP / 2), cp = i - rr * (ICP / 2);
+      const int ih = ir0 + rr, iw = ic0 + 2 * cp;
+      float v0 = 0.f, v1 = 0.f;  // zero padding of conv1
+      if (i < IR * (ICP / 2) && pw0 < Wp && (unsigned)ih < (unsigned)H) {
+        if ((unsigned)iw < (unsigned)W) v0 = (float)xin[(size_t)ih * W + iw];
+        if ((unsigned)(iw + 1) < (unsigned)W) v1 = (float)xin[(size_t)ih * W + iw + 1];
+      }
+      pre[k][0] = v0;
+      pre[k][1] = v1;
+    }
+  };
+  request(0);
   for (int tl = 0; tl < TL; ++tl) {
     const int pw0 = (blockIdx.x * TL + tl) * TPW;
     if (pw0 >= Wp) break;
     const int cc0 = 2 * pw0 - 1;
-    const int ic0 = 2 * cc0 - 3;
-    for (int i = tid; i < IR * (ICP / 2); i += NT) {   // one word = two neighbouring pixels
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {   // one word = two neighbouring pixels
+      const int i = tid + k * NT;
+      if (i >= IR * (ICP / 2)) break;
       const int rr = i / (ICP / 2), cp = i - rr * (ICP / 2);
-      const int ih = ir0 + rr, iw = ic0 + 2 * cp;
-      float v0 = 0.f, v1 = 0.f;  // zero padding of conv1
-      if ((unsigned)ih < (unsigned)H) {
-        if ((unsigned)iw < (unsigned)W) v0 = (float)xin[(size_t)ih * W + iw];
-        if ((unsigned)(iw + 1) < (unsigned)W) v1 = (float)xin[(size_t)ih * W + iw + 1];
-      }
+      const float v0 = pre[k][0], v1 = pre[k][1];
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const bf16x2 pk = {(__bf16)v0, (__bf16)v1};
       in_s[rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pk);
@@ -212,6 +232,7 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
         in_s[2 * IMG + rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pl);
       }
     }
+    if (tl + 1 < TL) request(tl + 1);
     __syncthreads();
     {
       const int mt = wv;
@@ -419,9 +440,9 @@ void launch_stem_bf16(const void* x, int x_u8, const void* wfrag, const float* s
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
   dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
-  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<false, uint8_t>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag),
+  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<false, uint8_t, __bf16>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag),
                                scale, bias, static_cast<__bf16*>(out), H, W);
-  else hipLaunchKernelGGL((stem_bf16_kernel<false, float>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag), scale, bias,
+  else hipLaunchKernelGGL((stem_bf16_kernel<false, float, __bf16>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag), scale, bias,
                           static_cast<__bf16*>(out), H, W);
   OCR_HIP(hipGetLastError());
 }
@@ -431,9 +452,9 @@ void launch_stem_x3(const void* x, int x_u8, const void* wfrag3, const float* sc
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
   dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
-  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<true, uint8_t>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag3),
+  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<true, uint8_t, float>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag3),
                                scale, bias, out, H, W);
-  else hipLaunchKernelGGL((stem_bf16_kernel<true, float>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag3), scale, bias,
+  else hipLaunchKernelGGL((stem_bf16_kernel<true, float, float>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag3), scale, bias,
                           out, H, W);
   OCR_HIP(hipGetLastError());
 }

@@ -11,6 +11,7 @@ usage: make_pmc_json.py <f32|bf16> <fetch_dir> <write_dir> <mops_dir> <busy_dir>
 Per kernel label (bench.py's names) and per launch, second (warm) forward of each run.  The extract is stamped with a hash
 of ocr-rs_amd/csrc (bench.csrc_hash): bench.py marks it stale when the kernel sources change afterwards."""
 import collections
+import re
 import csv
 import glob
 import json
@@ -23,8 +24,15 @@ TILE = {"128, 128": "128x128", "128, 64": "128x64", "64, 64": "64x64"}
 
 def pretty(name: str) -> str:
     # "void ocr::igemm::conv_igemm<float, float, 64, 64, 3, 1, 0, 0>(...)" -> bench.py's kernel label
+    m = re.search(r"conv_igemmI(DF16b|f)(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+    if m:   # a name rocprofv3 left mangled (__bf16 template arguments)
+        name = "void ocr::igemm::conv_igemm<%s, %s, %s, %s, %s, %s, %s, %s, %s>(" % (
+            "__bf16" if m.group(1) != "f" else "float", "__bf16" if m.group(2) != "f" else "float", m.group(3), m.group(4), m.group(5),
+            m.group(6), m.group(7), m.group(8), "true" if m.group(9) == "1" else "false")
+    if "conv3x3_bf16_c64" in name:
+        return "conv3x3_bf16_c64"
     if "conv_igemm<" not in name:
-        return "stem_x3_conv7x7_bn_relu_maxpool" if "stem_bf16_kernel<true" in name else \
+        return "stem_x3_conv7x7_bn_relu_maxpool" if ("stem_bf16_kernel<true" in name or "stem_bf16_kernelILb1E" in name) else \
                "stem_conv7x7_bn_relu_maxpool" if ("stem_kernel" in name or "stem_bf16_kernel" in name) else \
                "convt2x2_sigmoid" if "convt2_sigmoid" in name else \
                "tail_x3_convt1_bn_relu_convt2_sigmoid" if "tail_fused_kernel<float, true>" in name else \
@@ -72,7 +80,7 @@ def load(d, counter):
     """[(label, counter value summed over its rows)] per dispatch, in dispatch order"""
     per = collections.OrderedDict()
     for did, name, val in rows_of(d, counter):
-        if "ocr::" in name:
+        if "ocr::" in name or "_ZN3ocr" in name:
             per[did] = (pretty(name), per.get(did, ("", 0.0))[1] + val)
     return [per[k] for k in sorted(per)]
 
