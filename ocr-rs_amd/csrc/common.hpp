@@ -151,19 +151,22 @@ void launch_crops(const float* frames_dev, int H, int W, const CropBox* boxes_de
 struct RecWeights {
   const float *c1f, *c1b;   // conv1 as MFMA fragments [13][64], bias [32]
   const float *c2f, *c2b;   // conv2 as MFMA fragments [25][2][4][64][4], bias [64]
-  const float* c2s;         // conv2 as 16x16x4 fragments [25][4][2][64][4] (small-batch kernel)
   const float *f1w, *f1b;   // fc1 [512][1024], bias [512]
   const float* f1s;         // fc1 in the operand order of the small-batch kernel (rec_fc1_small_weights)
   const float *f2f, *f2b;   // fc2 as MFMA fragments [2][64][64][4] (rows 62, 63 zero), bias [64]
+  const void* c2x;          // conv2 as three bf16 fragment sets for the split-bf16 small-batch kernel (rec_conv2_small_x3_fragments)
+  const float* f2s;         // fc2 in the fragment order of rec_fc2_small_kernel (rec_fc2_small_fragments)
 };
 std::vector<float> rec_conv1_fragments(const float* w_32x25);
 std::vector<float> rec_conv2_fragments(const float* w_64x32x25);
 int rec_crops_per_block(int n);
-std::vector<float> rec_conv2_small_fragments(const float* w_64x32x25);
 std::vector<float> rec_fc1_small_weights(const float* w_512x1024);
+std::vector<uint16_t> rec_conv2_small_x3_fragments(const float* w_64x32x25);
+std::vector<float> rec_fc2_small_fragments(const float* w_62x512);
+// the small-batch pass, stage 0 conv (split-bf16 conv2), 1 fc1 (K split over waves), 2 fc2 + softmax + top-1
+void launch_rec_small(const RecWeights& w, const float* crops, int n, float* feat, float* hid, float* logits62, int32_t* labels,
+                      double* probs, hipStream_t s, int stage);
 bool rec_small_batch(int n);   // the latency-optimised kernels (16x16x4 MFMA chains) take batches up to 1024 crops
-void launch_rec_conv_small(const RecWeights& w, const float* crops, int n, float* feat, hipStream_t s);
-void launch_rec_fc1_small(const RecWeights& w, const float* feat, int n, float* hid, hipStream_t s);
 void launch_rec_conv(const RecWeights& w, const float* crops, int n, float* feat, hipStream_t s);
 std::vector<float> rec_fc2_fragments(const float* w_62x512);
 void launch_rec_fc2_softmax(const RecWeights& w, const float* hid, int n, float* logits62, int32_t* labels, double* probs, hipStream_t s);

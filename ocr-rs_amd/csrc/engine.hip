@@ -1151,7 +1151,6 @@ Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(dev
   w_.c1f = arena_.upload(rec_conv1_fragments(vec("conv1.weight", {32, 1, 5, 5}).data()));
   w_.c1b = arena_.upload(vec("conv1.bias", {32}));
   w_.c2f = arena_.upload(rec_conv2_fragments(vec("conv2.weight", {64, 32, 5, 5}).data()));
-  w_.c2s = arena_.upload(rec_conv2_small_fragments(vec("conv2.weight", {64, 32, 5, 5}).data()));
   w_.c2b = arena_.upload(vec("conv2.bias", {64}));
   w_.f1w = arena_.upload(vec("fc1.weight", {512, 1024}));
   w_.f1s = arena_.upload(rec_fc1_small_weights(vec("fc1.weight", {512, 1024}).data()));
@@ -1159,6 +1158,8 @@ Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(dev
   std::vector<float> b2 = vec("fc2.bias", {62});
   b2.resize(64, 0.f);  // two padding columns: the kernel works on 32-column MFMA tiles
   w_.f2f = arena_.upload(rec_fc2_fragments(vec("fc2.weight", {62, 512}).data()));
+  w_.f2s = arena_.upload(rec_fc2_small_fragments(vec("fc2.weight", {62, 512}).data()));
+  w_.c2x = arena_.upload_u16(rec_conv2_small_x3_fragments(vec("conv2.weight", {64, 32, 5, 5}).data()));
   w_.f2b = arena_.upload(b2);
 }
 
@@ -1196,10 +1197,24 @@ void Recognizer::classify(const float* crops, int n, float* logits, int32_t* lab
     ensure_workspace(nb);
     Recorder rec(prof, stream_);
     const bool small = rec_small_batch(nb);
+    if (small) {
+      // configs[2]-sized batches: three launches built for latency (split-bf16 conv2, K-split fc1, 16-crop fc2 tiles)
+      rec.begin();
+      launch_rec_small(w_, crops + (size_t)b * 784, nb, feat_, hid_, nullptr, nullptr, nullptr, stream_, 0);
+      rec.end("rec_conv_small_x3", 2.0 * nb * (576.0 * 32 * 26 + 64.0 * 64 * 800), (double)nb * (784 + 1024) * 4 + 13 * 64 * 4 + 25 * 2048 * 6);
+      rec.begin();
+      launch_rec_small(w_, nullptr, nb, feat_, hid_, nullptr, nullptr, nullptr, stream_, 1);
+      rec.end("rec_fc1_ksplit", 2.0 * nb * 1024 * 512, 4.0 * ((double)nb * (1024 + 512) + 1024.0 * 512));
+      rec.begin();
+      launch_rec_small(w_, nullptr, nb, feat_, hid_, logits ? logits + (size_t)b * 62 : nullptr, labels ? labels + b : nullptr,
+                       probs ? probs + b : nullptr, stream_, 2);
+      rec.end("rec_fc2_small_softmax_top1", 2.0 * nb * 512 * 64, (double)nb * (512 * 4 + 12) + 64 * 512 * 4);
+      rec.finish();
+      continue;
+    }
     rec.begin();
-    if (small) launch_rec_conv_small(w_, crops + (size_t)b * 784, nb, feat_, stream_);
-    else launch_rec_conv(w_, crops + (size_t)b * 784, nb, feat_, stream_);
-    rec.end(small ? "rec_conv_small" : rec_crops_per_block(nb) == 2 ? "rec_conv<2>" : "rec_conv<4>",
+    launch_rec_conv(w_, crops + (size_t)b * 784, nb, feat_, stream_);
+    rec.end(rec_crops_per_block(nb) == 2 ? "rec_conv<2>" : "rec_conv<4>",
             2.0 * nb * (576.0 * 32 * 26 + 64.0 * 64 * 800), (double)nb * (784 + 1024) * 4 + 13 * 64 * 4 + 25 * 2048 * 4);
     // fc1 + bias + ReLU as a plain GEMM over the batch: M = crops, K = Cin, N = Cout
     auto fc = [&](const char* name, const float* in, const float* wgt, const float* bias, int cin, int cout, bool relu, float* out) {
@@ -1226,13 +1241,7 @@ void Recognizer::classify(const float* crops, int n, float* logits, int32_t* lab
       launch_conv_igemm(d, stream_);
       rec.end(name, 2.0 * nb * cin * cout, 4.0 * ((double)nb * (cin + cout) + (double)cin * cout));
     };
-    if (small) {
-      rec.begin();
-      launch_rec_fc1_small(w_, feat_, nb, hid_, stream_);
-      rec.end("rec_fc1_small", 2.0 * nb * 1024 * 512, 4.0 * ((double)nb * (1024 + 512) + 1024.0 * 512));
-    } else {
-      fc("rec_fc1", feat_, w_.f1w, w_.f1b, 1024, 512, true, hid_);
-    }
+    fc("rec_fc1", feat_, w_.f1w, w_.f1b, 1024, 512, true, hid_);
     rec.begin();
     launch_rec_fc2_softmax(w_, hid_, nb, logits ? logits + (size_t)b * 62 : nullptr, labels ? labels + b : nullptr,
                            probs ? probs + b : nullptr, stream_);

@@ -16,6 +16,8 @@
 //   fc1                  the batched GEMM [B x 1024] x [1024 x 512] (+b, ReLU) through conv_igemm's 1x1 form - LDS-DMA
 //                        staged, weights shared by the 64 / 128 crops of a tile
 //   rec_fc2_softmax_kernel  [B x 512] x [512 x 64] (+b; 62 real columns), softmax over the 62 logits in f64, top-1
+#include <cstring>
+
 #include "common.hpp"
 
 namespace ocr {
@@ -186,41 +188,46 @@ __global__ __launch_bounds__(256, 2) void rec_conv_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------------------------
 // Low-latency forms for small batches (BASELINE configs[2] is 256 crops: one launch wave, nothing to amortise).  The
-// time of the kernels above is then the LENGTH OF ONE DEPENDENT MFMA CHAIN: conv2 accumulates K = 800 as 400
-// v_mfma_f32_32x32x2_f32 of 64 cycles each, fc1 K = 1024 as 512.  v_mfma_f32_16x16x4_f32 contracts four k per
-// instruction with a 40-cycle dependent latency, and fed with k in the order (0,4,1,5),(2,6,3,7) of every group of
-// eight it produces the SAME BITS as the 32x32x2 chain in its (0,4),(1,5),(2,6),(3,7) order
-// (tools/probes/mfma_chain_order.hip): the small-batch path is 2.5x shorter per chain, uses 16 waves per crop, and a
-// crop's logits still do not depend on the batch it arrives in.
+// time of the kernels above is then the LENGTH OF ONE DEPENDENT MFMA CHAIN (conv2 accumulates K = 800 as 400
+// v_mfma_f32_32x32x2_f32 of 64 cycles each, fc1 K = 1024 as 512) on a machine that is mostly idle.
+// Three launches built for LATENCY, one crop per workgroup in the conv stage:
+// rec_conv_small_x3_kernel: conv1 as above; the pooled map goes to LDS as three bf16 images (p = hi + mid + lo exactly), and
+// conv2 runs on v_mfma_f32_16x16x32_bf16 - K = 32 input channels of one tap per instruction, six partial products per
+// tap (weights as three bf16 fragment sets): 150 MFMAs of 16 cycles per wave where the f32 form issues 200 of 32.
+// Results are f32-accurate (dropped terms <= 2^-23 of a product), not bit-identical to the large-batch path - the
+// contract is logits within 1e-4 and labels exact.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int P1X_PLANE = P1_PIX * 64;   // bytes of one bf16 image [144 pixels][32 channels]
+// byte offset of channel c of pooled pixel pix inside a plane: 16-byte chunk c / 8 in slot (c / 8) ^ ((pix >> 1) & 3)
+// (conflict-free for the conv2 fragment reads of every tap: checked exhaustively)
+__device__ __forceinline__ int p1x_offset(int pix, int c) { return pix * 64 + ((((c >> 3) ^ ((pix >> 1) & 3)) << 4) | ((c & 7) << 1)); }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// conv1 + pool + conv2 + pool of ONE crop per 1024-thread workgroup.  conv1 as in rec_conv_kernel (18 tiles over the
-// 16 waves); conv2: wave w owns the 16 x 16 tile (pixel rows 2 (w >> 2), 2 (w >> 2) + 1 of the 8 x 8 output = four
-// pool windows, output channels 16 (w & 3) .. + 15).  Tile row 4 slot + sub is sub-pixel `sub` of window `slot`:
-// a lane's four accumulator registers are one window, the pool is a max over them.
-#ifdef REC_STAMPS
-__device__ long long g_rec_stamps[16];
-#define REC_STAMP(k) do { if (blockIdx.x == 0 && tid == 0) g_rec_stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define REC_STAMP(k) do {} while (0)
-#endif
-__global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __restrict__ crops, int n, const float* __restrict__ w1f,
-                                                              const float* __restrict__ b1, const float* __restrict__ w2s,
-                                                              const float* __restrict__ b2, float* __restrict__ feat) {
-  __shared__ __attribute__((aligned(16))) float p1[P1_PIX * P1_ROW];
+__global__ __launch_bounds__(1024) void rec_conv_small_x3_kernel(const float* __restrict__ crops, int n, const float* __restrict__ w1f,
+                                                                 const float* __restrict__ b1, const uint4* __restrict__ w2x,
+                                                                 const float* __restrict__ b2, float* __restrict__ feat) {
+  __shared__ __attribute__((aligned(16))) unsigned char p1x[3 * P1X_PLANE];
   __shared__ __attribute__((aligned(16))) float img[IMG];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int crop = blockIdx.x;
-  REC_STAMP(0);
   if (tid < IMG / 4) *reinterpret_cast<f32x4*>(img + tid * 4) = *reinterpret_cast<const f32x4*>(crops + (size_t)crop * IMG + tid * 4);
+  // conv2 coordinates and the first weights: requested before conv1 so that their L2 latency runs under it
+  const int r = lane & 15, q = lane >> 4;
+  const int rt = wave >> 2, ct = wave & 3;
+  const int slot = r >> 2, sub = r & 3;
+  const int pix0 = (2 * rt + (sub >> 1)) * 12 + 2 * slot + (sub & 1);      // window (py = rt, px = slot)
+  const uint4* wf = w2x + (size_t)ct * 3 * 64 + lane;                      // [tap][ct][plane][lane] 16 bytes
+  constexpr int DEPTH = 4;
+  uint4 ring[DEPTH][3];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) ring[d][pl] = wf[(size_t)(d * 4 * 3 + pl) * 64];
   float w1r[13];
 #pragma unroll
   for (int s = 0; s < 13; ++s) w1r[s] = w1f[s * 64 + lane];
   const float bias1 = b1[lane & 31];
   __syncthreads();
-  REC_STAMP(1);
   for (int tile = wave; tile < 18; tile += 16) {
     const int i = lane & 31, h = lane >> 5, j = lane & 31;
     const int wi = tile * 8 + (i >> 2);
@@ -237,104 +244,154 @@ __global__ __launch_bounds__(1024) void rec_conv_small_kernel(const float* __res
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(im[h ? o1 : o0], w1r[s], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      p1[p1_index(tile * 8 + 2 * g + h, j)] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias1;
+    for (int g = 0; g < 4; ++g) {
+      const float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias1;
+      const __bf16 vh = (__bf16)v;            // round to nearest even at every level: the remainders are exact in f32
+      const float r1 = v - (float)vh;
+      const __bf16 vm = (__bf16)r1;
+      const __bf16 vl = (__bf16)(r1 - (float)vm);
+      const int o = p1x_offset(tile * 8 + 2 * g + h, j);
+      *reinterpret_cast<__bf16*>(p1x + o) = vh;
+      *reinterpret_cast<__bf16*>(p1x + P1X_PLANE + o) = vm;
+      *reinterpret_cast<__bf16*>(p1x + 2 * P1X_PLANE + o) = vl;
+    }
   }
-  REC_STAMP(2);
   __syncthreads();
-  REC_STAMP(3);
-  // conv2: 16 x 16 x 4 MFMA, lane (row r = lane & 15, k slot q = lane >> 4)
-  const int r = lane & 15, q = lane >> 4;
-  const int rt = wave >> 2, ct = wave & 3;
-  const int slot = r >> 2, sub = r & 3;
-  const int pix0 = (2 * rt + (sub >> 1)) * 12 + 2 * slot + (sub & 1);      // window (py = rt, px = slot)
-  const int el = q >> 1, c16 = q & 1;                                      // element pair (el, el + 2) of chunk 2 g + c16
-  const f32x4* wf = reinterpret_cast<const f32x4*>(w2s) + ct * 2 * 64 + lane;  // [tap][ct][gpair][lane] float4
+  // conv2: one v_mfma_f32_16x16x32_bf16 group per tap; lane (row r, channels 8 q .. 8 q + 7)
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // a tap is 8 MFMAs = 320 cycles, an L2 round trip is longer: the weights of the next DEPTH taps are kept in flight
-  constexpr int DEPTH = 5;
-  f32x4 ring[DEPTH][2];
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    ring[d][0] = wf[(d * 4 * 2) * 64];
-    ring[d][1] = wf[(d * 4 * 2 + 1) * 64];
-  }
 #pragma unroll
   for (int tap = 0; tap < 25; ++tap) {
-    const f32x4 bc0 = ring[tap % DEPTH][0], bc1 = ring[tap % DEPTH][1];
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, ring[tap % DEPTH][0]), wm = __builtin_bit_cast(bf16x8, ring[tap % DEPTH][1]),
+                 wl = __builtin_bit_cast(bf16x8, ring[tap % DEPTH][2]);
     if (tap + DEPTH < 25) {
-      ring[tap % DEPTH][0] = wf[((tap + DEPTH) * 4 * 2) * 64];
-      ring[tap % DEPTH][1] = wf[((tap + DEPTH) * 4 * 2 + 1) * 64];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ring[tap % DEPTH][pl] = wf[(size_t)((tap + DEPTH) * 4 * 3 + pl) * 64];
     }
     const int ky = tap / 5, kx = tap - ky * 5;
     const int pix = pix0 + ky * 12 + kx;
-    const float* row = p1 + pix * P1_ROW;
-    const int sw = (pix >> 1) & 7;
-    f32x4 a[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) a[g] = *reinterpret_cast<const f32x4*>(row + (((2 * g + c16) ^ sw) << 2));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      // group g of eight input channels: instruction 0 multiplies k = (0,4,1,5) + 8 g, instruction 1 k = (2,6,3,7) + 8 g
-      const f32x4 bw = g < 2 ? bc0 : bc1;
-      const float a0 = el ? a[g][1] : a[g][0], a1 = el ? a[g][3] : a[g][2];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[2 * (g & 1)], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[2 * (g & 1) + 1], acc, 0, 0, 0);
-    }
+    const unsigned char* row = p1x + pix * 64 + ((q ^ ((pix >> 1) & 3)) << 4);
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(row), am = *reinterpret_cast<const bf16x8*>(row + P1X_PLANE),
+                 al = *reinterpret_cast<const bf16x8*>(row + 2 * P1X_PLANE);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc, 0, 0, 0);   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc, 0, 0, 0);
   }
-  REC_STAMP(4);
-  // C/D map of 16x16x4: column = lane & 15, rows 4 q .. 4 q + 3 in the four registers = window q of this tile.
-  // feat goes out in the operand order of rec_fc1_small_kernel (see there): k = co * 16 + p of crop `crop`
+  // C/D map of 16x16: column = lane & 15, rows 4 q .. 4 q + 3 in the four registers = window q of this tile.
+  // feat goes out in the operand order of the fc1 kernels: k = co * 16 + p of crop `crop`
   const int co = 16 * ct + r;
   const float v = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + b2[co];
   const int kk = co * 16 + 4 * rt + q;
-  feat[((((size_t)(crop >> 4) * 128 + (kk >> 3)) * 2 + ((kk >> 2) & 1)) * 16 + (crop & 15)) * 4 + (kk & 3)] = v;
-  REC_STAMP(5);
+  feat[((((size_t)(crop >> 4) * 64 + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * 16 + (crop & 15)) * 4 + (kk & 3)] = v;
 }
 
-// fc1 + bias + ReLU for small batches: wave = one 16 crops x 16 outputs tile over the whole K = 1024 as 256 dependent
-// v_mfma_f32_16x16x4_f32 in conv_igemm's k order (bit-identical to the large-batch GEMM).  Both operands are read in
-// OPERAND ORDER, [tile][group G of eight k][4 c16 + ...]: float index (((tile * 128 + G) * 2 + c16) * 16 + r) * 4 + e
-// holds element (row r of the tile, k = 8 G + 4 c16 + e) - a wave load is 512 contiguous bytes (rec_conv_small_kernel
-// writes feat that way, the host re-lays fc1.weight out).  grid (ceil(n / 16), 8), 4 waves = 64 output columns.
-__global__ __launch_bounds__(256) void rec_fc1_small_kernel(const float* __restrict__ feat_t, int n, const float* __restrict__ w_t,
-                                                            const float* __restrict__ bias, float* __restrict__ hid) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, q = lane >> 4, el = q >> 1, c16 = q & 1;
-  const int row0 = blockIdx.x * 16, ct = blockIdx.y * 4 + wave;
-  const f32x4* ap = reinterpret_cast<const f32x4*>(feat_t) + (size_t)blockIdx.x * 128 * 32 + c16 * 16 + r;
-  const f32x4* bp = reinterpret_cast<const f32x4*>(w_t) + (size_t)ct * 128 * 32 + c16 * 16 + r;
+// fc1 + bias + ReLU, K split over the waves: a workgroup = 16 crops x 64 outputs, wave (column tile ct = w & 3, K quarter
+// kq = w >> 2) accumulates 64 dependent v_mfma_f32_16x16x4_f32 (a 256-long chain cut in four);
+// the four partial tiles meet in LDS, summed in a fixed order.  grid (ceil(n / 16), 8), 1024 threads.
+__global__ __launch_bounds__(1024) void rec_fc1_ksplit_kernel(const float* __restrict__ feat_t, int n, const float* __restrict__ w_t,
+                                                              const float* __restrict__ bias, float* __restrict__ hid) {
+  __shared__ float part[4][16][65];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int ctw = wave & 3, kq = wave >> 2;
+  const int row0 = blockIdx.x * 16, ct = blockIdx.y * 4 + ctw;
+  // both operands in OPERAND ORDER [tile][g of sixteen k][q][r][e]: lane (r, q) of group g holds k = 16 g + 4 q + e in element
+  // e and multiplies it in its e-th instruction - every loaded byte is used, a wave load is 1 KB contiguous
+  const f32x4* ap = reinterpret_cast<const f32x4*>(feat_t) + ((size_t)blockIdx.x * 64 + 16 * kq) * 64 + lane;
+  const f32x4* bp = reinterpret_cast<const f32x4*>(w_t) + ((size_t)ct * 64 + 16 * kq) * 64 + lane;
+  f32x4 a[16], b[16];   // the whole K quarter in flight (128 registers), then the 64-long chain
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    a[u] = ap[u * 64];
+    b[u] = bp[u * 64];
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 8;  // groups in flight: 16 loads per lane ahead of their 16 MFMAs (640 cycles)
-  f32x4 a[2][U], b[2][U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    a[0][u] = ap[u * 32];
-    b[0][u] = bp[u * 32];
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[kq][4 * q + e][16 * ctw + r] = acc[e];
+  __syncthreads();
+  const int rr = tid >> 6, cc = tid & 63;
+  const int row = row0 + rr, col = blockIdx.y * 64 + cc;
+  const float v = (part[0][rr][cc] + part[1][rr][cc]) + (part[2][rr][cc] + part[3][rr][cc]) + bias[col];
+  if (row < n) hid[(size_t)row * 512 + col] = fmaxf(v, 0.f);
+}
+
+// fc2 + bias + softmax(f64) + top-1 for small batches: 16 crops per workgroup, wave (column tile ct = w & 3 of the 64 padded
+// columns, K quarter kq = w >> 2) runs a 32-long v_mfma_f32_16x16x4_f32 chain; partial tiles summed in LDS in a fixed
+// order; then 16 lanes per crop as in rec_fc2_softmax_kernel.  w2s: rec_fc2_small_fragments.
+__global__ __launch_bounds__(1024) void rec_fc2_small_kernel(const float* __restrict__ hid, int n, const float* __restrict__ w2s,
+                                                             const float* __restrict__ b2, float* __restrict__ logits_out,
+                                                             int32_t* __restrict__ labels, double* __restrict__ probs) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][68];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int ct = wave & 3, kq = wave >> 2;
+  const int m0 = blockIdx.x * 16;
+  {
+    const int row = min(m0 + r, n - 1);   // rows past the batch re-read the last crop (never stored)
+    // lane (r, q) of group g multiplies k = 128 kq + 16 g + 4 q + e in its e-th instruction (both operands alike)
+    const f32x4* ap = reinterpret_cast<const f32x4*>(hid + (size_t)row * 512 + 128 * kq + 4 * q);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(w2s) + ((size_t)(ct * 4 + kq) * 8) * 64 + lane;   // [ct][kq][g][lane] float4
+    f32x4 a[8], b[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      a[g] = ap[4 * g];
+      b[g] = bp[g * 64];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][e], b[g][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[kq][4 * q + e][16 * ct + r] = acc[e];
   }
+  __syncthreads();
+  if (tid >= 256) return;
+  const int rr = tid >> 4, l16 = tid & 15;  // crop row of the tile, its columns 4 l16 .. 4 l16 + 3
+  const int crop = m0 + rr;
+  f32x4 v = (*reinterpret_cast<const f32x4*>(&part[0][rr][4 * l16]) + *reinterpret_cast<const f32x4*>(&part[1][rr][4 * l16])) +
+            (*reinterpret_cast<const f32x4*>(&part[2][rr][4 * l16]) + *reinterpret_cast<const f32x4*>(&part[3][rr][4 * l16]));
+  v += *reinterpret_cast<const f32x4*>(b2 + 4 * l16);
+  if (l16 == 15) v[2] = v[3] = -INFINITY;  // columns 62, 63 are padding
+  if (crop < n && logits_out) {
 #pragma unroll
-  for (int g0 = 0; g0 < 128; g0 += U) {
-    const int cur = (g0 / U) & 1;
-    if (g0 + U < 128) {
+    for (int e = 0; e < 4; ++e)
+      if (4 * l16 + e < 62) logits_out[(size_t)crop * 62 + 4 * l16 + e] = v[e];
+  }
+  if (!labels && !probs) return;
+  float mx = v[0];  // first index of the maximum
+  int arg = 4 * l16;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        a[cur ^ 1][u] = ap[(g0 + U + u) * 32];
-        b[cur ^ 1][u] = bp[(g0 + U + u) * 32];
-      }
+  for (int e = 1; e < 4; ++e)
+    if (v[e] > mx) {
+      mx = v[e];
+      arg = 4 * l16 + e;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(el ? a[cur][u][1] : a[cur][u][0], el ? b[cur][u][1] : b[cur][u][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(el ? a[cur][u][3] : a[cur][u][2], el ? b[cur][u][3] : b[cur][u][2], acc, 0, 0, 0);
+  for (int k = 1; k <= 8; k <<= 1) {
+    const float ov = __shfl_xor(mx, k, 64);
+    const int oa = __shfl_xor(arg, k, 64);
+    if (ov > mx || (ov == mx && oa < arg)) {
+      mx = ov;
+      arg = oa;
     }
   }
-  const int col = 16 * ct + r;
-  const float bv = bias[col];
+  double e = 0.0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = row0 + 4 * q + e;
-    if (row < n) hid[(size_t)row * 512 + col] = fmaxf(acc[e] + bv, 0.f);
+  for (int c = 0; c < 4; ++c) e += exp((double)v[c] - (double)mx);  // exp(-inf) = 0 for the padding
+#pragma unroll
+  for (int k = 1; k <= 8; k <<= 1) e += __shfl_xor(e, k, 64);
+  if (l16 == 0 && crop < n) {
+    if (labels) labels[crop] = arg;
+    if (probs) probs[crop] = 1.0 / e;
   }
 }
 
@@ -420,9 +477,6 @@ __global__ __launch_bounds__(1024) void rec_fc2_softmax_kernel(const float* __re
 
 }  // namespace
 
-#ifdef REC_STAMPS
-void rec_read_stamps(long long* out) { OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rec_stamps), sizeof(g_rec_stamps))); }
-#endif
 
 // conv1 [32][1][5][5] -> [13 steps][64 lanes]: lane (j = l & 31, h = l >> 5) of step s holds w[j][k = 2 s + h] (0 for k = 25)
 std::vector<float> rec_conv1_fragments(const float* w) {
@@ -450,47 +504,75 @@ std::vector<float> rec_conv2_fragments(const float* w) {
   return f;
 }
 
-// conv2 [64][32][5][5] for the 16x16x4 form: [25 taps][4 ct][2 gpair][64 lanes][4]; lane (c = l & 15, q = l >> 4) of
-// group g = 2 gpair + (e >> 1) holds w[16 ct + c][ci][tap] for ci = 8 g + (q >> 1) + 4 (q & 1) + 2 (e & 1)
-std::vector<float> rec_conv2_small_fragments(const float* w) {
-  std::vector<float> f((size_t)25 * 4 * 2 * 64 * 4);
+// fc1.weight [512][1024] in the operand order of rec_fc1_ksplit_kernel: [32 column tiles][64 g][4 q][16 c][4 e] holds
+// w[16 ct + c][16 g + 4 q + e]
+std::vector<float> rec_fc1_small_weights(const float* w) {
+  std::vector<float> f((size_t)512 * 1024);
+  for (int ct = 0; ct < 32; ++ct)
+    for (int g = 0; g < 64; ++g)
+      for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < 16; ++c)
+          for (int e = 0; e < 4; ++e)
+            f[((((size_t)ct * 64 + g) * 4 + q) * 16 + c) * 4 + e] = w[(size_t)(16 * ct + c) * 1024 + 16 * g + 4 * q + e];
+  return f;
+}
+
+// conv2 [64][32][5][5] for the split-bf16 16x16x32 form: [25 taps][4 ct][3 planes hi / mid / lo][64 lanes][8 bf16]; lane
+// (c = l & 15, q = l >> 4) holds w[16 ct + c][ci = 8 q + j][tap] in element j
+std::vector<uint16_t> rec_conv2_small_x3_fragments(const float* w) {
+  auto bf = [](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  };
+  auto up = [](uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  std::vector<uint16_t> f((size_t)25 * 4 * 3 * 64 * 8);
   for (int tap = 0; tap < 25; ++tap)
     for (int ct = 0; ct < 4; ++ct)
-      for (int gp = 0; gp < 2; ++gp)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const float x = w[((size_t)(16 * ct + (l & 15)) * 32 + 8 * (l >> 4) + j) * 25 + tap];
+          const uint16_t h = bf(x);
+          const float r1 = x - up(h);
+          const uint16_t m = bf(r1);
+          const size_t o = ((((size_t)tap * 4 + ct) * 3) * 64 + l) * 8 + j;
+          f[o] = h;
+          f[o + 64 * 8] = m;
+          f[o + 2 * 64 * 8] = bf(r1 - up(m));
+        }
+  return f;
+}
+
+// fc2 [62][512] for rec_fc2_small_kernel: [4 ct][4 kq][8 g][64 lanes][4]; element e of lane (c = l & 15, q = l >> 4) is
+// w[16 ct + c][128 kq + 16 g + 4 q + e] (0 for rows 62, 63)
+std::vector<float> rec_fc2_small_fragments(const float* w) {
+  std::vector<float> f((size_t)4 * 4 * 8 * 64 * 4, 0.f);
+  for (int ct = 0; ct < 4; ++ct)
+    for (int kq = 0; kq < 4; ++kq)
+      for (int g = 0; g < 8; ++g)
         for (int l = 0; l < 64; ++l)
           for (int e = 0; e < 4; ++e) {
-            const int c = l & 15, q = l >> 4, g = 2 * gp + (e >> 1);
-            const int co = 16 * ct + c, ci = 8 * g + (q >> 1) + 4 * (q & 1) + 2 * (e & 1);
-            f[((((size_t)tap * 4 + ct) * 2 + gp) * 64 + l) * 4 + e] = w[((size_t)co * 32 + ci) * 25 + tap];
+            const int o = 16 * ct + (l & 15), k = 128 * kq + 16 * g + 4 * (l >> 4) + e;
+            if (o < 62) f[((((size_t)ct * 4 + kq) * 8 + g) * 64 + l) * 4 + e] = w[(size_t)o * 512 + k];
           }
   return f;
 }
 
-// fc1.weight [512][1024] in the operand order of rec_fc1_small_kernel: [32 column tiles][128 G][2 c16][16 c][4 e]
-std::vector<float> rec_fc1_small_weights(const float* w) {
-  std::vector<float> f((size_t)512 * 1024);
-  for (int ct = 0; ct < 32; ++ct)
-    for (int G = 0; G < 128; ++G)
-      for (int c16 = 0; c16 < 2; ++c16)
-        for (int c = 0; c < 16; ++c)
-          for (int e = 0; e < 4; ++e)
-            f[((((size_t)ct * 128 + G) * 2 + c16) * 16 + c) * 4 + e] = w[(size_t)(16 * ct + c) * 1024 + 8 * G + 4 * c16 + e];
-  return f;
+void launch_rec_small(const RecWeights& w, const float* crops, int n, float* feat, float* hid, float* logits, int32_t* labels,
+                      double* probs, hipStream_t s, int stage) {
+  if (n <= 0) return;
+  if (stage == 0) hipLaunchKernelGGL(rec_conv_small_x3_kernel, dim3(n), dim3(1024), 0, s, crops, n, w.c1f, w.c1b, static_cast<const uint4*>(w.c2x), w.c2b, feat);
+  else if (stage == 1) hipLaunchKernelGGL(rec_fc1_ksplit_kernel, dim3((n + 15) / 16, 8), dim3(1024), 0, s, feat, n, w.f1s, w.f1b, hid);
+  else if (logits || labels || probs) hipLaunchKernelGGL(rec_fc2_small_kernel, dim3((n + 15) / 16), dim3(1024), 0, s, hid, n, w.f2s, w.f2b, logits, labels, probs);
+  OCR_HIP(hipGetLastError());
 }
 
 constexpr int kRecSmallBatch = 1024;  // up to here the chain-latency-optimised kernels; beyond, the throughput ones
-
-void launch_rec_conv_small(const RecWeights& w, const float* crops, int n, float* feat, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(rec_conv_small_kernel, dim3(n), dim3(1024), 0, s, crops, n, w.c1f, w.c1b, w.c2s, w.c2b, feat);
-  OCR_HIP(hipGetLastError());
-}
-
-void launch_rec_fc1_small(const RecWeights& w, const float* feat, int n, float* hid, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(rec_fc1_small_kernel, dim3((n + 15) / 16, 8), dim3(256), 0, s, feat, n, w.f1s, w.f1b, hid);
-  OCR_HIP(hipGetLastError());
-}
 
 bool rec_small_batch(int n) { return n <= kRecSmallBatch; }
 

@@ -13,9 +13,6 @@ namespace ocr { void winograd43_set_debug(int d); }
 #ifdef W43_STAMPS
 namespace ocr { void winograd43_read_stamps(long long* out); }
 #endif
-#ifdef REC_STAMPS
-namespace ocr { void rec_read_stamps(long long* out); }
-#endif
 #ifdef WS_STAMPS
 #endif
 
@@ -387,9 +384,6 @@ int ocr_test_comm_assemble(const ocr_polygons_t* const* shards, int world, ocr_p
 
 #ifdef W43_STAMPS
 int ocr_test_w43_stamps(long long* out) { ocr::winograd43_read_stamps(out); return 0; }
-#endif
-#ifdef REC_STAMPS
-int ocr_test_rec_stamps(long long* out) { ocr::rec_read_stamps(out); return 0; }
 #endif
 int ocr_test_w43_debug(int d) { ocr::winograd43_set_debug(d); return 0; }
 #ifdef WS_STAMPS

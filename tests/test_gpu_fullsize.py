@@ -93,9 +93,14 @@ def test_config2_recognition_4096_crops():
     srt = np.sort(ref, axis=1)
     decided = (srt[:, -1] - srt[:, -2]) > 1e-3
     assert (labels[sub][decided] == rl[decided]).all()
-    # size-independent: a crop's result does not depend on the batch around it
-    l2, p2 = rec.classify_host(crops[100:101])
-    assert l2[0] == labels[100] and p2[0] == probs[100]
+    # size-independent: a crop's result does not depend on the batch around it - bit for bit inside the small-batch kernels
+    # (one crop per workgroup, fixed summation orders), to rounding between batches that take different tile shapes
+    l2, p2 = rec.classify_host(crops[1100:3100])                  # another large batch holding crop 1200
+    assert l2[100] == labels[1200] and abs(p2[100] - probs[1200]) < 1e-6
+    l3, p3 = rec.classify_host(crops[100:101])                    # the small path, alone ...
+    l4, p4 = rec.classify_host(crops[40:296])                     # ... and inside a configs[2]-sized batch
+    assert l3[0] == l4[60] and p3[0] == p4[60]
+    assert l3[0] == labels[100] and abs(p3[0] - probs[100]) < 1e-6
     assert np.array_equal(np.argmax(logits, axis=1).astype(np.int32), labels)
     rec.close()
 
@@ -103,7 +108,8 @@ def test_config2_recognition_4096_crops():
 def test_recognition_large_batch_chunks_and_batch_independence():
     """65 536 + 19 crops: two passes of the recogniser's workspace (Recognizer::kChunk), the last one ragged.
     Size-independent property: a crop's label and probability do not depend on the batch around it (every dot
-    product is one k-ordered f32 FMA chain whatever the tile shape) - checked at the chunk seam and the tail."""
+    product of the large-batch kernels is one k-ordered f32 FMA chain whatever the tile shape) - checked at the chunk seam
+    and the tail against other large batches, and to rounding against the small-batch kernels."""
     import torch
     rw = W.make_rec_weights(0)
     rec = capi.Recognizer(W.pack_blob(rw), 0)
@@ -119,9 +125,12 @@ def test_recognition_large_batch_chunks_and_batch_independence():
     labels, probs, logits = labels.cpu().numpy(), probs.cpu().numpy(), logits.cpu().numpy()
     assert np.array_equal(np.argmax(logits, axis=1).astype(np.int32), labels)
     assert np.all((probs > 1.0 / 62 - 1e-12) & (probs <= 1.0))
-    for i in (0, 65535, 65536, 65537, n - 1):
-        l1, p1 = rec.classify_host(crops[i:i + 1])
-        assert l1[0] == labels[i] and p1[0] == probs[i]
+    for i in (0, 65535, 65536, n - 1):
+        lo = min(max(i - 1500, 0), n - 3000)
+        l1, p1 = rec.classify_host(crops[lo:lo + 3000])           # a different large batch around crop i
+        assert l1[i - lo] == labels[i] and abs(p1[i - lo] - probs[i]) < 1e-6
+        l1, p1 = rec.classify_host(crops[i:i + 1])                # the small-batch kernels: same label, probability to rounding
+        assert l1[0] == labels[i] and abs(p1[0] - probs[i]) < 1e-6
     sub = np.r_[np.arange(0, n, 997), np.arange(65530, 65545)]
     ref = T.rec_forward(rw, crops[sub])
     assert np.abs(logits[sub] - ref).max() < TOL

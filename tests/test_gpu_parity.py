@@ -310,7 +310,7 @@ def test_rec_device_path_guards_and_profile(rec, rec_w):
     prof = rec.classify_profile(d.data_ptr(), n, labels.data_ptr(), probs.data_ptr())
     rec.synchronize()
     names = [p[0] for p in prof]
-    assert names == ["rec_conv_small", "rec_fc1_small", "rec_fc2_softmax_top1"]     # n <= 1024: the chain-latency kernels
+    assert names == ["rec_conv_small_x3", "rec_fc1_ksplit", "rec_fc2_small_softmax_top1"]     # n <= 1024: the latency kernels
     big = rec.classify_profile(torch.from_numpy(W.synth_crops(6, 2000)).cuda().data_ptr(), 2000)
     assert [p[0] for p in big] == ["rec_conv<2>", "rec_fc1", "rec_fc2_softmax_top1"]
     assert all(ms > 0 for _, ms, _, _ in prof)
