@@ -12,7 +12,12 @@ set -o pipefail
 O=$PWD/gpurun_out/${1:-r03/final}
 mkdir -p $O
 export TMPDIR=/tmp
+python3 -c "import bench; print(bench.csrc_hash())" > $O/csrc_sha.txt   # the kernel sources these passes ran (stamps profiles/pmc.json)
 rocprofv3 --kernel-trace --stats -d $O/stats -o t -- python3 bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err || exit 1
+# the same with the headline loop and the roofline passes only: every detector launch is a batch-32 forward, so the
+# average duration per kernel is the one bench.py's HIP events report (the full command also runs 8-frame pieces for the
+# host-memory rates and other weights, which share kernel names)
+rocprofv3 --kernel-trace --stats -d $O/stats_headline -o t -- python3 bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_headline.json 2> /dev/null || exit 1
 echo "bench under rocprof done"
 for P in f32 bf16; do
   OPT=""; [ $P = bf16 ] && OPT="precision=bf16"

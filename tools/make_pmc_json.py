@@ -110,7 +110,9 @@ mf32 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_F32")))
 mbf16 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_BF16")))
 busy = per_label(second_half(load(d_busy, "SQ_VALU_MFMA_BUSY_CYCLES")))
 gui = per_label(second_half(load(d_busy, "GRBM_GUI_ACTIVE")))
-entry = {"batch": 32, "size": 640, "csrc_sha": bench.csrc_hash(),
+sha_file = os.path.join(os.path.dirname(os.path.abspath(d_fetch)), "csrc_sha.txt")   # written on the GPU box by collect_profiles.sh
+csrc_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else bench.csrc_hash()
+entry = {"batch": 32, "size": 640, "csrc_sha": csrc_sha,
          "source": f"rocprofv3 --pmc, one counter set per pass over tools/profile_layers.py 32 640 1 ({dtype}); profiles/{tag}_pmc_{dtype}.csv",
          "kernels": {}}
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{dtype}.csv"), "w") as fcsv:
