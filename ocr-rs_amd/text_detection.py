@@ -46,6 +46,8 @@ class FuncT:
         if isinstance(xs, np.ndarray):
             if xs.ndim != 4 or xs.shape[1] != 1:
                 raise capi.OcrError(1, f"expected N x 1 x H x W, got {xs.shape}")
+            if xs.dtype == np.uint8:     # the reference's GrayImage bytes (image_ops.rs:350-364): converted inside the first kernel
+                return self._det.forward_host_u8(xs)
             return self._det.forward_host(xs)
         import torch
         if not (xs.is_cuda and xs.dtype == torch.float32 and xs.is_contiguous() and xs.dim() == 4 and xs.shape[1] == 1):
