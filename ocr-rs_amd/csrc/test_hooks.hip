@@ -227,12 +227,15 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
 // one 3x3 s1 p1 conv (+ scale / bias / residual / ReLU) through the Winograd F(2x2,3x3) path on caller data:
 // weight transform, input transform, batched 16-problem GEMM, output transform.  x: NHWC, wgt: [cout][9][cin].
 int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, int cin, const float* wgt, int cout,
-                           const float* scale, const float* bias, const float* residual, int relu, int unfused, float* out) {
+                           const float* scale, const float* bias, const float* residual, int relu, int unfused_and_cus, float* out) {
   return guard([&] {
+    int unfused = unfused_and_cus;
     using namespace ocr;
     if (!det || !x || !wgt || !out) fail(OCR_ERR_INVALID, "null argument");
     OCR_HIP(hipSetDevice(det->impl.device()));
     hipStream_t s = det->impl.stream();
+    const int num_cus = unfused >> 8;   // optional, for the fused kernel's grid
+    unfused &= 0xff;
     const size_t wm = unfused >= 3 ? 4 : 2, wa = (wm + 2) * (wm + 2);   // unfused: 1 = F(2x2,3x3), 3 = F(4x4,3x3), both unfused; 4 = the fused F(4x4,3x3) kernel
     const size_t th = (h + wm - 1) / wm, tw = (w + wm - 1) / wm, T = (size_t)n * th * tw;
     const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
@@ -254,9 +257,9 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     const float* d_sc = scale ? dev(scale, cout) : nullptr;
     const float* d_bi = bias ? dev(bias, cout) : nullptr;
     const float* d_res = residual ? dev(residual, out_e) : nullptr;
-    if (unfused == 4) {  // fused F(4x4,3x3)
+    if (unfused == 4) {  // fused F(4x4,3x3); num_cus sizes its persistent grid (two workgroups per CU)
       float* d_uf = dev(winograd43_fragments(u, cout, cin).data(), u.size());
-      launch_winograd43_fused(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, 256, s);
+      launch_winograd43_fused(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, num_cus > 0 ? num_cus : 256, s);
       OCR_HIP(hipStreamSynchronize(s));
       OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
       return;

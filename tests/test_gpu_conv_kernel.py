@@ -268,6 +268,21 @@ def test_winograd43_fused_conv_matches_aten(det, case):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("num_cus", [1, 5, 37, 100, 304])
+def test_winograd43_fused_any_grid_size(det, num_cus):
+    """The fused kernel's persistent grid is 2 x num_cus workgroups (multiProcessorCount of the device: a partitioned or
+    differently sized part gives another number): whatever the grid - fewer workgroups than XCDs, not a multiple of
+    eight, more than there are blocks - every block is computed exactly once."""
+    rng = np.random.default_rng(num_cus)
+    for n, h, w, cin, cout in ((3, 40, 56, 64, 64), (2, 24, 40, 128, 128)):
+        x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
+        wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+        res = rng.standard_normal((n, h, w, cout), dtype=np.float32)
+        got = det.debug_winograd_conv(x, wg, None, None, res, True, unfused=4 | (num_cus << 8))
+        ref, _ = _ref(x, wg, 1, None, None, res, None, True)
+        assert float(np.abs(got - ref).max()) / (float(np.abs(ref).max()) + 1e-12) < 1e-4
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 9, 21), (3, 1, 1), (2, 160, 160), (1, 8, 16), (5, 24, 40), (1, 64, 272)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("has_res,relu,bn", [(True, True, True), (False, False, False), (True, False, True)])

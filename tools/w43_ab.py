@@ -1,5 +1,8 @@
-"""A/B of the fused F(4x4,3x3) kernel's block order in ONE process (devices differ by several per cent): XCD-contiguous
-runs against the plain linear order, alternating forwards.  python3 tools/w43_ab.py [rounds]"""
+"""A/B of the fused F(4x4,3x3) kernel in ONE process (devices differ by several per cent), alternating forwards over
+settings of the test hook's word: 0 = shipped (XCD-contiguous runs), 16 = plain linear block order.
+python3 tools/w43_ab.py [rounds] [word ...]
+(Round 3 also tried starting the second half of the grid 8 k ... 65 k cycles late, so that the two workgroups of a CU run
+out of phase: 0.2142 -> 0.2143 / 0.2163 / 0.2186 / 0.2233 ms - the delay is only partly won back, removed.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,9 +13,10 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)
 x = torch.from_numpy(W.synth_image_batch(1, 32, 640, 640)).cuda()
 prob = torch.empty_like(x)
-acc = {0: {}, 16: {}}
+VARIANTS = [int(v, 0) for v in sys.argv[2:]] or [0, 16]
+acc = {v: {} for v in VARIANTS}
 for r in range(rounds + 1):
-    for dbg in (0, 16):
+    for dbg in VARIANTS:
         capi.test_lib().ocr_test_w43_debug(dbg)
         for nm, ms, fl, by in det.forward_profile(x.data_ptr(), 32, 640, 640, prob.data_ptr()):
             if r and "winograd43_fused" in nm:
@@ -20,6 +24,5 @@ for r in range(rounds + 1):
                 e[0] += ms
                 e[1] += 1
 capi.test_lib().ocr_test_w43_debug(0)
-for nm in acc[0]:
-    a, b = acc[0][nm], acc[16][nm]
-    print(f"{nm:28s} xcd runs {a[0] / a[1]:.4f} ms   linear {b[0] / b[1]:.4f} ms   ({a[1]} launches each)")
+for nm in acc[VARIANTS[0]]:
+    print(f"{nm:28s} " + "   ".join(f"[{v:#x}] {acc[v][nm][0] / acc[v][nm][1]:.4f} ms" for v in VARIANTS))
