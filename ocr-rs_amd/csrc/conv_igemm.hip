@@ -141,6 +141,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// f(integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+
 [[maybe_unused]] constexpr int ROWB = 128;                 // bytes of K per LDS row (one cache line): 32 f32 or 64 bf16
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;     // voffset beyond any tensor (< 2^31 bytes): reads as zero
 
@@ -472,19 +481,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         f.al[e] = (__bf16)r2;
       }
     };
-    // six of the nine partial products of column tile j (mid.lo, lo.mid, lo.lo are below 2^-23 of the product), small terms first
-    auto mfma6 = [&](const Frag& f, int j) {
-      if (IGEMM_DBG(p, 8)) {
-        asm volatile("" ::"v"(f.al), "v"(f.ah), "v"(f.am), "v"(f.bh[j]), "v"(f.bm[j]), "v"(f.bl[j]));
-        return;
-      }
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am, f.bm[j], acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am, f.bh[j], acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bm[j], acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[0][j], 0, 0, 0);
-    };
+    // six of the nine partial products per column tile (mid.lo, lo.mid, lo.lo are below 2^-23 of the product): mfma_at below
     // total K-steps and the DMA iterator
     int total = 0;
     if constexpr (SRC == SRC_PYR4) {
@@ -549,6 +546,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       }
     };
     constexpr int NP = AI + 3 * BSUB;   // DMA instructions per wave and step: A row groups, then B planes
+    static_assert(NP == 10 || NP == 7, "the hand-counted s_waitcnt vmcnt values assume 128 x 128 or 128 x 64 tiles");
     auto dma_piece = [&](int stage, auto piece_c) {
       constexpr int P = decltype(piece_c)::value;
       if constexpr (P < AI) {
@@ -574,98 +572,103 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         dma_piece(stage, std::integral_constant<int, 9>{});
       }
     };
-    // one MFMA group (six per column tile) with, behind each column tile, its share of the next fragment's split and (phase 2)
-    // of the DMA instructions: the matrix pipe works on the tile just issued while the wave issues them
-    auto phase = [&](const Frag& cur, const Raw& nraw, Frag& nxt, int dma_stage) {   // dma_stage < 0: no DMA in this phase
-      if constexpr (NT == 2) {
-        mfma6(cur, 0);
-        split_part(nraw, nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        for (int i = 0; i < 4; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma_stage >= 0) {
-          dma_piece(dma_stage, std::integral_constant<int, 0>{});
-          dma_piece(dma_stage, std::integral_constant<int, 1>{});
-          dma_piece(dma_stage, std::integral_constant<int, 2>{});
-          dma_piece(dma_stage, std::integral_constant<int, 3>{});
-        }
-        mfma6(cur, 1);
-        split_part(nraw, nxt, std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        for (int i = 0; i < 4; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma_stage >= 0) {
-          dma_piece(dma_stage, std::integral_constant<int, 4>{});
-          dma_piece(dma_stage, std::integral_constant<int, 5>{});
-          dma_piece(dma_stage, std::integral_constant<int, 6>{});
-        }
-      } else {
-        static_assert(NT == 4 && NP == 10, "phase(): NT is 2 or 4");
-        mfma6(cur, 0);
-        split_part(nraw, nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma_stage >= 0) {
-          dma_piece(dma_stage, std::integral_constant<int, 0>{});
-          dma_piece(dma_stage, std::integral_constant<int, 1>{});
-          dma_piece(dma_stage, std::integral_constant<int, 2>{});
-        }
-        mfma6(cur, 1);
-        split_part(nraw, nxt, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma_stage >= 0) {
-          dma_piece(dma_stage, std::integral_constant<int, 3>{});
-          dma_piece(dma_stage, std::integral_constant<int, 4>{});
-        }
-        mfma6(cur, 2);
-        split_part(nraw, nxt, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma_stage >= 0) {
-          dma_piece(dma_stage, std::integral_constant<int, 5>{});
-          dma_piece(dma_stage, std::integral_constant<int, 6>{});
-          dma_piece(dma_stage, std::integral_constant<int, 7>{});
-        }
-        mfma6(cur, 3);
-        split_part(nraw, nxt, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma_stage >= 0) {
-          dma_piece(dma_stage, std::integral_constant<int, 8>{});
-          dma_piece(dma_stage, std::integral_constant<int, 9>{});
-        }
+    // product pr (0..5, small terms first) of column tile j, as MFMA number idx = NT * pr + j of a group: consecutive
+    // MFMAs of a wave go to DIFFERENT accumulators (a dependent MFMA issued back to back waits for its predecessor's
+    // result; per accumulator the order of the six products is unchanged, so the sums are bit-identical either way)
+    auto mfma_at = [&](const Frag& f, auto idx_c) {
+      constexpr int idx = decltype(idx_c)::value, j = idx % NT, pr = idx / NT;
+      if (IGEMM_DBG(p, 8)) {
+        asm volatile("" ::"v"(f.al), "v"(f.ah), "v"(f.am), "v"(f.bh[j]), "v"(f.bm[j]), "v"(f.bl[j]));
+        return;
       }
+      if constexpr (pr == 0) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[0][j], 0, 0, 0);
+      if constexpr (pr == 1) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[0][j], 0, 0, 0);
+      if constexpr (pr == 2) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am, f.bm[j], acc[0][j], 0, 0, 0);
+      if constexpr (pr == 3) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am, f.bh[j], acc[0][j], 0, 0, 0);
+      if constexpr (pr == 4) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bm[j], acc[0][j], 0, 0, 0);
+      if constexpr (pr == 5) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[0][j], 0, 0, 0);
     };
-#ifdef IGEMM_DEBUG
-    if (IGEMM_DBG(p, 16) && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) __builtin_amdgcn_s_sleep(12);  // stagger the two workgroups of a CU
+    // One MFMA group = 6 NT MFMAs in four regions of 6 NT / 4; the other work of the wave is dealt out BETWEEN the MFMAs
+    // (an MFMA keeps the matrix pipe busy for 32 cycles - room for ~7 other instructions of the same wave):
+    //   region 0: the LDS reads of the next group's fragments (issued at its start, landing under its MFMAs)
+    //   regions 1..3: the split of the next A fragment, a few VALU behind every MFMA
+    //   region ends (phase 2 only): this wave's DMA instructions of the step after next
+    // (the empty asm statements pin the split to its region: without them the compiler sinks the whole split - pure
+    // arithmetic - to its first use behind the barrier, where no MFMA of this wave covers it)
+    auto phase = [&](const Frag& cur, int rd_stage, int rd_kk, Raw& nraw, Frag& nxt, int dma_stage) {   // dma_stage < 0: no DMA in this phase
+      constexpr int Q = 6 * NT / 4;   // MFMAs per region
+      constexpr int D1 = NP == 10 ? 3 : 2, D2 = NP == 10 ? 6 : 4, D3 = NP == 10 ? 8 : 6;
+      constexpr int E1 = NT == 4 ? 4 : 3;   // split elements per region: [0, E1), [E1, 6), [6, 8) (NT = 4: whole cvt_pk pairs)
+      read_frag(rd_stage, rd_kk, nraw, nxt);
+      static_for<0, Q>([&](auto i) { mfma_at(cur, i); });
+      for (int i = 0; i < Q; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma_stage >= 0) static_for<0, D1>([&](auto i) { dma_piece(dma_stage, i); });
+      asm volatile("" : "+v"(nraw.a0), "+v"(nraw.a1));
+      static_for<Q, 2 * Q>([&](auto i) { mfma_at(cur, i); });
+      split_part(nraw, nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, E1>{});
+      asm volatile("" : "+v"(nxt.ah), "+v"(nxt.am), "+v"(nxt.al));
+      for (int i = 0; i < Q; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NT == 4 ? 4 : 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma_stage >= 0) static_for<D1, D2>([&](auto i) { dma_piece(dma_stage, i); });
+      asm volatile("" : "+v"(nraw.a0), "+v"(nraw.a1));
+      static_for<2 * Q, 3 * Q>([&](auto i) { mfma_at(cur, i); });
+      split_part(nraw, nxt, std::integral_constant<int, E1>{}, std::integral_constant<int, 6>{});
+      asm volatile("" : "+v"(nxt.ah), "+v"(nxt.am), "+v"(nxt.al));
+      for (int i = 0; i < Q; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NT == 4 ? 2 : 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma_stage >= 0) static_for<D2, D3>([&](auto i) { dma_piece(dma_stage, i); });
+      asm volatile("" : "+v"(nraw.a1));
+      static_for<3 * Q, 4 * Q>([&](auto i) { mfma_at(cur, i); });
+      split_part(nraw, nxt, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+      asm volatile("" : "+v"(nxt.ah), "+v"(nxt.am), "+v"(nxt.al));
+      for (int i = 0; i < Q; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NT == 4 ? 2 : 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma_stage >= 0) static_for<D3, NP>([&](auto i) { dma_piece(dma_stage, i); });
+    };
+#ifdef IGEMM_STAGGER   // experiment: the second workgroup of a CU (odd wave slot) starts IGEMM_STAGGER x 8 k cycles late
+    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)
+      for (int i = 0; i < IGEMM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
+    // the first two steps are requested back to back; the loop starts as soon as the first has landed
     select_next();
     dma_all(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     if (total > 1) {
       select_next();
       dma_all(1);
+      if constexpr (NP == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
     Frag fx = {}, fy = {};
     Raw rw = {};
     read_frag(0, 0, rw, fx);
     split_part(rw, fx, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
     if (IGEMM_DBG(p, 256)) total = 1;
     for (int k = 0; k < total; ++k) {
-      read_frag(par, 1, rw, fy);
-      phase(fx, rw, fy, -1);
+      phase(fx, par, 1, rw, fy, -1);
       // this wave's reads of stage par are complete and its share of DMA k+1 has landed; after the barrier so is everyone's
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (IGEMM_DBG(p, 512)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (timing only: does not wait for the DMA)
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       if (!IGEMM_DBG(p, 64)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const bool more = k + 2 < total;
       if (more) select_next();
-      read_frag(par ^ 1, 0, rw, fx);   // (after the last step: reads of a stale stage, never used)
-      phase(fy, rw, fx, more ? par : -1);
+      phase(fy, par ^ 1, 0, rw, fx, more ? par : -1);   // (after the last step: reads of a stale stage, never used)
       par ^= 1;
     }
     __syncthreads();
@@ -719,34 +722,44 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   if (STORE == STORE_NHWC && sizeof(TO) == 4 && !p.out2) {
     const int colq = lane & 31;
     const int rowq = (lane >> 5) * 4;
-    const bool full_tile = m0 + BM <= p.M;
+    {
+      // buffer stores relative to this wave's corner of the output: per store only accumulator read, scale / bias, ReLU
+      // and one address add (row index x row bytes, a scalar); the column tile is an immediate; rows beyond M fall outside
+      // the descriptor's range and are dropped by the hardware.  (A 64-bit index, a compare and an exec mask per store -
+      // the first form of this loop - cost a third of the run time of the K = 256 Winograd GEMMs.)
+      const unsigned row_b = (unsigned)p.Cout * 4u;
+      const int r0 = m0 + wm * WM;
+      const int rows = min(max(p.M - r0, 0), WM);
+      const size_t corner = ((size_t)bz * p.M + r0) * p.Cout + (n0 + wn * WN);
+      const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(static_cast<float*>(p.out) + corner), 0,
+                                                            __builtin_amdgcn_readfirstlane((int)(rows * row_b)), 0x00020000);
+      const size_t rcorner = (size_t)r0 * p.Cout + (n0 + wn * WN);
+      const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(static_cast<const float*>(p.residual ? p.residual : p.out) + (p.residual ? rcorner : corner)), 0,
+                                                            __builtin_amdgcn_readfirstlane((int)(rows * row_b)), 0x00020000);
+      const unsigned voff = (unsigned)rowq * row_b + (unsigned)colq * 4u;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + wn * WN + j * 32 + colq;
-      const float sc = p.scale ? p.scale[col] : 1.f;
-      const float bi = p.bias ? p.bias[col] : 0.f;
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * WN + j * 32 + colq;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float bi = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int mbase = m0 + wm * WM + i * 32 + rowq;
-        float res[16];
-        if (p.residual) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = min(mbase + (e & 3) + 8 * (e >> 2), p.M - 1);
-            res[e] = Elem<TO>::load1(p.residual, (size_t)m * p.Cout + col);
-          }
-        } else {
+        for (int i = 0; i < MT; ++i) {
+          float res[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) res[e] = 0.f;
-        }
+          if (p.residual) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + (e & 3) + 8 * (e >> 2);
-          float v = acc[i][j][e] * sc + bi + res[e];
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (full_tile || m < p.M) Elem<TO>::store1(p.out, ((size_t)bz * p.M + m) * p.Cout + col, v);
+            for (int e = 0; e < 16; ++e)
+              res[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * row_b + j * 128, 0, 0));
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] * sc + bi + res[e];
+            if (p.relu) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, voff + (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * row_b + j * 128, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile at a time: keeps the residual staging at 16 registers
         }
-        __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile at a time: keeps the residual staging at 16 registers
       }
     }
     return;
