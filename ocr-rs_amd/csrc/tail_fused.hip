@@ -61,6 +61,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // X3 (TI = float): the f32 head on the bf16 matrix cores - pixels stay f32 in HBM / LDS and are split into three bf16 terms in
 // registers once per workgroup (the four taps share them), the weights arrive as three bf16 planes (split3_weights of
 // [4 taps][64 co][64 ci]); six partial products per pair, f32 accumulate: 48 MFMAs of 32 cycles per tap instead of 64 of 64.
+// f(integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+
 template <typename TI, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -155,6 +164,110 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
     }
     __syncthreads();   // every wave has its pixels in registers: their LDS rows become weight buffer 1
   }
+  if constexpr (X3) {
+    // Software-pipelined over the four taps: the MFMAs of tap t (48 of 32 cycles, the two channel halves as ALTERNATING
+    // accumulator chains - a dependent MFMA issued back to back waits for its predecessor) carry the epilogue of tap t - 1
+    // (bias / bin_bn2 / ReLU / bin_conv_tr2 / sigmoid: ~230 VALU and 48 LDS reads per lane) between them; two accumulator
+    // sets alternate.  The empty asm statements pin that epilogue to its region (the compiler would otherwise sink it to
+    // the stores at the end of the kernel, where no MFMA covers it).
+    f32x16 accs[2][2];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 wfr[2][2][3];     // [buffer][channel half][hi, mid, lo]: weight fragments of a 16-channel group
+    f32x4 svq[2], bvq[2], w2e[8];
+    auto load_w = [&](auto t_c, auto kk_c) {
+      constexpr int t = decltype(t_c)::value, kk = decltype(kk_c)::value, buf = kk & 1;
+      const float* wb = Ws + (t & 1) * W_STRIDE;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const float* wr = wb + (32 * ct + frow) * 32 + xoff[kk];   // chunk 2 kk + half of the 64-channel bf16 row
+        wfr[buf][ct][0] = *reinterpret_cast<const bf16x8*>(wr);
+        wfr[buf][ct][1] = *reinterpret_cast<const bf16x8*>(wr + 64 * 32);
+        wfr[buf][ct][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * 64 * 32);
+      }
+    };
+    // MFMA idx (0..11) of 16-channel group kk: product idx / 2 (small terms first: mid.lo, lo.mid, lo.lo are below 2^-23
+    // of the product) of channel half idx % 2 - consecutive MFMAs go to different accumulators, per accumulator the order
+    // is the one of the un-pipelined form (bit-identical sums)
+    auto mfma_one = [&](auto t_c, auto kk_c, auto idx_c) {
+      constexpr int t = decltype(t_c)::value, kk = decltype(kk_c)::value, idx = decltype(idx_c)::value;
+      constexpr int ct = idx & 1, pr = idx >> 1, buf = kk & 1;
+      constexpr int wsel = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0;
+      if constexpr (pr == 1) accs[t & 1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[buf][ct][wsel], pxl[kk], accs[t & 1][ct], 0, 0, 0);
+      else if constexpr (pr == 2 || pr == 4) accs[t & 1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[buf][ct][wsel], pxm[kk], accs[t & 1][ct], 0, 0, 0);
+      else accs[t & 1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[buf][ct][wsel], pxh[kk], accs[t & 1][ct], 0, 0, 0);
+    };
+    // epilogue of tap t in 32 elements: quarter s4 = (ct, q pair), element j = 4 qq + r4 of the quarter; channel
+    // co = 32 ct + (e&3) + 8 (e>>2) + 4 half with e = 4 q + r4; accs[t & 1][ct][e] = Z_t^T[co][pixel = lane&31]
+    auto finish_reads = [&](auto t_c, auto s4_c, auto first_c) {   // the LDS operands of quarter s4: first / second half of them
+      constexpr int t = decltype(t_c)::value, s4 = decltype(s4_c)::value, first = decltype(first_c)::value, ct = s4 >> 1;
+      if constexpr (first) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int co0 = t * 64 + 32 * ct + 8 * (2 * (s4 & 1) + qq) + 4 * half;
+          svq[qq] = *reinterpret_cast<const f32x4*>(&tab_s[co0]);   // folded bias / bin_bn2 of this tap
+          bvq[qq] = *reinterpret_cast<const f32x4*>(&tab_b[co0]);
+        }
+      }
+      static_for<(first ? 0 : 4), (first ? 4 : 8)>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value, e = 4 * (2 * (s4 & 1) + (j >> 2)) + (j & 3);
+        w2e[j] = *reinterpret_cast<const f32x4*>(&tab_w2[(32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half) * 4]);
+      });
+    };
+    auto finish_elem = [&](auto t_c, auto s4_c, auto j_c) {
+      constexpr int t = decltype(t_c)::value, s4 = decltype(s4_c)::value, j = decltype(j_c)::value;
+      constexpr int ct = s4 >> 1, qq = j >> 2, r4 = j & 3, e = 4 * (2 * (s4 & 1) + qq) + r4;
+      const float z = fmaxf(accs[t & 1][ct][e] * svq[qq][r4] + bvq[qq][r4], 0.f);  // + bias, bin_bn2, ReLU
+#pragma unroll
+      for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2e[j][u], part[u]);
+    };
+    auto finish_end = [&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float sm = part[u] + __shfl_xor(part[u], 32, 64) + p.bias2;  // the other half holds the other 32 channels
+        o[t][u] = 1.0f / (1.0f + expf(-sm));
+        part[u] = 0.f;
+      }
+    };
+    using std::integral_constant;
+    // one slice = one MFMA of tap t plus its share of the epilogue of tap t - 1; nothing moves across a slice boundary
+    static_for<0, 4>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      if constexpr (t + 1 < 4) issue_w(t + 1, (t + 1) & 1);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[t & 1][ct][e] = 0.f;
+      load_w(t_c, integral_constant<int, 0>{});
+      static_for<0, 4>([&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        static_for<0, 12>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          mfma_one(t_c, kk_c, i_c);
+          if constexpr (t > 0) {
+            constexpr integral_constant<int, (t > 0 ? t - 1 : 0)> tp{};
+            if constexpr (i == 0) finish_reads(tp, kk_c, integral_constant<int, 1>{});
+            if constexpr (i == 1) finish_reads(tp, kk_c, integral_constant<int, 0>{});
+            if constexpr (i >= 2 && i < 10) finish_elem(tp, kk_c, integral_constant<int, (i >= 2 && i < 10 ? i - 2 : 0)>{});
+            if constexpr (i == 11 && kk == 3) finish_end(tp);
+          }
+          if constexpr (i == 10 && kk < 3) load_w(t_c, integral_constant<int, (kk < 3 ? kk + 1 : 0)>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      if constexpr (t + 1 < 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    });
+    static_for<0, 4>([&](auto s4_c) {
+      constexpr integral_constant<int, 3> t3{};
+      finish_reads(t3, s4_c, integral_constant<int, 1>{});
+      finish_reads(t3, s4_c, integral_constant<int, 0>{});
+      static_for<0, 8>([&](auto j_c) { finish_elem(t3, s4_c, j_c); });
+    });
+    finish_end(integral_constant<int, 3>{});
+  } else {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t + 1 < 4) issue_w(t + 1, (t + 1) & 1);
@@ -235,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+  }
   }
   // pixel (n,i,j) owns prob[n][4i .. 4i+3][4j .. 4j+3]: row 2a+c', column 2b+d' = o[a*2+b][c'*2+d'].
   // Lanes 0-31 write rows 0,1, lanes 32-63 rows 2,3 (both halves hold the sums): float4 per row,
