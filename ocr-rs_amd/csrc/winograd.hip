@@ -206,6 +206,24 @@ __global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __r
   const long long n = r / th;
   const size_t step = (size_t)T * K;
   const float* src = m + (size_t)t * K + k;
+  // the residual block first: its 16 loads are in flight under the 36 loads and the arithmetic of the transform (requested
+  // where they are consumed, behind the per-pixel bounds checks, they cost 0.024 ms per layer3 conv for 52 MB - half the
+  // kernel); pixels beyond the image re-read the last row / column and are never stored
+  f32x2 res[4][4];
+  if (residual) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int yy = min(4 * ty + p, H - 1), xx = min(4 * tx + q, W - 1);
+        res[p][q] = *reinterpret_cast<const f32x2*>(residual + ((n * H + yy) * W + xx) * (size_t)K + k);
+      }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) res[p][q] = f32x2{0.f, 0.f};
+  }
   f32x2 u[4][6];  // A^T M, column by column
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -231,8 +249,7 @@ __global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __r
       const int xx = 4 * tx + q;
       if (xx >= W) continue;
       const size_t o = ((n * H + yy) * W + xx) * (size_t)K + k;
-      f32x2 val = o4[q] * sc + bi;
-      if (residual) val += *reinterpret_cast<const f32x2*>(residual + o);
+      f32x2 val = o4[q] * sc + bi + res[p][q];
       if (relu) {
         val[0] = fmaxf(val[0], 0.f);
         val[1] = fmaxf(val[1], 0.f);
