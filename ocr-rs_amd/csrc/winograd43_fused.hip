@@ -380,18 +380,13 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
       for (int h = 0; h < 2; ++h) {
         // residual of this half, requested before the transform so that its latency hides behind it
         f32x4 res[8];
-        auto row_offset = [&](int k, bool& ok) -> unsigned {   // byte offset of image row y0 + 8 h + k (scalar; y < 2^31 bytes)
-          const int yy = y0 + 8 * h + k;
-          ok = yy < p.H;
-          return (unsigned)(((n * p.H + yy) * p.W * p.K) * 4);
-        };
+        // image row y0 + 8 h + k: its byte offset (scalar; y < 2^31 bytes) and this lane's offset inside it - out of the
+        // descriptor's range for rows below the image, so that loads (zeros) and stores (dropped) need no branch
+        auto row_offset = [&](int k) -> unsigned { return (unsigned)(((n * p.H + min(y0 + 8 * h + k, p.H - 1)) * p.W * p.K) * 4); };
+        auto row_voff = [&](int k) -> unsigned { return y0 + 8 * h + k < p.H ? ep_v : OOB; };
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          bool ok;
-          const unsigned so = row_offset(k, ok);
-          res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (ok) res[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ep_v, __builtin_amdgcn_readfirstlane(so), 0));
-        }
+        for (int k = 0; k < 8; ++k)
+          res[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, row_voff(k), __builtin_amdgcn_readfirstlane(row_offset(k)), 0));
         W43_STAMP(17 + 4 * h);
         __syncthreads();  // h = 0: every wave is done with V; h = 1: the first half has been read
         W43_STAMP(18 + 4 * h);
@@ -420,20 +415,26 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         W43_STAMP(19 + 4 * h);
         __syncthreads();
         W43_STAMP(20 + 4 * h);
+        // all eight pixel rows of the half out of LDS first (one wait, not eight), then arithmetic and stores with one uniform
+        // branch (ReLU) instead of two per row; rows below the image are dropped by the descriptor's range check
+        f32x4 vr[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int pl = k * 16 + (tid >> 4);
-          f32x4 v = *reinterpret_cast<const f32x4*>(lds + V_OFF + (pl * 64 + ((c4 + 16 * (tid >> 6)) & 63)) * 4);
-          v = v * sc + bi + res[k];
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          bool ok;
-          const unsigned so = row_offset(k, ok);
-          if (ok && !W43_DBG(p, 8))
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, ep_v, __builtin_amdgcn_readfirstlane(so), 0);
+          vr[k] = *reinterpret_cast<const f32x4*>(lds + V_OFF + (pl * 64 + ((c4 + 16 * (tid >> 6)) & 63)) * 4);
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vr[k] = vr[k] * sc + bi + res[k];
+        if (p.relu) {   // one uniform branch per half
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vr[k][e] = fmaxf(vr[k][e], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (!W43_DBG(p, 8))
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vr[k]), y_rsrc, row_voff(k), __builtin_amdgcn_readfirstlane(row_offset(k)), 0);
       }
     }
     W43_STAMP(25);
