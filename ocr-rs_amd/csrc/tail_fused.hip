@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
   // tap: into registers once.  Read from LDS inside the tap loop they were 32 more dependent round trips per tap.
   // (X3: its pixel fragments need 48 registers; it reads these from LDS per tap and channel half instead - the reads
   // ride under bf16 MFMAs, which leave the vector and LDS pipes free)
-  f32x4 w2r[X3 ? 1 : 2][16];
+  f32x4 w2r[X3 ? 1 : 2][16];   // (X3 reads them from LDS slice by slice instead)
   if constexpr (!X3) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -277,24 +277,6 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
     const float* wb = Ws + (t & 1) * W_STRIDE;
-    if constexpr (X3) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)     // channel half 0 complete first: its epilogue runs beside the MFMAs of half 1
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const float* wr = wb + (32 * ct + frow) * 32 + xoff[kk];   // chunk 2 kk + half of the 64-channel bf16 row
-          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wr);
-          const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wr + 64 * 32);
-          const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wr + 2 * 64 * 32);
-          // small terms first (mid.lo, lo.mid, lo.lo are below 2^-23 of the product)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, pxh[kk], acc[ct], 0, 0, 0);
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pxl[kk], acc[ct], 0, 0, 0);
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, pxm[kk], acc[ct], 0, 0, 0);
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, pxh[kk], acc[ct], 0, 0, 0);
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pxm[kk], acc[ct], 0, 0, 0);
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pxh[kk], acc[ct], 0, 0, 0);
-        }
-    } else
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -328,15 +310,11 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs p) {
       }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      if constexpr (X3) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) w2r[0][e] = *reinterpret_cast<const f32x4*>(&tab_w2[(32 * ct + (e & 3) + 8 * (e >> 2) + 4 * half) * 4]);
-      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float z = fmaxf(acc[ct][e] * sv[ct][e >> 2][e & 3] + bv[ct][e >> 2][e & 3], 0.f);  // + bias, bin_bn2, ReLU
 #pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2r[X3 ? 0 : ct][e][u], part[u]);
+        for (int u = 0; u < 4; ++u) part[u] = fmaf(z, w2r[ct][e][u], part[u]);
       }
     }
 #pragma unroll
