@@ -142,8 +142,14 @@ __device__ __forceinline__ void bt6(const V d0, const V d1, const V d2, const V 
 }
 
 // one thread = one tile x 2 channels (36 loads of 8 bytes; consecutive threads walk the channels).  v layout [36][T][C].
+// Addresses through buffer descriptors: lane part (the tile's first pixel, this channel pair) in the voffset, tap / component
+// part a scalar - no 64-bit index arithmetic and no branch per element (the first form spent ~10 integer instructions and
+// an exec-mask branch on each of its 36 loads); taps outside the image get an out-of-range voffset and read as zero.
+// The input descriptor starts one row and one pixel BEFORE the tensor so that the tap offsets (i W + j) C are non-negative.
+constexpr unsigned WOOB = 0x80000000u;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void winograd43_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H, int W,
-                                                               int C, int th, int tw, long long T) {
+                                                               int C, int th, int tw, long long T, unsigned x_bytes, unsigned v_bytes) {
   const int c2n = C >> 1;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= T * c2n) return;
@@ -152,32 +158,38 @@ __global__ __launch_bounds__(256) void winograd43_input_kernel(const float* __re
   const int tx = (int)(t % tw);
   const long long r = t / tw;
   const int ty = (int)(r % th);
-  const long long n = r / th;
-  const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+  const int n = (int)(r / th);
+  const unsigned lead = (unsigned)(W + 1) * C * 4;
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - (size_t)(W + 1) * C, 0, x_bytes + lead, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(v, 0, v_bytes, 0x00020000);
+  const unsigned voff0 = (unsigned)((((n * H + 4 * ty) * W + 4 * tx) * C + c) * 4);
+  bool row_ok[6], col_ok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    row_ok[i] = (unsigned)(4 * ty - 1 + i) < (unsigned)H;
+    col_ok[i] = (unsigned)(4 * tx - 1 + i) < (unsigned)W;
+  }
   f32x2 rt[6][6];  // B^T d, column by column
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     f32x2 d[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int yy = y0 + i, xx = x0 + j;
-      const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      const f32x2 zero = {0.f, 0.f};
-      d[i] = ok ? *reinterpret_cast<const f32x2*>(x + ((n * H + yy) * W + xx) * C + c) : zero;
-    }
+    for (int i = 0; i < 6; ++i)
+      d[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, (row_ok[i] && col_ok[j]) ? voff0 : WOOB,
+                                                                            (i * W + j) * C * 4, 0));
     f32x2 tcol[6];
     bt6(d[0], d[1], d[2], d[3], d[4], d[5], tcol);
 #pragma unroll
     for (int i = 0; i < 6; ++i) rt[i][j] = tcol[i];
   }
-  const size_t step = (size_t)T * C;
+  const unsigned step = (unsigned)(T * C) * 4u;              // bytes between components (36 x step < 2^31: checked by the launcher)
+  const unsigned voff_v = (unsigned)((t * C + c) * 4);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {  // (B^T d) B
     f32x2 o[6];
     bt6(rt[i][0], rt[i][1], rt[i][2], rt[i][3], rt[i][4], rt[i][5], o);
-    float* dst = v + ((size_t)(6 * i) * T + t) * C + c;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(dst + j * step) = o[j];
+    for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[j]), v_rsrc, voff_v, (6 * i + j) * step, 0);
   }
 }
 
@@ -190,11 +202,14 @@ __device__ __forceinline__ void at6(const V m0, const V m1, const V m2, const V 
   y[3] = d12 + 8.f * d34 + m5;
 }
 
-// one thread = one tile x 2 output channels.  m layout [36][T][K]; y NHWC.
+// one thread = one tile x 2 output channels.  m layout [36][T][K]; y NHWC.  Buffer addressing as in the input kernel; the
+// residual block is requested first: its 16 loads are in flight under the 36 loads and the arithmetic of the transform
+// (requested where they are consumed, behind per-pixel bounds checks, they cost 0.024 ms per layer3 conv for 52 MB - half
+// the kernel); pixels beyond the image read as zero and are not stored (out-of-range voffset).
 __global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                                 const float* __restrict__ bias, const float* __restrict__ residual,
                                                                 int relu, float* __restrict__ y, int H, int W, int K, int th,
-                                                                int tw, long long T) {
+                                                                int tw, long long T, unsigned m_bytes, unsigned y_bytes) {
   const int k2n = K >> 1;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= T * k2n) return;
@@ -203,33 +218,30 @@ __global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __r
   const int tx = (int)(t % tw);
   const long long r = t / tw;
   const int ty = (int)(r % th);
-  const long long n = r / th;
-  const size_t step = (size_t)T * K;
-  const float* src = m + (size_t)t * K + k;
-  // the residual block first: its 16 loads are in flight under the 36 loads and the arithmetic of the transform (requested
-  // where they are consumed, behind the per-pixel bounds checks, they cost 0.024 ms per layer3 conv for 52 MB - half the
-  // kernel); pixels beyond the image re-read the last row / column and are never stored
+  const int n = (int)(r / th);
+  const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m), 0, m_bytes, 0x00020000);
+  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
+  const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual : y), 0, residual ? y_bytes : 0u, 0x00020000);
+  const unsigned voff0 = (unsigned)((((n * H + 4 * ty) * W + 4 * tx) * K + k) * 4);
+  unsigned pv[4][4];   // this lane's offset of pixel (p, q) of the tile: the tile origin, or out of range beyond the image
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pv[p][q] = (4 * ty + p < H && 4 * tx + q < W) ? voff0 : WOOB;
   f32x2 res[4][4];
-  if (residual) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int yy = min(4 * ty + p, H - 1), xx = min(4 * tx + q, W - 1);
-        res[p][q] = *reinterpret_cast<const f32x2*>(residual + ((n * H + yy) * W + xx) * (size_t)K + k);
-      }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) res[p][q] = f32x2{0.f, 0.f};
-  }
+    for (int q = 0; q < 4; ++q)
+      res[p][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, pv[p][q], (p * W + q) * K * 4, 0));   // (no residual: 0 records, zeros)
+  const unsigned step = (unsigned)(T * K) * 4u;
+  const unsigned voff_m = (unsigned)((t * K + k) * 4);
   f32x2 u[4][6];  // A^T M, column by column
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     f32x2 a[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a[i] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * i + j) * step);
+    for (int i = 0; i < 6; ++i) a[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(m_rsrc, voff_m, (6 * i + j) * step, 0));
     f32x2 col[4];
     at6(a[0], a[1], a[2], a[3], a[4], a[5], col);
 #pragma unroll
@@ -242,19 +254,14 @@ __global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __r
   for (int p = 0; p < 4; ++p) {
     f32x2 o4[4];
     at6(u[p][0], u[p][1], u[p][2], u[p][3], u[p][4], u[p][5], o4);
-    const int yy = 4 * ty + p;
-    if (yy >= H) continue;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int xx = 4 * tx + q;
-      if (xx >= W) continue;
-      const size_t o = ((n * H + yy) * W + xx) * (size_t)K + k;
       f32x2 val = o4[q] * sc + bi + res[p][q];
       if (relu) {
         val[0] = fmaxf(val[0], 0.f);
         val[1] = fmaxf(val[1], 0.f);
       }
-      *reinterpret_cast<f32x2*>(y + o) = val;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), y_rsrc, pv[p][q], (p * W + q) * K * 4, 0);
     }
   }
 }
@@ -268,7 +275,9 @@ void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C,
     const long long T = (long long)N * th * tw;
     const long long threads = T * (C / 2);
     if (threads >= (1ll << 31) * 256) fail(OCR_ERR_INVALID, "winograd input: too large");
-    hipLaunchKernelGGL(winograd43_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, v, H, W, C, th, tw, T);
+    const unsigned long long xb = (unsigned long long)N * H * W * C * 4, vb = 36ull * T * C * 4;
+    if (xb + (unsigned long long)(W + 1) * C * 4 >= (1ull << 31) || vb >= (1ull << 31)) fail(OCR_ERR_INVALID, "winograd input: tensors beyond 2 GB");
+    hipLaunchKernelGGL(winograd43_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, v, H, W, C, th, tw, T, (unsigned)xb, (unsigned)vb);
     OCR_HIP(hipGetLastError());
     return;
   }
@@ -288,8 +297,10 @@ void launch_winograd_output(const float* m, const float* scale, const float* bia
     const long long T = (long long)N * th * tw;
     const long long threads = T * (K / 2);
     if (threads >= (1ll << 31) * 256) fail(OCR_ERR_INVALID, "winograd output: too large");
+    const unsigned long long yb = (unsigned long long)N * H * W * K * 4, mb = 36ull * T * K * 4;
+    if (yb >= (1ull << 31) || mb >= (1ull << 31)) fail(OCR_ERR_INVALID, "winograd output: tensors beyond 2 GB");
     hipLaunchKernelGGL(winograd43_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, scale, bias, residual,
-                       relu, y, H, W, K, th, tw, T);
+                       relu, y, H, W, K, th, tw, T, (unsigned)mb, (unsigned)yb);
     OCR_HIP(hipGetLastError());
     return;
   }
