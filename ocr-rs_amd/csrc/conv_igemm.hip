@@ -47,6 +47,7 @@ namespace igemm {  // named (not anonymous): the kernel stubs are referenced fro
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -815,6 +816,43 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = zero4;
   if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
   if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + col);
+  if constexpr (STORE == STORE_PHASE && sizeof(TO) == 4) {
+    if (!p.out2) {
+      // f32 phase store (the upsampled FPN terms, bin_conv1's pyramid): buffer loads / stores at (pixel row offset + column) - rows
+      // beyond M get an out-of-range offset and are dropped by the hardware; no 64-bit index, no compare-and-branch per row
+      const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(((unsigned)p.M << (2 * p.up_shift)) * (unsigned)p.Cout * 4u));
+      const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.out), 0, out_bytes, 0x00020000);
+      const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.residual ? p.residual : p.out), 0, p.residual ? out_bytes : 0u, 0x00020000);
+      const unsigned colb = (unsigned)col * 4u;
+      auto rows = [&](auto relu_c) {
+        constexpr int G = PASSES < 4 ? PASSES : 4;
+#pragma unroll
+        for (int k0 = 0; k0 < PASSES; k0 += G) {
+          unsigned ro[G];
+          f32x4 res[G];
+#pragma unroll
+          for (int k = 0; k < G; ++k) {
+            const int rr = rr0 + (k0 + k) * RPP;
+            ro[k] = m0 + rr < p.M ? (unsigned)row_aux[rr] * 4u + colb : OOB;
+            res[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ro[k], 0, 0));   // (no residual: zeros)
+          }
+#pragma unroll
+          for (int k = 0; k < G; ++k) {
+            const int rr = rr0 + (k0 + k) * RPP;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&tile[rr * BN + c4]) * sc + bi + res[k];
+            if constexpr (decltype(relu_c)::value) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, ro[k], 0, 0);
+          }
+        }
+      };
+      if (p.relu) rows(std::true_type{});
+      else rows(std::false_type{});
+      return;
+    }
+  }
   if constexpr (STORE != STORE_SHUFFLE2) {
     constexpr int G = PASSES < 4 ? PASSES : 4;  // rows in flight per thread: bounds the staging registers
 #pragma unroll
@@ -932,7 +970,7 @@ static void check(const ConvDesc& d) {
     if (!phase2 || d.up != 8 || d.ks != 3 || d.stride != 1 || d.pad != 0 || d.Cin != 64 || d.Cout != 64 || d.Ho != d.Hin ||
         d.Wo != d.Win || d.out2 || d.residual || !d.out || (d.out_bf16 && !d.in_bf16) || d.batch > 1)
       fail(OCR_ERR_INVALID, "%s: PYR4 needs the 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
-    if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large", d.name);
+    if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 30)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large (2^32 bytes)", d.name);
     if ((long long)d.wgt_bytes != 64ll * d.Cout * 21 * 64 * ebw) fail(OCR_ERR_INVALID, "%s: PYR4 weight bytes", d.name);
     if ((long long)d.src_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: sources must be < 2^31 bytes; split the batch", d.name);
     for (int i = 0; i < 4; ++i) {
@@ -949,8 +987,8 @@ static void check(const ConvDesc& d) {
     if (d.up != 2 && d.up != 4 && d.up != 8) fail(OCR_ERR_INVALID, "%s: PHASE store with up = %d", d.name, d.up);
     if (d.ks != 2 || d.stride != 1 || d.pad != 1 || d.Ho != d.Hin || d.Wo != d.Win || d.out2 || d.src_mode != SRC_PLAIN || !d.out)
       fail(OCR_ERR_INVALID, "%s: PHASE store needs a 2x2 s1 pad-1 conv on the low-res grid", d.name);
-    if ((long long)d.N * d.Ho * d.Wo * d.up * d.up * d.Cout >= (1ll << 31))
-      fail(OCR_ERR_INVALID, "%s: PHASE output too large", d.name);
+    if ((long long)d.N * d.Ho * d.Wo * d.up * d.up * d.Cout >= (1ll << 30))   // the f32 epilogue addresses it through one buffer descriptor
+      fail(OCR_ERR_INVALID, "%s: PHASE output too large (2^32 bytes)", d.name);
   } else {
     if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
     if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);
