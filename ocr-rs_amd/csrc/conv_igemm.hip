@@ -48,6 +48,7 @@ namespace igemm {  // named (not anonymous): the kernel stubs are referenced fro
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -59,6 +60,13 @@ template <> struct Elem<float> {
   static __device__ __forceinline__ void store4(void* base, size_t idx, f32x4 v) { *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v; }
   static __device__ __forceinline__ float load1(const void* base, size_t idx) { return static_cast<const float*>(base)[idx]; }
   static __device__ __forceinline__ void store1(void* base, size_t idx, float v) { static_cast<float*>(base)[idx] = v; }
+  // four elements at byte offset voff of a buffer descriptor (out of range: zeros / dropped)
+  template <typename R> static __device__ __forceinline__ f32x4 bload4(R rsrc, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+  }
+  template <typename R> static __device__ __forceinline__ void bstore4(R rsrc, unsigned voff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, 0, 0);
+  }
 };
 template <> struct Elem<__bf16> {
   static __device__ __forceinline__ f32x4 load4(const void* base, size_t idx) {
@@ -72,6 +80,15 @@ template <> struct Elem<__bf16> {
   }
   static __device__ __forceinline__ float load1(const void* base, size_t idx) { return (float)static_cast<const __bf16*>(base)[idx]; }
   static __device__ __forceinline__ void store1(void* base, size_t idx, float v) { static_cast<__bf16*>(base)[idx] = (__bf16)v; }
+  template <typename R> static __device__ __forceinline__ f32x4 bload4(R rsrc, unsigned voff) {
+    const bf16x4 h = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
+    f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return v;
+  }
+  template <typename R> static __device__ __forceinline__ void bstore4(R rsrc, unsigned voff, f32x4 v) {
+    bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};  // round to nearest even
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rsrc, voff, 0, 0);
+  }
 };
 
 // One 16-byte-per-lane LDS-DMA load (buffer_load_dwordx4 ... lds): lane l's 16 bytes land at lds_addr + 16 l.
@@ -816,14 +833,17 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = zero4;
   if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
   if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + col);
-  if constexpr (STORE == STORE_PHASE && sizeof(TO) == 4) {
+  if constexpr (STORE == STORE_PHASE || STORE == STORE_NHWC) {
     if (!p.out2) {
-      // f32 phase store (the upsampled FPN terms, bin_conv1's pyramid): buffer loads / stores at (pixel row offset + column) - rows
-      // beyond M get an out-of-range offset and are dropped by the hardware; no 64-bit index, no compare-and-branch per row
-      const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(((unsigned)p.M << (2 * p.up_shift)) * (unsigned)p.Cout * 4u));
+      // plain and phase stores (f32 or bf16): buffer loads / stores at (row offset + column) - rows beyond M lie outside the
+      // descriptor's range (NHWC) or get an out-of-range offset (PHASE) and are dropped by the hardware; no 64-bit index, no
+      // compare-and-branch per row (the general form below spent a fifth of the short bf16 kernels on them)
+      constexpr unsigned ES = sizeof(TO);
+      const unsigned out_elems = STORE == STORE_PHASE ? ((unsigned)p.M << (2 * p.up_shift)) * (unsigned)p.Cout : (unsigned)p.M * (unsigned)p.Cout;
+      const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(out_elems * ES));
       const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.out), 0, out_bytes, 0x00020000);
       const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.residual ? p.residual : p.out), 0, p.residual ? out_bytes : 0u, 0x00020000);
-      const unsigned colb = (unsigned)col * 4u;
+      const unsigned colb = (unsigned)col * ES, rowb = (unsigned)p.Cout * ES;
       auto rows = [&](auto relu_c) {
         constexpr int G = PASSES < 4 ? PASSES : 4;
 #pragma unroll
@@ -833,8 +853,9 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #pragma unroll
           for (int k = 0; k < G; ++k) {
             const int rr = rr0 + (k0 + k) * RPP;
-            ro[k] = m0 + rr < p.M ? (unsigned)row_aux[rr] * 4u + colb : OOB;
-            res[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ro[k], 0, 0));   // (no residual: zeros)
+            if constexpr (STORE == STORE_PHASE) ro[k] = m0 + rr < p.M ? (unsigned)row_aux[rr] * ES + colb : OOB;
+            else ro[k] = (unsigned)(m0 + rr) * rowb + colb;
+            res[k] = Elem<TO>::bload4(r_rsrc, ro[k]);   // (no residual: zeros)
           }
 #pragma unroll
           for (int k = 0; k < G; ++k) {
@@ -844,7 +865,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #pragma unroll
               for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, ro[k], 0, 0);
+            Elem<TO>::bstore4(o_rsrc, ro[k], v);
           }
         }
       };
