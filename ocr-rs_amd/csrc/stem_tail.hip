@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
   // runs under the previous tile's MFMAs and pooling instead of in front of every tile
   constexpr int NLD = (IR * (ICP / 2) + NT - 1) / NT;
   float pre[NLD][2];
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<TX*>(xin), 0, (unsigned)(H * W * (int)sizeof(TX)), 0x00020000);
   auto request = [&](int tl) {
     const int pw0 = (blockIdx.x * TL + tl) * TPW;
     const int ic0 = 2 * (2 * pw0 - 1) - 3;
@@ -201,13 +202,17 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
       const int i = tid + k * NT;
       const int rr = i / (ICP / 2), cp = i - rr * (ICP / 2);
       const int ih = ir0 + rr, iw = ic0 + 2 * cp;
-      float v0 = 0.f, v1 = 0.f;  // zero padding of conv1
-      if (i < IR * (ICP / 2) && pw0 < Wp && (unsigned)ih < (unsigned)H) {
-        if ((unsigned)iw < (unsigned)W) v0 = (float)xin[(size_t)ih * W + iw];
-        if ((unsigned)(iw + 1) < (unsigned)W) v1 = (float)xin[(size_t)ih * W + iw + 1];
+      // zero padding of conv1 = an out-of-range offset into this frame's buffer descriptor (no branch per pixel)
+      const bool rowok = i < IR * (ICP / 2) && pw0 < Wp && (unsigned)ih < (unsigned)H;
+      const unsigned o0 = rowok && (unsigned)iw < (unsigned)W ? (unsigned)((ih * W + iw) * (int)sizeof(TX)) : 0x80000000u;
+      const unsigned o1 = rowok && (unsigned)(iw + 1) < (unsigned)W ? (unsigned)((ih * W + iw + 1) * (int)sizeof(TX)) : 0x80000000u;
+      if constexpr (sizeof(TX) == 4) {
+        pre[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o0, 0, 0));
+        pre[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o1, 0, 0));
+      } else {
+        pre[k][0] = (float)__builtin_amdgcn_raw_buffer_load_b8(x_rsrc, o0, 0, 0);
+        pre[k][1] = (float)__builtin_amdgcn_raw_buffer_load_b8(x_rsrc, o1, 0, 0);
       }
-      pre[k][0] = v0;
-      pre[k][1] = v1;
     }
   };
   request(0);
@@ -264,13 +269,25 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wreg[0][1][s], acc1, 0, 0, 0);
         }
       }
+      // a tile whose 9 x 13 conv pixels all lie inside the conv map (every tile but the first row / column of tiles and a
+      // ragged last column) needs no validity test: per element two FMA, two max, one paired LDS write - the general
+      // form's per-element division, compares and selects were a fifth of this kernel's instructions
+      if (cr0 >= 0 && cr0 + CR <= Hc && cc0 >= 0 && cc0 + CC <= Wc) {   // workgroup-uniform
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int qr = p / CC, qc = p - qr * CC;
-        const bool valid = (unsigned)(cr0 + qr) < (unsigned)Hc && (unsigned)(cc0 + qc) < (unsigned)Wc;
-        conv_s[p][l31] = valid ? fmaxf(acc0[e] * sc0 + bi0, 0.f) : 0.f;
-        conv_s[p][32 + l31] = valid ? fmaxf(acc1[e] * sc1 + bi1, 0.f) : 0.f;
+        for (int e = 0; e < 16; ++e) {
+          const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
+          conv_s[p][l31] = fmaxf(acc0[e] * sc0 + bi0, 0.f);
+          conv_s[p][32 + l31] = fmaxf(acc1[e] * sc1 + bi1, 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int p = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int qr = p / CC, qc = p - qr * CC;
+          const bool valid = (unsigned)(cr0 + qr) < (unsigned)Hc && (unsigned)(cc0 + qc) < (unsigned)Wc;
+          conv_s[p][l31] = valid ? fmaxf(acc0[e] * sc0 + bi0, 0.f) : 0.f;
+          conv_s[p][32 + l31] = valid ? fmaxf(acc1[e] * sc1 + bi1, 0.f) : 0.f;
+        }
       }
     }
     __syncthreads();
