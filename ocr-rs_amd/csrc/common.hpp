@@ -120,6 +120,11 @@ void launch_winograd_output(const float* mm, const float* scale, const float* bi
 std::vector<float> winograd43_fragments(const std::vector<float>& u, int cout, int cin);
 void launch_winograd43_fused(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual,
                              int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
+// ... and with its GEMMs on the bf16 matrix cores, f32 operands as three bf16 terms each (winograd43_x3.hip; mfma=split_bf16):
+// two pixel blocks per workgroup, one workgroup per CU.  ufrag: winograd43_x3_fragments(winograd_weights(.., 4)).
+std::vector<uint16_t> winograd43_x3_fragments(const std::vector<float>& u, int cout, int cin);
+void launch_winograd43_x3(const float* x, const void* ufrag, const float* scale, const float* bias, const float* residual,
+                          int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
 // tail: convT2x2 s2 64->1 + bias + sigmoid (+ optional binarize)
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob,
                            uint8_t* bitmap, float thresh, int N, int H2, int W2, hipStream_t s);

@@ -157,7 +157,9 @@ void Detector::add_winograd_weights(ConvW& cw) {
 
 void Detector::add_winograd_fused_weights(ConvW& cw) {
   if ((cw.cin != 64 && cw.cin != 128 && cw.cin != 256) || cw.cout % 64 || cw.ks != 3) fail(OCR_ERR_INTERNAL, "fused Winograd: unsupported conv shape");
-  cw.wino43_fused = arena_.upload(winograd43_fragments(winograd_weights(cw.host.data(), cw.cout, cw.cin, 4), cw.cout, cw.cin));
+  const std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin, 4);
+  cw.wino43_fused = arena_.upload(winograd43_fragments(u, cw.cout, cw.cin));
+  if (split_bf16_ && winograd43_x3_) cw.wino43_x3 = arena_.upload_u16(winograd43_x3_fragments(u, cw.cout, cw.cin));
 }
 
 // hi / mid / lo bf16 planes of a conv's f32 weights (and of its Winograd form): what conv_igemm's split-bf16 kernels read
@@ -234,6 +236,7 @@ void Detector::parse_options(const char* options) {
       return (int)v;
     };
     if (key == "winograd_fused") winograd_fused_ = num() != 0;
+    else if (key == "winograd43_x3") winograd43_x3_ = num() != 0;
     else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "winograd43") winograd43_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
@@ -280,7 +283,7 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   // composed FPN weights, 24.4 MB of bf16 copies and fragments on demand, padding
   // ... and with mfma=split_bf16 the bf16 planes (6 bytes per weight) of the convs that run that way: 170 MB for layer4's
   // Winograd matrices, 57 MB for layer3's, 33 MB for bin_conv1's phase weights
-  arena_.reserve((size_t)(split_bf16_ ? 768 : 384) << 20);
+  arena_.reserve((size_t)(split_bf16_ ? 800 : 384) << 20);
 
   {  // conv1 [64,1,7,7] -> [49][64]; bn1
     const float* w = wb.get("conv1.weight", {64, 1, 7, 7}).data;
@@ -818,6 +821,15 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   // [tiles x Cin] x [Cin x Cout] GEMMs in one batched launch, output transform with the epilogue (f32 only)
   auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual,
                      bool relu = true) {
+    if (!bf && cw.wino43_x3) {  // transforms fused into the GEMM kernel, the GEMMs on the bf16 matrix cores (split-bf16)
+      rec.begin();
+      launch_winograd43_x3(static_cast<const float*>(src), cw.wino43_x3, cw.scale, cw.bias, static_cast<const float*>(residual),
+                           relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
+      const double px43 = (double)n * hh * ww;
+      rec.end(cw.cin == 64 ? "winograd43_fused_x3<c64>" : cw.cin == 128 ? "winograd43_fused_x3<c128>" : "winograd43_fused_x3<c256>",
+              2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout, px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 6);
+      return;
+    }
     if (!bf && cw.wino43_fused) {  // transforms fused into the GEMM kernel
       {
         rec.begin();

@@ -46,6 +46,7 @@ struct ConvW {
   size_t wino_bytes = 0;
   int wino_tile = 2;       // ... or F(4x4,3x3), [36][Cout][Cin], where the option winograd43 asks for it
   float* wino43_fused = nullptr;  // F(4x4,3x3) weights as MFMA B fragments for winograd43_fused.hip (Cin 64 / 128)
+  void* wino43_x3 = nullptr;      // ... as three bf16 planes of B fragments for winograd43_x3.hip (mfma=split_bf16)
   int up = 0;              // STORE_PHASE convs: upsampling factor (weights hold up*up phase sets)
   float* scale = nullptr;  // folded eval batch norm, may stay null
   float* bias = nullptr;
@@ -158,6 +159,7 @@ class Detector {
   float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [(m+2)^2][T][C] and [(m+2)^2][T][K] scratch of the layer in flight
   void add_winograd_weights(ConvW& cw);
   void add_winograd_fused_weights(ConvW& cw);
+  bool winograd43_x3_ = true;    // option winograd43_x3=0: the fused F(4x4,3x3) convs stay on the f32 matrix instructions under mfma=split_bf16
   bool winograd_fused_ = true;   // option winograd_fused=0: direct / unfused-Winograd convs instead of the fused F(4x4,3x3) kernel
   // option mfma=split_bf16 (default) | f32: the MFMA-bound f32 convs without a Winograd kernel of their own (stride-2 3x3,
   // composed FPN phase convs, bin_conv1 over the pyramid, the 36 Winograd GEMMs of layer3 / layer4) run on the bf16 matrix

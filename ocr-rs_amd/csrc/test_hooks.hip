@@ -257,6 +257,17 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     const float* d_sc = scale ? dev(scale, cout) : nullptr;
     const float* d_bi = bias ? dev(bias, cout) : nullptr;
     const float* d_res = residual ? dev(residual, out_e) : nullptr;
+    if (unfused == 5) {  // fused F(4x4,3x3) on the bf16 matrix cores (split-bf16); one workgroup per CU
+      const std::vector<uint16_t> uf = winograd43_x3_fragments(u, cout, cin);
+      void* d_uf = nullptr;
+      OCR_HIP(hipMalloc(&d_uf, uf.size() * 2));
+      allocs.push_back(d_uf);
+      OCR_HIP(hipMemcpy(d_uf, uf.data(), uf.size() * 2, hipMemcpyHostToDevice));
+      launch_winograd43_x3(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, num_cus > 0 ? num_cus : 256, s);
+      OCR_HIP(hipStreamSynchronize(s));
+      OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
+      return;
+    }
     if (unfused == 4) {  // fused F(4x4,3x3); num_cus sizes its persistent grid (two workgroups per CU)
       float* d_uf = dev(winograd43_fragments(u, cout, cin).data(), u.size());
       launch_winograd43_fused(d_x, d_uf, d_sc, d_bi, d_res, relu, d_y, n, h, w, cin, cout, num_cus > 0 ? num_cus : 256, s);

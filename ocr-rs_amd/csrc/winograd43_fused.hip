@@ -479,6 +479,7 @@ std::vector<float> winograd43_fragments(const std::vector<float>& u, int cout, i
 
 static int g_w43_debug = 0;
 void winograd43_set_debug(int d) { g_w43_debug = d; }
+int winograd43_get_debug() { return g_w43_debug; }
 
 void launch_winograd43_fused(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual,
                              int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s) {

@@ -268,6 +268,59 @@ def test_winograd43_fused_conv_matches_aten(det, case):
     assert err < 1e-4, err
 
 
+W43X_CASES = W43F_CASES + [
+    (3, 16, 16, 64, 64, True, True, True),       # an odd number of pixel blocks: the last workgroup owns one block and an empty one
+    (1, 16, 16, 128, 128, False, True, False),   # a single block, two output-channel blocks
+    (2, 33, 17, 64, 64, True, True, True),       # one pixel past a block edge both ways
+]
+
+
+@pytest.mark.parametrize("case", W43X_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_winograd43_fused_x3_conv_matches_aten(det, case):
+    """The fused F(4x4,3x3) kernel with its GEMMs on the bf16 matrix cores (winograd43_x3.hip: f32 operands as three bf16 terms,
+    six partial products, f32 accumulate) against ATen's direct conv2d: the SAME bar as the f32 kernels."""
+    n, h, w, cin, cout, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:5]) & 0xFFFF)
+    x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
+    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, h, w, cout), dtype=np.float32) if has_res else None
+    got = det.debug_winograd_conv(x, wg, scale, bias, res, relu, unfused=5)
+    ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
+    err = float(np.abs(got - ref).max()) / (float(np.abs(ref).max()) + 1e-12)
+    assert err < 1e-4, err
+
+
+def test_winograd43_fused_x3_matches_f32_kernel(det):
+    """Split-bf16 against the exact-f32 fused kernel on the same operands, with 24 binades of exponent spread across pixels and
+    channels: the split is exact and the dropped products are below 2^-23, so the two differ by summation order only."""
+    rng = np.random.default_rng(7)
+    n, h, w, cin, cout = 2, 32, 48, 64, 64
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32) * np.exp2(rng.integers(-12, 12, (n, h, w, 1))).astype(np.float32)
+    wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    a = det.debug_winograd_conv(x, wg, None, None, None, False, unfused=4)
+    b = det.debug_winograd_conv(x, wg, None, None, None, False, unfused=5)
+    # compare per 16 x 16 block (a tile's error scales with the largest value the tile's transform saw)
+    for yy in range(0, h, 16):
+        for xx in range(0, w, 16):
+            sa, sb = a[:, yy:yy + 16, xx:xx + 16], b[:, yy:yy + 16, xx:xx + 16]
+            assert float(np.abs(sa - sb).max()) <= 2e-5 * (float(np.abs(x[:, max(yy - 1, 0):yy + 17, max(xx - 1, 0):xx + 17]).max()) + 1e-30), (yy, xx)
+
+
+@pytest.mark.parametrize("num_cus", [1, 5, 37, 100, 304])
+def test_winograd43_fused_x3_any_grid_size(det, num_cus):
+    """winograd43_x3.hip's persistent grid is num_cus workgroups: whatever the grid, every pair of blocks is computed exactly once."""
+    rng = np.random.default_rng(num_cus)
+    for n, h, w, cin, cout in ((3, 40, 56, 64, 64), (2, 24, 40, 128, 128)):
+        x = np.maximum(rng.standard_normal((n, h, w, cin), dtype=np.float32), 0)
+        wg = (rng.standard_normal((cout, 9, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+        res = rng.standard_normal((n, h, w, cout), dtype=np.float32)
+        got = det.debug_winograd_conv(x, wg, None, None, res, True, unfused=5 | (num_cus << 8))
+        ref, _ = _ref(x, wg, 1, None, None, res, None, True)
+        assert float(np.abs(got - ref).max()) / (float(np.abs(ref).max()) + 1e-12) < 1e-4
+
+
 @pytest.mark.parametrize("num_cus", [1, 5, 37, 100, 304])
 def test_winograd43_fused_any_grid_size(det, num_cus):
     """The fused kernel's persistent grid is 2 x num_cus workgroups (multiProcessorCount of the device: a partitioned or
