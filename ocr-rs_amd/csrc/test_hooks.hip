@@ -11,7 +11,7 @@ using ocr::guard;
 using ocr::align256;
 namespace ocr { void winograd43_set_debug(int d); }
 #ifdef W43_STAMPS
-namespace ocr { void winograd43_read_stamps(long long* out); }
+namespace ocr { void winograd43_read_stamps(long long* out); void winograd43_x3_read_stamps(long long* out); }
 #endif
 #ifdef WS_STAMPS
 #endif
@@ -398,6 +398,7 @@ int ocr_test_comm_assemble(const ocr_polygons_t* const* shards, int world, ocr_p
 
 #ifdef W43_STAMPS
 int ocr_test_w43_stamps(long long* out) { ocr::winograd43_read_stamps(out); return 0; }
+int ocr_test_w43x_stamps(long long* out) { ocr::winograd43_x3_read_stamps(out); return 0; }
 #endif
 int ocr_test_w43_debug(int d) { ocr::winograd43_set_debug(d); return 0; }
 #ifdef WS_STAMPS

@@ -86,6 +86,19 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 #define W43X_DBG(p, bit) false
 #endif
 
+#ifdef W43_STAMPS
+// diagnostic build only (make EXTRA=-DW43_STAMPS): s_memtime of workgroup 0, waves 0 and 4 (one of each half), at the phase
+// boundaries of its first three units; kept in LDS during the kernel and copied out at the end (tools/w43x_stamps.py)
+__device__ long long g_w43x_stamps[2 * 3 * 64];
+#define W43X_STAMP(k)                                                                                          \
+  do {                                                                                                         \
+    if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && unit_count < 3)                                     \
+      stamp_lds[((wave >> 2) * 3 + unit_count) * 64 + (k)] = (long long)__builtin_amdgcn_s_memtime();          \
+  } while (0)
+#else
+#define W43X_STAMP(k) do {} while (0)
+#endif
+
 // rows of B^T d produced by phase ph: the pairs share their loads (rows 0 / 5 read patch rows 0, 2, 4 / 1, 3, 5; the others 1 .. 4)
 __host__ __device__ constexpr int phase_row(int ph, int r) { return ph == 0 ? (r == 0 ? 0 : 5) : ph == 1 ? (r == 0 ? 1 : 2) : (r == 0 ? 3 : 4); }
 // processing order o = 12 ph + 6 r + j  ->  component 6 i + j
@@ -129,6 +142,10 @@ template <int NCH>
 __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+#ifdef W43_STAMPS
+  __shared__ long long stamp_lds[2 * 3 * 64];
+  int unit_count = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, cg = wave & 3;   // rows of M this wave accumulates (first / second of a phase's pair), its 16 output channels
@@ -191,7 +208,10 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
         const bool row_ok = (unsigned)yy < (unsigned)p.H;
         const unsigned soff = row_ok ? (unsigned)(((bn * p.H + yy) * p.W * p.C + (2 * c + hf) * 16) * 4) : 0u;
         const unsigned dst = lds0 + (unsigned)((2 * dg + hf) * PATCH_STRIDE + row * PITCH + part * 1024);
-        const unsigned voff = row_ok ? pv : OOB;
+        // (the select sits right in front of its use: hoisted, the eighteen offsets live in registers - or scratch - all chunk long)
+        unsigned voff = pv;
+        asm volatile("" : "+v"(voff));
+        voff = row_ok ? voff : OOB;
         dma16(x_rsrc, __builtin_amdgcn_readfirstlane(dst), voff, __builtin_amdgcn_readfirstlane(soff));
       }
   };
@@ -261,7 +281,10 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) acur[g][pl] = *reinterpret_cast<const bf16x8*>(a_ptr + (g * 3 + pl) * 1024);
+      for (int pl = 0; pl < 3; ++pl) {
+        if (W43X_DBG(p, 128)) asm volatile("" : "=v"(acur[g][pl]));
+        else acur[g][pl] = *reinterpret_cast<const bf16x8*>(a_ptr + (g * 3 + pl) * 1024);
+      }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int t = 6 * PH + j;
@@ -291,7 +314,10 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) anext[g][pl] = *reinterpret_cast<const bf16x8*>(a_ptr + (((j + 1) * 2 + g) * 3 + pl) * 1024);
+          for (int pl = 0; pl < 3; ++pl) {
+            if (W43X_DBG(p, 128)) asm volatile("" : "=v"(anext[g][pl]));
+            else anext[g][pl] = *reinterpret_cast<const bf16x8*>(a_ptr + (((j + 1) * 2 + g) * 3 + pl) * 1024);
+          }
       }
       if (!W43X_DBG(p, 32)) {
         const bf16x8 bh = __builtin_bit_cast(bf16x8, b[0]), bm = __builtin_bit_cast(bf16x8, b[1]), bl = __builtin_bit_cast(bf16x8, b[2]);
@@ -341,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
   nxt = cur;
   for (int lu = q; lu < count; lu += stride) {
     const bool has_next_unit = lu + stride < count;
+    W43X_STAMP(0);
     if (has_next_unit) locate(first + lu + stride, nxt);
     if (!patch_in_flight) issue_patch(cur, 0);
     patch_in_flight = false;
@@ -359,22 +386,36 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
       // with its first RING - 1 components requested, everything older - this wave's share of the chunk's patches - has landed
 #pragma unroll
       for (int t = 0; t < RING - 1; ++t) issue_b(c, t, ring[t]);
+      W43X_STAMP(1 + 14 * c);
       wait_vm<3 * (RING - 1)>();
+      W43X_STAMP(2 + 14 * c);
       __syncthreads();   // every wave's share; and nobody still reads the V of the previous chunk
+      W43X_STAMP(3 + 14 * c);
       transform(std::integral_constant<int, 0>{});
+      W43X_STAMP(4 + 14 * c);
       __syncthreads();
+      W43X_STAMP(5 + 14 * c);
       mfma_phase(std::integral_constant<int, 0>{}, c, false, cur, 0);
+      W43X_STAMP(6 + 14 * c);
       __syncthreads();
+      W43X_STAMP(7 + 14 * c);
       transform(std::integral_constant<int, 1>{});
+      W43X_STAMP(8 + 14 * c);
       __syncthreads();
+      W43X_STAMP(9 + 14 * c);
       mfma_phase(std::integral_constant<int, 1>{}, c, false, cur, 0);
+      W43X_STAMP(10 + 14 * c);
       __syncthreads();
+      W43X_STAMP(11 + 14 * c);
       transform(std::integral_constant<int, 2>{});
+      W43X_STAMP(12 + 14 * c);
       __syncthreads();   // the patches are free from here on
+      W43X_STAMP(13 + 14 * c);
       // the next patch: this unit's next chunk, or chunk 0 of the next unit
       Blocks tgt = cur;
       if (last_chunk) tgt = nxt;
       mfma_phase(std::integral_constant<int, 2>{}, c, has_patch, tgt, last_chunk ? 0 : c + 1);
+      W43X_STAMP(14 + 14 * c);
     }
     patch_in_flight = has_next_unit;
 
@@ -414,16 +455,26 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
           }
         }
       };
-      if (half == 0) finish(std::integral_constant<int, 0>{});
+      W43X_STAMP(57);
+      if (W43X_DBG(p, 256)) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) Y[a][b] = acc[a % 3][b][0] + acc[b % 3][a][1];
+      } else if (half == 0) finish(std::integral_constant<int, 0>{});
       else finish(std::integral_constant<int, 1>{});
 
+      W43X_STAMP(58);
       // Y -> pixel rows: lane = output channel 16 cg + (lane & 15), tile column tx = lane >> 4, register = tile row ty; both blocks'
       // halves of 8 pixel rows staged through the V space (block `half` by this wave), then row-major epilogue by all threads
-      const int tx = lane >> 4;
-      const int col = ((cg * 16 + (lane & 15)) + 16 * tx) & 63;  // rotated by the tile column: the four tiles of a store hit different banks
-      const int c4 = (tid & 15) * 4;
+      int etid = tid;                          // (made opaque: everything derived from it here is computed here, not carried through the unit)
+      asm volatile("" : "+v"(etid));
+      const int elane = etid & 63;
+      const int tx = elane >> 4;
+      const int col = ((cg * 16 + (elane & 15)) + 16 * tx) & 63;  // rotated by the tile column: the four tiles of a store hit different banks
+      const int c4 = (etid & 15) * 4;
       const int eg = half;                     // pixel block of this thread's epilogue rows
-      const int et = tid & 255;                // ... and its place in it: pixel column et >> 4, channels c4 .. c4 + 3
+      const int et = etid & 255;               // ... and its place in it: pixel column et >> 4, channels c4 .. c4 + 3
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + kb * 64 + c4);
       if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + kb * 64 + c4);
@@ -438,7 +489,9 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
         f32x4 res[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          res[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, row_voff(k), __builtin_amdgcn_readfirstlane(row_offset(k)), 0));
+          res[k] = W43X_DBG(p, 64) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, row_voff(k), __builtin_amdgcn_readfirstlane(row_offset(k)), 0));
+        W43X_STAMP(59 + 2 * h);
         __syncthreads();  // h = 0: the exchange area has been read; h = 1: the first halves have been read
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -470,7 +523,15 @@ __global__ __launch_bounds__(512, 2) void winograd43_x3_kernel(W43XArgs p) {
       }
     }
     cur = nxt;
+    W43X_STAMP(63);
+#ifdef W43_STAMPS
+    ++unit_count;
+#endif
   }
+#ifdef W43_STAMPS
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 2 * 3 * 64) g_w43x_stamps[tid] = stamp_lds[tid];
+#endif
 #endif
 }
 
@@ -521,6 +582,9 @@ std::vector<uint16_t> winograd43_x3_fragments(const std::vector<float>& u, int c
 
 void winograd43_set_debug(int d);
 int winograd43_get_debug();
+#ifdef W43_STAMPS
+void winograd43_x3_read_stamps(long long* out) { OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w43x_stamps), sizeof(g_w43x_stamps))); }
+#endif
 
 void launch_winograd43_x3(const float* x, const void* ufrag, const float* scale, const float* bias, const float* residual,
                           int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s) {

@@ -11,14 +11,15 @@ from ocr_rs_amd import capi, weights as W
 capi.use_test_library()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0)
-x = torch.from_numpy(W.synth_image_batch(1, 32, 640, 640)).cuda()
+NB = int(os.environ.get("W43_BATCH", "32"))
+x = torch.from_numpy(W.synth_image_batch(1, NB, 640, 640)).cuda()
 prob = torch.empty_like(x)
 VARIANTS = [int(v, 0) for v in sys.argv[2:]] or [0, 16]
 acc = {v: {} for v in VARIANTS}
 for r in range(rounds + 1):
     for dbg in VARIANTS:
         capi.test_lib().ocr_test_w43_debug(dbg)
-        for nm, ms, fl, by in det.forward_profile(x.data_ptr(), 32, 640, 640, prob.data_ptr()):
+        for nm, ms, fl, by in det.forward_profile(x.data_ptr(), NB, 640, 640, prob.data_ptr()):
             if r and "winograd43_fused" in nm:
                 e = acc[dbg].setdefault(nm, [0.0, 0])
                 e[0] += ms
