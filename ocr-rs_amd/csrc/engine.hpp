@@ -159,7 +159,8 @@ class Detector {
   float *wino_v_ = nullptr, *wino_m_ = nullptr;  // [(m+2)^2][T][C] and [(m+2)^2][T][K] scratch of the layer in flight
   void add_winograd_weights(ConvW& cw);
   void add_winograd_fused_weights(ConvW& cw);
-  bool winograd43_x3_ = true;    // option winograd43_x3=0: the fused F(4x4,3x3) convs stay on the f32 matrix instructions under mfma=split_bf16
+  bool winograd43_x3_ = false;   // option winograd43_x3=1: the fused F(4x4,3x3) convs on the bf16 matrix cores too (winograd43_x3.hip; measured
+                                 // slower than the f32-MFMA kernel, DESIGN.md section 3 - kept selectable for A/B)
   bool winograd_fused_ = true;   // option winograd_fused=0: direct / unfused-Winograd convs instead of the fused F(4x4,3x3) kernel
   // option mfma=split_bf16 (default) | f32: the MFMA-bound f32 convs without a Winograd kernel of their own (stride-2 3x3,
   // composed FPN phase convs, bin_conv1 over the pyramid, the 36 Winograd GEMMs of layer3 / layer4) run on the bf16 matrix
