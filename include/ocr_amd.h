@@ -205,7 +205,10 @@ int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, i
  * and post-processes the previous batch while the GPU works.  The probability map stays on the device unless
  * prob_host != NULL, which then holds this batch's map once the NEXT call (the one returning its polygons) has returned.
  * x_host may be reused as soon as the call returns only if it is pageable; a pinned buffer must stay untouched until
- * the next call returns.  Finish with x_host = NULL. */
+ * the next call returns.  Finish with x_host = NULL.  Batches may differ in size and element kind from call to call; a
+ * batch that needs larger staging slots than the pending one is enqueued only after the pending batch has been finished
+ * (that one call loses its overlap, results are unchanged).  The staging of this entry point is its own: blocking
+ * ocr_det_forward / ocr_det_forward_u8 calls on host memory between two pipelined calls do not disturb the pending batch. */
 #define OCR_ELEM_F32 0
 #define OCR_ELEM_U8 1
 int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem, int n, int h, int w, float* prob_host,
@@ -217,7 +220,11 @@ int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem
  * mapped back to frame coordinates with adj_xy, is resampled bilinearly to 28 x 28 and divided by
  * 255 (load_image_as_tensor's scaling, image_ops.rs:80-83): crops is n_polygons x 784 f32, ready
  * for ocr_rec_forward / ocr_rec_classify.  frames: N x 1 x H x W f32 (the detector's input).
- * frames and crops share mem_kind; polys and adj_xy are host memory.  Rule: oracle/crop_oracle.py. */
+ * frames and crops share mem_kind; polys and adj_xy are host memory.  Rule: oracle/crop_oracle.py.
+ * Stream order: the crop kernel runs behind everything queued on the detector's stream when the call is made - except,
+ * while a pipelined batch is pending (ocr_det_detect_pipelined*), the forward of that pending batch: the crops of the batch
+ * that has come back are cut beside it, behind whatever was queued before that forward was.  Device frames written by work
+ * queued AFTER the last pipelined call need the caller's own synchronisation. */
 int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, int mem_kind,
                       const ocr_polygons_t* polys, const double* adj_xy, float* crops);
 

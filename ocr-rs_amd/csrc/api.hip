@@ -343,8 +343,13 @@ int ocr_extract_crops(ocr_det_t* det, const float* frames, int n, int h, int w, 
     }
     OCR_HIP(hipSetDevice(det->impl.device()));
     // while a pipelined forward is in flight on the handle's stream the crops of the batch that just came back are cut on
-    // the post-processing stream, beside it (frames and polygons of a finished batch: no ordering against that forward)
-    hipStream_t s = det->impl.has_pending() ? det->impl.post_stream() : det->impl.stream();
+    // the post-processing stream, beside it: ordered behind everything that was queued on the handle's stream BEFORE that
+    // forward (whatever produced these frames), not behind the forward itself
+    hipStream_t s = det->impl.stream();
+    if (det->impl.has_pending()) {
+      s = det->impl.post_stream();
+      if (det->impl.before_forward_event()) OCR_HIP(hipStreamWaitEvent(s, det->impl.before_forward_event(), 0));
+    }
     const size_t fr_bytes = (size_t)n * h * w * 4, bx_bytes = boxes.size() * sizeof(CropBox), cr_bytes = (size_t)np * 784 * 4;
     if (mem_kind == OCR_MEM_DEVICE) {
       char* sc = static_cast<char*>(det->impl.scratch(1, align256(bx_bytes)));
@@ -431,6 +436,7 @@ int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, i
     Detector::Pending next;
     if (x_dev) {
       if (!prob_dev || !adj_xy) fail(OCR_ERR_INVALID, "detect_pipelined: null tensor");
+      d.mark_before_forward();
       d.forward(x_dev, n, h, w, prob_dev, nullptr, 0.f, nullptr);   // enqueue: runs while the previous batch is post-processed
       next.prob = prob_dev;
       next.n = n;
@@ -460,22 +466,39 @@ int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem
     *prev_out = nullptr;
     Detector& d = det->impl;
     OCR_HIP(hipSetDevice(d.device()));
+    // finishing a batch: wait for its forward, send the map home if it was asked for, polygons out
+    auto finish = [&](Detector::Pending& prev) {
+      hipStream_t ps = d.post_stream();
+      OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
+      if (prev.prob_host)   // the caller asked for the map too: it leaves on the same stream, ahead of the bit image
+        OCR_HIP(hipMemcpyAsync(prev.prob_host, prev.prob, (size_t)prev.n * prev.h * prev.w * 4, hipMemcpyDeviceToHost, ps));
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
+    };
     Detector::Pending next;
     if (x_host) {
       if (!adj_xy) fail(OCR_ERR_INVALID, "detect_pipelined_host: null adjust values");
       if (x_elem != OCR_ELEM_F32 && x_elem != OCR_ELEM_U8) fail(OCR_ERR_INVALID, "detect_pipelined_host: element kind %d", x_elem);
       if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32) fail(OCR_ERR_INVALID, "detect_pipelined_host: N=%d H=%d W=%d (H and W must be positive multiples of 32)", n, h, w);
       const size_t es = x_elem == OCR_ELEM_U8 ? 1 : 4, px = (size_t)n * h * w;
-      d.ensure_staging(px * es, px);
+      constexpr int SET = Detector::STAGE_PIPELINED;
+      // a batch that needs larger staging slots than the pending one (more frames, or f32 after u8) frees the slot the pending
+      // batch's map lives in: that batch is finished FIRST (this one call loses its overlap), then the slots grow
+      if (d.staging_would_grow(SET, px * es, px) && d.has_pending()) {
+        Detector::Pending none;
+        Detector::Pending prev = d.swap_pending(none);
+        finish(prev);
+      }
+      d.ensure_staging(SET, px * es, px);
       // this batch's frames into the free input slot (the slot's previous forward was awaited when ITS polygons came back),
       // the forward behind the copy; the map stays on the device
-      const int slot = d.next_stage_slot();
+      const int slot = d.next_stage_slot(SET);
       hipEvent_t arrived;
-      const void* xd = d.stage_input(slot, x_host, px * es, &arrived);
-      d.forward(xd, n, h, w, d.stage_prob(slot), nullptr, 0.f, nullptr, x_elem == OCR_ELEM_U8 ? 1 : 0, arrived);
-      OCR_HIP(hipEventRecord(d.forward_done_event(slot), d.stream()));
-      d.stage_used();
-      next.prob = d.stage_prob(slot);
+      const void* xd = d.stage_input(SET, slot, x_host, px * es, &arrived);
+      d.mark_before_forward();
+      d.forward(xd, n, h, w, d.stage_prob(SET, slot), nullptr, 0.f, nullptr, x_elem == OCR_ELEM_U8 ? 1 : 0, arrived);
+      OCR_HIP(hipEventRecord(d.forward_done_event(SET, slot), d.stream()));
+      d.stage_used(SET);
+      next.prob = d.stage_prob(SET, slot);
       next.prob_host = prob_host;
       next.n = n;
       next.h = h;
@@ -483,17 +506,11 @@ int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem
       next.adj.assign(adj_xy, adj_xy + 2 * (size_t)n);
       ocr_postproc_default_params(&next.params);
       if (params) next.params = *params;
-      next.event = d.forward_done_event(slot);
+      next.event = d.forward_done_event(SET, slot);
       next.valid = true;
     }
     Detector::Pending prev = d.swap_pending(next);
-    if (prev.valid) {
-      hipStream_t ps = d.post_stream();
-      OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
-      if (prev.prob_host)   // the caller asked for the map too: it leaves on the same stream, ahead of the bit image
-        OCR_HIP(hipMemcpyAsync(prev.prob_host, prev.prob, (size_t)prev.n * prev.h * prev.w * 4, hipMemcpyDeviceToHost, ps));
-      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
-    }
+    if (prev.valid) finish(prev);
   });
 }
 

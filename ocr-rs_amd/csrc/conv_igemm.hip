@@ -991,7 +991,8 @@ static void check(const ConvDesc& d) {
     if (!phase2 || d.up != 8 || d.ks != 3 || d.stride != 1 || d.pad != 0 || d.Cin != 64 || d.Cout != 64 || d.Ho != d.Hin ||
         d.Wo != d.Win || d.out2 || d.residual || !d.out || (d.out_bf16 && !d.in_bf16) || d.batch > 1)
       fail(OCR_ERR_INVALID, "%s: PYR4 needs the 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
-    if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 30)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large (2^32 bytes)", d.name);
+    // (rows beyond M are dropped through the out-of-range marker 2^31 as their byte offset: the output must end below it)
+    if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 29)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large (2^31 bytes)", d.name);
     if ((long long)d.wgt_bytes != 64ll * d.Cout * 21 * 64 * ebw) fail(OCR_ERR_INVALID, "%s: PYR4 weight bytes", d.name);
     if ((long long)d.src_bytes >= (1ll << 31)) fail(OCR_ERR_INVALID, "%s: sources must be < 2^31 bytes; split the batch", d.name);
     for (int i = 0; i < 4; ++i) {
@@ -1008,8 +1009,9 @@ static void check(const ConvDesc& d) {
     if (d.up != 2 && d.up != 4 && d.up != 8) fail(OCR_ERR_INVALID, "%s: PHASE store with up = %d", d.name, d.up);
     if (d.ks != 2 || d.stride != 1 || d.pad != 1 || d.Ho != d.Hin || d.Wo != d.Win || d.out2 || d.src_mode != SRC_PLAIN || !d.out)
       fail(OCR_ERR_INVALID, "%s: PHASE store needs a 2x2 s1 pad-1 conv on the low-res grid", d.name);
-    if ((long long)d.N * d.Ho * d.Wo * d.up * d.up * d.Cout >= (1ll << 30))   // the f32 epilogue addresses it through one buffer descriptor
-      fail(OCR_ERR_INVALID, "%s: PHASE output too large (2^32 bytes)", d.name);
+    // the f32 epilogue addresses it through one buffer descriptor and drops rows beyond M through the out-of-range marker 2^31
+    if ((long long)d.N * d.Ho * d.Wo * d.up * d.up * d.Cout >= (1ll << 29))
+      fail(OCR_ERR_INVALID, "%s: PHASE output too large (2^31 bytes)", d.name);
   } else {
     if (d.ks != 1 && d.ks != 3) fail(OCR_ERR_INVALID, "%s: kernel size %d", d.name, d.ks);
     if (d.stride != 1 && d.stride != 2) fail(OCR_ERR_INVALID, "%s: stride %d", d.name, d.stride);

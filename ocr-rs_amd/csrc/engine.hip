@@ -3,6 +3,8 @@
 //   /root/reference/src/char_recognition/model.rs:13-39
 // Weights are re-laid out once at create time (OIHW -> OHWI, eval batch norm folded
 // to per-channel scale/bias); activations live in NHWC f32 workspaces in HBM.
+#include <sched.h>
+
 #include "engine.hpp"
 
 #include <thread>
@@ -528,13 +530,15 @@ Detector::~Detector() {
   free_workspace();
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
-  for (int i = 0; i < 2; ++i) {
-    if (stage_in_[i]) (void)hipFree(stage_in_[i]);
-    if (stage_out_[i]) (void)hipFree(stage_out_[i]);
-    if (ev_in_[i]) (void)hipEventDestroy(ev_in_[i]);
-    if (ev_fwd_[i]) (void)hipEventDestroy(ev_fwd_[i]);
-    if (ev_out_[i]) (void)hipEventDestroy(ev_out_[i]);
-  }
+  for (Staging& st : stage_)
+    for (int i = 0; i < 2; ++i) {
+      if (st.in[i]) (void)hipFree(st.in[i]);
+      if (st.out[i]) (void)hipFree(st.out[i]);
+      if (st.ev_in[i]) (void)hipEventDestroy(st.ev_in[i]);
+      if (st.ev_fwd[i]) (void)hipEventDestroy(st.ev_fwd[i]);
+      if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
+    }
+  if (ev_before_fwd_) (void)hipEventDestroy(ev_before_fwd_);
   if (copy_stream_) {
     (void)hipStreamSynchronize(copy_stream_);
     (void)hipStreamDestroy(copy_stream_);
@@ -544,10 +548,27 @@ Detector::~Detector() {
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
-// CPU share of this process: the cgroup quota where there is one (a container on a big host), else the online cores
+// CPU share of this process: its affinity mask (a rank pinned by taskset / numactl), capped by the cgroup quota where there
+// is one (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us: a container on a big host)
 static int host_cpu_share() {
-  unsigned n = std::thread::hardware_concurrency();
+  unsigned n = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+  if (n == 0) n = std::thread::hardware_concurrency();
   if (n == 0) n = 1;
+  auto read_ll = [](const char* path, long long* v) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) return false;
+    const bool ok = std::fscanf(f, "%lld", v) == 1;
+    std::fclose(f);
+    return ok;
+  };
+  long long q1 = 0, p1 = 0;
+  if (read_ll("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q1) && read_ll("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p1) && q1 > 0 && p1 > 0) {
+    const long long q = q1 / p1;
+    if (q >= 1 && (unsigned)q < n) n = (unsigned)q;
+  }
   if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
     char quota[32] = {0};
     long long period = 0;
@@ -1083,44 +1104,58 @@ const float* Detector::stage(int id, size_t* elems) const {
 // frames cross PCIe into a double-buffered device staging area on a copy stream while the previous piece computes.
 // Pinned host memory (ocr_host_alloc) makes those copies asynchronous and full speed; pageable memory works too (the HIP
 // runtime stages it itself and the call blocks for the duration of each copy).
-void Detector::ensure_staging(size_t in_bytes, size_t prob_elems) {
+void Detector::ensure_staging(int set, size_t in_bytes, size_t prob_elems) {
+  if (set < 0 || set > 1) fail(OCR_ERR_INTERNAL, "staging set %d", set);
+  Staging& st = stage_[set];
   if (!copy_stream_) {
     OCR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     OCR_HIP(hipStreamCreateWithFlags(&out_stream_, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      OCR_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
-      OCR_HIP(hipEventCreateWithFlags(&ev_fwd_[i], hipEventDisableTiming));
-      OCR_HIP(hipEventCreateWithFlags(&ev_out_[i], hipEventDisableTiming));
-    }
   }
-  if (in_bytes > stage_in_bytes_ || prob_elems > stage_elems_) {
+  if (!st.ev_in[0])
+    for (int i = 0; i < 2; ++i) {
+      OCR_HIP(hipEventCreateWithFlags(&st.ev_in[i], hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&st.ev_fwd[i], hipEventDisableTiming));
+      OCR_HIP(hipEventCreateWithFlags(&st.ev_out[i], hipEventDisableTiming));
+    }
+  if (staging_would_grow(set, in_bytes, prob_elems)) {
+    // nothing may still read or write the slots being freed: the pipelined entry point has finished its pending batch (whose
+    // map lives in a slot of set 1) before it comes here; the streams are drained for the copies and forwards in flight
+    if (set == STAGE_PIPELINED && pending_.valid && pending_.prob && (pending_.prob == st.out[0] || pending_.prob == st.out[1]))
+      fail(OCR_ERR_INTERNAL, "staging of the pipelined path grown under its pending batch");
     OCR_HIP(hipStreamSynchronize(stream_));
     OCR_HIP(hipStreamSynchronize(copy_stream_));
     OCR_HIP(hipStreamSynchronize(out_stream_));
+    if (post_stream_) OCR_HIP(hipStreamSynchronize(post_stream_));
     for (int i = 0; i < 2; ++i) {
-      if (stage_in_[i]) OCR_HIP(hipFree(stage_in_[i]));
-      if (stage_out_[i]) OCR_HIP(hipFree(stage_out_[i]));
-      stage_in_[i] = nullptr;
-      stage_out_[i] = nullptr;
+      if (st.in[i]) OCR_HIP(hipFree(st.in[i]));
+      if (st.out[i]) OCR_HIP(hipFree(st.out[i]));
+      st.in[i] = nullptr;
+      st.out[i] = nullptr;
     }
-    stage_in_bytes_ = std::max(in_bytes, stage_in_bytes_);
-    stage_elems_ = std::max(prob_elems, stage_elems_);
+    st.in_bytes = std::max(in_bytes, st.in_bytes);
+    st.elems = std::max(prob_elems, st.elems);
     for (int i = 0; i < 2; ++i) {
-      OCR_HIP(hipMalloc(&stage_in_[i], stage_in_bytes_));
-      OCR_HIP(hipMalloc(reinterpret_cast<void**>(&stage_out_[i]), stage_elems_ * 4));
+      OCR_HIP(hipMalloc(&st.in[i], st.in_bytes));
+      OCR_HIP(hipMalloc(reinterpret_cast<void**>(&st.out[i]), st.elems * 4));
     }
-    stage_uses_ = 0;
+    st.uses = 0;
   }
 }
 
 // frames of the host batch -> staging slot (asynchronous when x is pinned); returns the device pointer and the event
-// that marks their arrival.  The slot's previous user (two pieces ago) must have finished its forward: ev_fwd_.
-const void* Detector::stage_input(int slot, const void* x_host, size_t bytes, hipEvent_t* arrived) {
-  if (stage_uses_ >= 2) OCR_HIP(hipStreamWaitEvent(copy_stream_, ev_fwd_[slot], 0));
-  OCR_HIP(hipMemcpyAsync(stage_in_[slot], x_host, bytes, hipMemcpyHostToDevice, copy_stream_));
-  OCR_HIP(hipEventRecord(ev_in_[slot], copy_stream_));
-  *arrived = ev_in_[slot];
-  return stage_in_[slot];
+// that marks their arrival.  The slot's previous user (two pieces ago) must have finished its forward: ev_fwd.
+const void* Detector::stage_input(int set, int slot, const void* x_host, size_t bytes, hipEvent_t* arrived) {
+  Staging& st = stage_[set];
+  if (st.uses >= 2) OCR_HIP(hipStreamWaitEvent(copy_stream_, st.ev_fwd[slot], 0));
+  OCR_HIP(hipMemcpyAsync(st.in[slot], x_host, bytes, hipMemcpyHostToDevice, copy_stream_));
+  OCR_HIP(hipEventRecord(st.ev_in[slot], copy_stream_));
+  *arrived = st.ev_in[slot];
+  return st.in[slot];
+}
+
+void Detector::mark_before_forward() {
+  if (!ev_before_fwd_) OCR_HIP(hipEventCreateWithFlags(&ev_before_fwd_, hipEventDisableTiming));
+  OCR_HIP(hipEventRecord(ev_before_fwd_, stream_));
 }
 
 void Detector::forward_host(const void* x, int x_u8, int n, int h, int w, float* prob) {
@@ -1129,19 +1164,20 @@ void Detector::forward_host(const void* x, int x_u8, int n, int h, int w, float*
   // pieces of at least 8 frames, at most four of them: the copy in of piece i + 1 and the copy out of piece i - 1 run
   // beside the forward of piece i
   const int piece = std::max(8, (n + 3) / 4);
-  ensure_staging((size_t)piece * frame * es, (size_t)piece * frame);
+  ensure_staging(STAGE_FORWARD, (size_t)piece * frame * es, (size_t)piece * frame);
+  Staging& st = stage_[STAGE_FORWARD];
   int k = 0;
   for (int b = 0; b < n; b += piece, ++k) {
     const int nb = std::min(piece, n - b), slot = k & 1;
     hipEvent_t arrived;
-    const void* xd = stage_input(slot, static_cast<const char*>(x) + (size_t)b * frame * es, (size_t)nb * frame * es, &arrived);
-    if (stage_uses_ >= 2) OCR_HIP(hipStreamWaitEvent(stream_, ev_out_[slot], 0));   // the slot's previous map has left
-    forward(xd, nb, h, w, stage_out_[slot], nullptr, 0.f, nullptr, x_u8, arrived);
-    OCR_HIP(hipEventRecord(ev_fwd_[slot], stream_));
-    OCR_HIP(hipStreamWaitEvent(out_stream_, ev_fwd_[slot], 0));
-    OCR_HIP(hipMemcpyAsync(prob + (size_t)b * frame, stage_out_[slot], (size_t)nb * frame * 4, hipMemcpyDeviceToHost, out_stream_));
-    OCR_HIP(hipEventRecord(ev_out_[slot], out_stream_));
-    ++stage_uses_;
+    const void* xd = stage_input(STAGE_FORWARD, slot, static_cast<const char*>(x) + (size_t)b * frame * es, (size_t)nb * frame * es, &arrived);
+    if (st.uses >= 2) OCR_HIP(hipStreamWaitEvent(stream_, st.ev_out[slot], 0));   // the slot's previous map has left
+    forward(xd, nb, h, w, st.out[slot], nullptr, 0.f, nullptr, x_u8, arrived);
+    OCR_HIP(hipEventRecord(st.ev_fwd[slot], stream_));
+    OCR_HIP(hipStreamWaitEvent(out_stream_, st.ev_fwd[slot], 0));
+    OCR_HIP(hipMemcpyAsync(prob + (size_t)b * frame, st.out[slot], (size_t)nb * frame * 4, hipMemcpyDeviceToHost, out_stream_));
+    OCR_HIP(hipEventRecord(st.ev_out[slot], out_stream_));
+    ++st.uses;
   }
   OCR_HIP(hipStreamSynchronize(out_stream_));
   OCR_HIP(hipStreamSynchronize(stream_));

@@ -73,14 +73,25 @@ class Detector {
                std::vector<ProfileEntry>* prof, int x_u8 = 0, hipEvent_t wait_for = nullptr);
   // host tensors in and out, blocking; copies and forward pipelined over pieces of the batch
   void forward_host(const void* x, int x_u8, int n, int h, int w, float* prob);
-  // device staging of the host-memory entry points: two input slots and two map slots, a copy-in and a copy-out stream
-  void ensure_staging(size_t in_bytes, size_t prob_elems);
-  const void* stage_input(int slot, const void* x_host, size_t bytes, hipEvent_t* arrived);
-  float* stage_prob(int slot) { return stage_out_[slot]; }
+  // device staging of the host-memory entry points: two input slots and two map slots per SET, a copy-in and a copy-out stream.
+  // Set 0 belongs to forward_host, set 1 to ocr_det_detect_pipelined_host, whose pending batch keeps its map in a slot across
+  // calls: neither a blocking host forward in between nor the other set's growth can touch it.  Growing a set frees its
+  // slots: the pipelined entry point finishes its pending batch first (staging_would_grow).
+  enum { STAGE_FORWARD = 0, STAGE_PIPELINED = 1 };
+  bool staging_would_grow(int set, size_t in_bytes, size_t prob_elems) const {
+    return in_bytes > stage_[set].in_bytes || prob_elems > stage_[set].elems;
+  }
+  void ensure_staging(int set, size_t in_bytes, size_t prob_elems);
+  const void* stage_input(int set, int slot, const void* x_host, size_t bytes, hipEvent_t* arrived);
+  float* stage_prob(int set, int slot) { return stage_[set].out[slot]; }
   hipStream_t out_stream() { return out_stream_; }
-  hipEvent_t forward_done_event(int slot) { return ev_fwd_[slot]; }
-  int next_stage_slot() { return (int)(stage_uses_ & 1); }
-  void stage_used() { ++stage_uses_; }
+  hipEvent_t forward_done_event(int set, int slot) { return stage_[set].ev_fwd[slot]; }
+  int next_stage_slot(int set) { return (int)(stage_[set].uses & 1); }
+  void stage_used(int set) { ++stage_[set].uses; }
+  // ocr_extract_crops beside a pipelined forward: everything queued on the handle's stream BEFORE that forward (recorded by the
+  // pipelined entry points just ahead of it) - whatever produced the frames of the batch that has come back
+  void mark_before_forward();
+  hipEvent_t before_forward_event() const { return ev_before_fwd_; }
   int post_threads() const;      // host threads of the post-processing stages (option post_threads, default min(16, CPU share))
   // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results.
   // Growing a slot invalidates only that slot's previous contents.
@@ -195,12 +206,16 @@ class Detector {
   int pipe_ev_next_ = 0;
   void* scratch_[2] = {nullptr, nullptr};
   size_t scratch_bytes_[2] = {0, 0};
-  void* stage_in_[2] = {nullptr, nullptr};
-  float* stage_out_[2] = {nullptr, nullptr};
-  size_t stage_in_bytes_ = 0, stage_elems_ = 0;
-  unsigned long long stage_uses_ = 0;   // pieces staged since the buffers were (re)allocated
+  struct Staging {
+    void* in[2] = {nullptr, nullptr};
+    float* out[2] = {nullptr, nullptr};
+    size_t in_bytes = 0, elems = 0;
+    unsigned long long uses = 0;   // pieces staged since the buffers were (re)allocated
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_fwd[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  };
+  Staging stage_[2];
   hipStream_t copy_stream_ = nullptr, out_stream_ = nullptr;
-  hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_fwd_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};
+  hipEvent_t ev_before_fwd_ = nullptr;
   int post_threads_ = 0;   // option post_threads: 0 = automatic
 };
 

@@ -107,6 +107,39 @@ def test_pipelined_detection_from_host_memory(pinned, u8):
         hb.close()
 
 
+def test_pipelined_host_staging_growth_and_interleaved_host_forward():
+    """A FRESH handle (staging sized by the first pipelined batch), batches that grow from call to call, a switch from u8 to f32
+    frames without a flush (4 x the input bytes) and a blocking host forward between two pipelined calls: the pending batch's
+    map lives in a staging slot across calls, and none of these may free or overwrite it (round-3 advisor finding)."""
+    S = 320
+    params = capi.default_params(skip_degenerate=True)
+    ref = capi.Detector(W.pack_blob(W.make_det_weights_text()), 0)
+    d = capi.Detector(W.pack_blob(W.make_det_weights_text()), 0)
+    pages = [W.synth_text_pages(900 + b, 2 + b, S, S)[0] for b in range(5)]                     # 2, 3, 4, 5, 6 pages: every call grows
+    batches = [np.clip(np.rint(b), 0, 255).astype(np.uint8) if i < 3 else np.rint(b).astype(np.float32) for i, b in enumerate(pages)]
+    want, want_maps = [], []
+    for fr in batches:
+        prob = ref.forward_host(fr.astype(np.float32))
+        want_maps.append(prob)
+        want.append(ref.postprocess(prob, fr.shape[0], S, S, np.ones((fr.shape[0], 2)), capi.MEM_HOST, params))
+    maps = [np.zeros(fr.shape, np.float32) for fr in batches]
+    other = W.synth_image_batch(3, 9, 64, 96)
+    other_want = ref.forward_host(other)
+    got = []
+    for i, fr in enumerate(batches):
+        got.append(d.detect_pipelined_host(fr, adjust_values=np.ones((fr.shape[0], 2)), prob_out=maps[i], params=params))
+        if i == 1:   # a blocking host forward of another shape while batch 1 is pending
+            assert np.array_equal(d.forward_host(other), other_want)
+    got.append(d.detect_pipelined_host(None))
+    assert got[0] is None
+    assert got[1:] == want
+    assert all(sum(len(p) for p in polys) > 0 for polys, _ in want)
+    for m, wm in zip(maps, want_maps):
+        assert np.array_equal(m, wm)
+    d.close()
+    ref.close()
+
+
 def test_post_threads_option(det):
     """post_threads sizes the host pool of the post-processing stages; results do not depend on it."""
     S = 320
