@@ -166,22 +166,28 @@ def make_det_weights_text(gain: float = 0.06, tau: float = 120.0, noise: float =
     return out
 
 
-def synth_text_pages(seed: int, n: int, h: int, w: int):
+def synth_text_pages(seed: int, n: int, h: int, w: int, dense: bool = False):
     """Synthetic pages for the end-to-end path: dark noisy paper (10..50) with a jittered grid of slanted word
-    boxes (190..250), as f32 N x 1 x H x W.  Returns (frames, boxes) with boxes[i] = [(x0, y0, x1, y1), ...]."""
+    boxes (190..250), as f32 N x 1 x H x W.  Returns (frames, boxes) with boxes[i] = [(x0, y0, x1, y1), ...].
+    dense: smaller words on a tighter grid (about 65 per 640 x 640 page instead of 18) - the post-processing stress case."""
     rng = np.random.RandomState(seed)
     frames = np.empty((n, 1, h, w), np.float32)
     yy, xx = np.mgrid[0:h, 0:w]
     boxes = []
+    sy, sx, my, mx = (48, 100, 44, 96) if dense else (80, 168, 64, 150)
     for i in range(n):
         page = rng.randint(10, 51, (h, w)).astype(np.float32)
         bl = []
-        for gy in range(24, h - 64, 80):
-            for gx in range(24, w - 150, 168):
+        for gy in range(24, h - my, sy):
+            for gx in range(24, w - mx, sx):
                 if rng.rand() < 0.15:
                     continue
-                bw, bh = 72 + rng.randint(0, 48), 24 + rng.randint(0, 16)
-                x0, y0 = gx + rng.randint(0, 16), gy + rng.randint(0, 12)
+                if dense:
+                    bw, bh = 44 + rng.randint(0, 28), 16 + rng.randint(0, 10)
+                    x0, y0 = gx + rng.randint(0, 10), gy + rng.randint(0, 6)
+                else:
+                    bw, bh = 72 + rng.randint(0, 48), 24 + rng.randint(0, 16)
+                    x0, y0 = gx + rng.randint(0, 16), gy + rng.randint(0, 12)
                 sl = rng.uniform(-0.08, 0.08)
                 m = (xx >= x0) & (xx < x0 + bw) & (yy >= y0 + sl * (xx - x0)) & (yy < y0 + bh + sl * (xx - x0))
                 page[m] = rng.randint(190, 251, int(m.sum())).astype(np.float32)
