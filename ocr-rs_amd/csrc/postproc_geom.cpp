@@ -38,6 +38,37 @@ static inline int dir_index(int dx, int dy) {
   return -1;
 }
 
+// bits s, s + 1, s + 2 of the bit image (the word behind is touched only when the window reaches into it)
+static inline unsigned get3(const uint32_t* bits, size_t s) {
+  const size_t q = s >> 5;
+  const unsigned sh = (unsigned)(s & 31);
+  unsigned v = bits[q] >> sh;
+  if (sh > 29) v |= bits[q + 1] << (32 - sh);
+  return v & 7u;
+}
+// one step of the border following as a table: [direction of the previous pixel][neighbour byte, bit d = neighbour kDx/kDy[d] is
+// foreground] -> direction of the next border pixel (the first set neighbour counter-clockwise from just after the previous
+// one) | 8 if the E neighbour was examined and found zero before it
+struct StepTable {
+  uint8_t t[8][256];
+  StepTable() {
+    for (int base = 0; base < 8; ++base)
+      for (int m = 0; m < 256; ++m) {
+        int found = 0, right_edge = 0;
+        for (int k = 1; k <= 8; ++k) {
+          const int d = (base - k) & 7;
+          if (m >> d & 1) {
+            found = d;
+            break;
+          }
+          if (d == 4) right_edge = 8;
+        }
+        t[base][m] = (uint8_t)(found | right_edge);
+      }
+  }
+};
+static const StepTable kStep;
+
 // The working grid of the algorithm (0 background, 1 foreground, +-id once a border has passed) is kept as the
 // immutable foreground BIT image plus a label array that only border pixels ever touch: value(x, y) = fg ? (label ?
 // label : 1) : 0.  A pixel can only start a border at the first or last pixel of a horizontal foreground run (its
@@ -47,15 +78,32 @@ static inline int dir_index(int dx, int dy) {
 void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& out) {
   out.clear();
   const size_t npx = (size_t)h * w;
-  int32_t* lab = static_cast<int32_t*>(std::calloc(npx ? npx : 1, sizeof(int32_t)));  // lazily zeroed pages
-  if (!lab) throw std::bad_alloc();
-  struct Free { int32_t* p; ~Free() { std::free(p); } } free_lab{lab};
+  // the label array lives with the calling thread (a pool thread traces image after image) and is all zero between calls:
+  // only border pixels are ever written, and they are put back one by one - no 4 H W bytes of fresh pages per image
+  struct Labels {
+    std::vector<int32_t> lab;
+    std::vector<uint32_t> touched;
+    std::vector<Pt> pts;
+  };
+  thread_local Labels tl;
+  if (tl.lab.size() < npx) tl.lab.assign(npx, 0);
+  int32_t* lab = tl.lab.data();
+  std::vector<uint32_t>& touched = tl.touched;
+  touched.clear();
+  struct Restore {
+    int32_t* lab;
+    std::vector<uint32_t>& touched;
+    ~Restore() {
+      for (uint32_t i : touched) lab[i] = 0;
+    }
+  } restore{lab, touched};
   auto fg = [&](size_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; };
   auto nz = [&](int x, int y) { return x >= 0 && x < w && y >= 0 && y < h && fg((size_t)y * w + x); };
   int border = 1;
   auto trace = [&](int x, int y, int adjx) {
     ++border;
-    std::vector<Pt> pts;
+    std::vector<Pt>& pts = tl.pts;   // grown once per thread; the contour leaves as an exactly sized copy
+    pts.clear();
     const int start = dir_index(adjx - x, 0);
     int p1x = 0, p1y = 0;
     bool found = false;
@@ -69,34 +117,48 @@ void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vec
     }
     if (!found) {
       pts.push_back({x, y});
+      if (lab[(size_t)y * w + x] == 0) touched.push_back((uint32_t)((size_t)y * w + x));
       lab[(size_t)y * w + x] = -border;
     } else {
-      int p2x = p1x, p2y = p1y, p3x = x, p3y = y;
+      int p3x = x, p3y = y;
+      int base = dir_index(p1x - x, p1y - y);   // direction of the previous pixel as seen from the current one
       for (;;) {
         pts.push_back({p3x, p3y});
-        const int base = dir_index(p2x - p3x, p2y - p3y);
         int p4x = 0, p4y = 0;
         bool right_edge = false;
-        for (int k = 1; k <= 8; ++k) {  // counter-clockwise, starting just after dir(p2)
-          const int d = (base - k) & 7;
-          if (nz(p3x + kDx[d], p3y + kDy[d])) {
-            p4x = p3x + kDx[d];
-            p4y = p3y + kDy[d];
-            break;
+        int dn = 0;
+        if (p3x > 0 && p3y > 0 && p3x + 1 < w && p3y + 1 < h) {
+          // interior pixel: the eight neighbours as one byte (three 3-bit windows of the bit image), the search as a table look-up
+          const size_t i3 = (size_t)p3y * w + p3x;
+          const unsigned top = get3(bits, i3 - w - 1), mid = get3(bits, i3 - 1), bot = get3(bits, i3 + w - 1);
+          const unsigned m = (mid & 1u) | (top & 1u) << 1 | (top & 2u) << 1 | (top & 4u) << 1 | (mid & 4u) << 2 | (bot & 4u) << 3 | (bot & 2u) << 5 |
+                             (bot & 1u) << 7;
+          const unsigned st = kStep.t[base][m];   // m != 0: the pixel we came from is a neighbour
+          dn = st & 7;
+          right_edge = (st & 8) != 0;
+        } else {
+          for (int k = 1; k <= 8; ++k) {  // counter-clockwise, starting just after the previous pixel's direction
+            const int d = (base - k) & 7;
+            if (nz(p3x + kDx[d], p3y + kDy[d])) {
+              dn = d;
+              break;
+            }
+            if (d == 4) right_edge = true;  // the E neighbour was examined and is zero
           }
-          if (d == 4) right_edge = true;  // the E neighbour was examined and is zero
         }
+        p4x = p3x + kDx[dn];
+        p4y = p3y + kDy[dn];
         int32_t& cell = lab[(size_t)p3y * w + p3x];
+        if (cell == 0) touched.push_back((uint32_t)((size_t)p3y * w + p3x));
         if (p3x + 1 == w || right_edge) cell = -border;
         else if (cell == 0) cell = border;
         if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
-        p2x = p3x;
-        p2y = p3y;
         p3x = p4x;
         p3y = p4y;
+        base = (dn + 4) & 7;
       }
     }
-    out.push_back(std::move(pts));
+    out.emplace_back(pts.begin(), pts.end());
   };
   // one pixel of the raster scan: outer border start if value == 1 and the W neighbour is 0 (x > 0), else hole border
   // start if value > 0 and the E neighbour is 0 (x + 1 < w)
@@ -446,6 +508,42 @@ void positive_union_outer(const std::vector<Pt>& ring_in, std::vector<Pt>& out) 
   const int n = (int)ring.size();
   if (n < 3) return;
 
+  std::vector<Pt> pts;
+  // Fast path for what an offset word box almost always is - a SIMPLE ring: no two non-adjacent edges meet (not even in a
+  // point), no two adjacent edges are collinear.  Its arrangement is the ring itself: the region left of a positively
+  // oriented ring has winding + 1 (kept whole), a negatively oriented one bounds nothing of positive winding (empty result).
+  // Exact integer tests, O(n^2) for n around 4 .. 10; anything else takes the general arrangement below.
+  bool simple = true;
+  for (int i = 0; i < n && simple; ++i) {
+    const Pt &a = ring[i], &b = ring[(i + 1) % n];
+    const long long d1x = b.x - a.x, d1y = b.y - a.y;
+    for (int j = i + 1; j < n && simple; ++j) {
+      const Pt &c = ring[j], &d = ring[(j + 1) % n];
+      const long long d2x = d.x - c.x, d2y = d.y - c.y;
+      long long den = d1x * d2y - d1y * d2x;
+      const bool adjacent = j == i + 1 || (i == 0 && j == n - 1);
+      if (adjacent) {
+        if (den == 0 || n == 3) simple = den != 0;   // collinear neighbours (a spike or a straight vertex): general path
+        continue;
+      }
+      const long long wx = c.x - a.x, wy = c.y - a.y;
+      if (den == 0) {
+        if (wx * d1y - wy * d1x == 0) simple = false;   // on one line: they may overlap or touch
+        continue;
+      }
+      long long tn = wx * d2y - wy * d2x, un = wx * d1y - wy * d1x;
+      if (den < 0) {
+        den = -den;
+        tn = -tn;
+        un = -un;
+      }
+      if (tn >= 0 && tn <= den && un >= 0 && un <= den) simple = false;
+    }
+  }
+  if (simple) {
+    if (shoelace2(ring) <= 0) return;
+    pts = ring;
+  } else {
   std::map<NodeKey, int> node_id;
   std::vector<long double> node_x, node_y;
   auto get_node = [&](i128 xn, i128 yn, i128 den) {
@@ -558,8 +656,8 @@ void positive_union_outer(const std::vector<Pt>& ring_in, std::vector<Pt>& out) 
       pick = l;
     }
   }
-  std::vector<Pt> pts;
   for (int nd : loops[pick]) pts.push_back({(int)cround((double)node_x[nd]), (int)cround((double)node_y[nd])});
+  }
   // FixupOutPolygon: drop duplicate and collinear vertices
   bool changed = true;
   while (changed && pts.size() >= 3) {

@@ -146,6 +146,31 @@ def test_expand_random_star_polygons_match_oracle():
         assert capi.host_expand_polygon(pts, 2.0)[0] == (O.expand_polygon(pts, 2.0) or [])
 
 
+def test_expand_word_boxes_simple_ring_fast_path_matches_oracle():
+    """Word-sized boxes - what the unclip step sees almost always: their offset ring is simple and takes the union's fast path
+    (postproc_geom.cpp::positive_union_outer).  Both orientations, slanted quads, a straight (collinear) vertex on an edge,
+    pentagons and thin slivers against the oracle's general arrangement."""
+    rnd = random.Random(23)
+    cases = []
+    for _ in range(150):
+        x0, y0 = rnd.randint(20, 500), rnd.randint(20, 500)
+        w, h = rnd.randint(3, 120), rnd.randint(2, 40)
+        sl = rnd.randint(-8, 8)
+        quad = [(x0, y0), (x0 + w, y0 + sl), (x0 + w, y0 + h + sl), (x0, y0 + h)]
+        kind = rnd.randint(0, 3)
+        if kind == 1:
+            quad = quad[::-1]                                           # the other orientation
+        elif kind == 2:
+            quad.insert(1, (x0 + w // 2, y0 + (sl * (w // 2)) // max(w, 1)))   # a (nearly) straight vertex on the top edge
+        elif kind == 3:
+            quad.insert(2, (x0 + w + rnd.randint(1, 9), y0 + sl + h // 2))     # a pentagon
+        if len(set(quad)) == len(quad):
+            cases.append(quad)
+    assert len(cases) > 100
+    for c in cases:
+        assert capi.host_expand_polygon(c, 2.0)[0] == (O.expand_polygon(c, 2.0) or []), c
+
+
 def test_cpp_host_mirror_compiles_and_reports_errors(tmp_path):
     """ocr-rs_amd/host/ocr_rs.hpp (the C++ mirror of the reference's call sites) builds with
     plain g++ against the C ABI and surfaces failures as ocr_rs::Error, not as a crash."""
