@@ -239,6 +239,7 @@ void Detector::parse_options(const char* options) {
     };
     if (key == "winograd_fused") winograd_fused_ = num() != 0;
     else if (key == "winograd43_x3") winograd43_x3_ = num() != 0;
+    else if (key == "out4_fused") out4_fused_ = num() != 0;
     else if (key == "winograd") winograd_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "winograd43") winograd43_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
@@ -342,7 +343,9 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   if (fpn_composed_ && winograd_fused_) {
     add_winograd_fused_weights(fpn_a_[0]);  // p2 lateral term, 64 -> 64 at H/4
     add_winograd_fused_weights(fpn_a_[1]);  // p3 lateral term, 128 -> 64 at H/8
-    add_winograd_fused_weights(out_[2]);    // out4, 256 -> 64 at H/16
+    if (out4_fused_) add_winograd_fused_weights(out_[2]);    // out4, 256 -> 64 at H/16
+    else add_winograd_weights(out_[2]);                      // ... or through the unfused F(4x4,3x3) path of layer3 / layer4
+    if (!out4_fused_) add_winograd_weights(out_[3]);         // out5 (256 -> 64 at H/32) likewise (direct conv: 100 tiles of K = 2304)
   }
   bin1_ = make_conv(wb, "bin_conv1.weight", "bin_bn1", 64, 256, 3);
   if (fpn_composed_) {
@@ -455,6 +458,7 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   }
   if (split_bf16_) {
     for (int l = 1; l < 4; ++l) add_split_weights(layer_[l][0][0]);   // the stride-2 3x3 convs
+    add_split_weights(in_[3]);    // in5 (1x1, 512 -> 256 at H/32): few tiles, long K - MFMA-bound as well (0.040 -> 0.030 ms)
     if (fpn_composed_) {
       for (int l = 0; l < 2; ++l) add_split_weights(fpn_b_[l]);       // phase convs of p2 / p3
       for (int l = 0; l < 3; ++l) add_split_weights(bin_up_[l]);
@@ -984,7 +988,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   conv("in5", in_[3], x_[3], h >> 5, w >> 5, 1, i_[3], false);
   if (fpn_composed_) {
     if (overlap_small) {
-      fork([&] { conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false); });
+      fork([&] { conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false); });   // (side stream: the direct conv, no shared Winograd workspace)
       {
         Extra td;
         td.up_residual = i_[3];
@@ -1001,7 +1005,8 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
         conv("in+topdown", in_[2], x_[2], h >> 4, w >> 4, 1, nullptr, false, td);
       }
       conv3x3("out", out_[2], sum_[2], h >> 4, w >> 4, p_[2], nullptr, false);
-      conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
+      if (out_[3].wino) conv3x3("out5", out_[3], i_[3], h >> 5, w >> 5, p_[3], nullptr, false);
+      else conv("out5", out_[3], i_[3], h >> 5, w >> 5, 1, p_[3], false);
     }
     if (overlap) {
       OCR_HIP(hipEventRecord(ev_side_, side_stream_));
