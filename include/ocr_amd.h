@@ -61,8 +61,12 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
 /* The same with explicit engine options, "key=value;key=value" (NULL or "" = the defaults).  The library never reads
  * the environment: which schedule runs is the caller's choice.  Every combination computes the same graph and is
  * held to the same parity bars (tests/test_gpu_parity.py::test_engine_modes_agree); they exist for A/B measurements.
- *   winograd_fused=0|1   (1)    fused Winograd F(4x4,3x3) kernel (winograd43_fused.hip) for the 3x3 s1 convs with 64, 128 (trunk,
- *                               FPN lateral terms) or 256 (out4) input channels; 0 = direct / unfused-Winograd convs
+ *   winograd_fused=0|1   (1)    fused Winograd F(4x4,3x3) kernel (winograd43_fused.hip) for the 3x3 s1 convs with 64 or 128 input
+ *                               channels (trunk, FPN lateral terms); 0 = direct / unfused-Winograd convs
+ *   out4_fused=0|1       (0)    1 = out4 (256 -> 64 at H/16) on the fused kernel too and out5 as a direct conv; 0 = both through the
+ *                               unfused F(4x4,3x3) path of layer3 / layer4 (faster at these grid sizes)
+ *   winograd43_x3=0|1    (0)    with mfma=split_bf16: 1 = the fused F(4x4,3x3) convs multiply on the bf16 matrix cores as well
+ *                               (winograd43_x3.hip, same error bound); measured slower than the f32-MFMA kernel, kept for A/B
  *   winograd=<cin>|0     (256)  unfused Winograd for 3x3 s1 trunk convs with Cin >= cin that have no fused form; 0 = off
  *   winograd43=<cin>|0   (256)  of those, the layers with Cin >= cin use F(4x4,3x3) (36 products per 16 outputs) instead of
  *                               F(2x2,3x3) (16 per 4); 0 = F(2x2) everywhere
@@ -74,14 +78,20 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               0 = min(16, CPU share of the process: cgroup quota or online cores).  One process per GPU on a
  *                               shared host should pass its share (cores / ranks)
  *   mfma=split_bf16|f32  (split_bf16)  how the f32 precision multiplies in the MFMA-bound convs that have no Winograd kernel
- *                               of their own (stride-2 3x3, FPN phase convs, bin_conv1 over the pyramid, the Winograd GEMMs of
- *                               layer3 / layer4).  split_bf16: every f32 operand as the exact sum of three bf16 terms, six partial
+ *                               of their own (stride-2 3x3, in5, FPN phase convs, bin_conv1 over the pyramid, the Winograd GEMMs of
+ *                               layer3 / layer4, out4 and out5).  split_bf16: every f32 operand as the exact sum of three bf16 terms, six partial
  *                               products per pair on v_mfma_f32_32x32x16_bf16, f32 accumulation - the error of an f32 FMA chain
  *                               (dropped terms <= 2^-23 of a product; profiles/r03_bf16x3_accuracy.txt), the same parity bars, up to
  *                               2.67 x the f32 matrix rate.  f32: every conv on v_mfma_f32_32x32x2_f32 (exact f32 FMA chain).
  *   precision=f32|bf16   (f32)  same as ocr_det_set_precision */
 int ocr_det_create_with_options(const void* weights, size_t weights_bytes, int device, const char* options,
                                 ocr_det_t** out);
+/* Size limit of one launch.  The kernels address every tensor with 32-bit BYTE offsets below the out-of-range marker 2^31
+ * (that marker is how zero padding and ragged tiles are expressed: such a lane reads zeros / its store is dropped), so every
+ * workspace tensor must stay under 2^31 bytes.  The largest one holds N x (H/4) x (W/4) x 256 f32 = 64 N H W bytes: the engine
+ * runs a batch in chunks of floor((2^31 - 1) / (64 H W)) frames - 81 at 640 x 640, 31 at 1024 x 1024, 7 at 2048 x 2048 - one
+ * after the other on the handle's stream.  Results do not depend on the chunking (frames are independent in eval mode;
+ * tests/test_gpu_fullsize.py).  Callers see it only as launch granularity. */
 /* The one-call replacement of `vs.load(file)` (text_detection/mod.rs:41-44): reads the file tch's
  * VarStore::save wrote (utils.rs:55-63) - a libtorch zip archive of named tensors - without libtorch or Python,
  * checks names and shapes against the graph of model.rs:68-105 and builds the detector. */
