@@ -161,6 +161,18 @@ constexpr int PWB = 36;          // bf16 per image row (72 bytes): 32 used
 // X3: the f32 stem on the bf16 matrix cores - the input tile as three bf16 images (pixel = hi + mid + lo exactly), the
 // weights as three fragment sets, six partial products per window (mid.lo, lo.mid, lo.lo are below 2^-23 of a product),
 // f32 accumulate, f32 output: 48 MFMAs of 32 cycles per wave and tile where the exact-f32 kernel above issues 56 of 64.
+#ifdef STEM_STAMPS
+// diagnostic build only (make EXTRA=-DSTEM_STAMPS): s_memtime of one workgroup in the middle of the grid, waves 0 and 3, at the phase
+// boundaries of its four tiles (tools/stem_stamps.py)
+__device__ long long g_stem_stamps[2 * 4 * 8];
+#define STEM_STAMP(k)                                                                                                  \
+  do {                                                                                                                 \
+    if (blockIdx.x == 3 && blockIdx.y == 20 && blockIdx.z == 5 && (wv == 0 || wv == 3) && lane == 0)                   \
+      g_stem_stamps[((wv ? 1 : 0) * 4 + tl) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime();                      \
+  } while (0)
+#else
+#define STEM_STAMP(k) do {} while (0)
+#endif
 template <bool X3, typename TX, typename TO>
 __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x, const u32x4* __restrict__ wfrag,
                                                        const float* __restrict__ scale, const float* __restrict__ bias,
@@ -216,10 +228,12 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
     }
   };
   request(0);
+  bool inexact = false;
   for (int tl = 0; tl < TL; ++tl) {
     const int pw0 = (blockIdx.x * TL + tl) * TPW;
     if (pw0 >= Wp) break;
     const int cc0 = 2 * pw0 - 1;
+    STEM_STAMP(0);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {   // one word = two neighbouring pixels
       const int i = tid + k * NT;
@@ -229,16 +243,24 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const bf16x2 pk = {(__bf16)v0, (__bf16)v1};
       in_s[rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pk);
-      if constexpr (X3) {   // remainders are exact in f32; round to nearest even at every level
+      if constexpr (X3 && sizeof(TX) == 4) {   // remainders are exact in f32; round to nearest even at every level
         const float r0 = v0 - (float)pk[0], r1 = v1 - (float)pk[1];
         const bf16x2 pm = {(__bf16)r0, (__bf16)r1};
         const bf16x2 pl = {(__bf16)(r0 - (float)pm[0]), (__bf16)(r1 - (float)pm[1])};
         in_s[IMG + rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pm);
         in_s[2 * IMG + rr * (PWB / 2) + cp] = __builtin_bit_cast(unsigned, pl);
+        inexact |= (r0 != 0.f) || (r1 != 0.f);
       }
     }
     if (tl + 1 < TL) request(tl + 1);
-    __syncthreads();
+    STEM_STAMP(1);
+    // Raw luma (integers 0 .. 255, what the reference feeds: image_ops.rs:350-364) IS its bf16 value: the mid and lo terms of every
+    // pixel of the tile are zero and the three products they enter are exactly zero - they are skipped, the sum is bit for bit
+    // the same.  u8 frames: statically so; f32 frames: decided per tile with the barrier that publishes it.
+    const bool six = X3 && sizeof(TX) == 4 && __builtin_amdgcn_readfirstlane(__syncthreads_or(inexact)) != 0;
+    if constexpr (!(X3 && sizeof(TX) == 4)) __syncthreads();
+    inexact = false;
+    STEM_STAMP(2);
     {
       const int mt = wv;
       const int pix = min(32 * mt + l31, NPIX - 1);
@@ -261,6 +283,7 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
           constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
+            if (PA[q] != 0 && !six) continue;   // a zero operand plane (workgroup-uniform)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], wreg[PB[q]][0][s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], wreg[PB[q]][1][s], acc1, 0, 0, 0);
           }
@@ -269,6 +292,7 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wreg[0][1][s], acc1, 0, 0, 0);
         }
       }
+      STEM_STAMP(3);
       // a tile whose 9 x 13 conv pixels all lie inside the conv map (every tile but the first row / column of tiles and a
       // ragged last column) needs no validity test: per element two FMA, two max, one paired LDS write - the general
       // form's per-element division, compares and selects were a fifth of this kernel's instructions
@@ -290,7 +314,9 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
         }
       }
     }
+    STEM_STAMP(4);
     __syncthreads();
+    STEM_STAMP(5);
     for (int o = tid; o < TPH * TPW * 16; o += NT) {
       const int c4 = (o & 15) * 4, pp = o >> 4;
       const int py = pp / TPW, px = pp - py * TPW;
@@ -315,6 +341,7 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
         }
       }
     }
+    STEM_STAMP(6);
   }  // tl
 }
 
@@ -475,6 +502,10 @@ void launch_stem_x3(const void* x, int x_u8, const void* wfrag3, const float* sc
                           out, H, W);
   OCR_HIP(hipGetLastError());
 }
+
+#ifdef STEM_STAMPS
+void stem_read_stamps(long long* out) { OCR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stem_stamps), sizeof(g_stem_stamps))); }
+#endif
 
 void launch_convt2_sigmoid(const float* in, const float* w4x64, float bias, float* prob, uint8_t* bitmap,
                            float thresh, int N, int H2, int W2, hipStream_t s) {

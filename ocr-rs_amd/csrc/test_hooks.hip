@@ -13,6 +13,10 @@ namespace ocr { void winograd43_set_debug(int d); }
 #ifdef W43_STAMPS
 namespace ocr { void winograd43_read_stamps(long long* out); void winograd43_x3_read_stamps(long long* out); }
 #endif
+#ifdef STEM_STAMPS
+namespace ocr { void stem_read_stamps(long long* out); }
+extern "C" int ocr_test_stem_stamps(long long* out) { ocr::stem_read_stamps(out); return 0; }
+#endif
 #ifdef WS_STAMPS
 #endif
 
