@@ -992,7 +992,7 @@ static void check(const ConvDesc& d) {
   // x3: f32 activations, weights as three bf16 planes (hi, mid, lo) of the f32 layout -> 6 bytes per weight
   const int ebw = d.x3 ? 6 : eb;
   if (d.x3 && d.src_mode == SRC_PYR4 && d.pyr_nsrc != 3) fail(OCR_ERR_INVALID, "%s: the split-bf16 PYR4 form takes the three upsampled sources only", d.name);
-  if (d.x3 && (d.in_bf16 || d.out_bf16 || d.src_mode == SRC_CAT4 || d.store_mode == STORE_SHUFFLE2 || d.out2))
+  if (d.x3 && (d.in_bf16 || d.out_bf16 || d.src_mode == SRC_CAT4 || d.store_mode == STORE_SHUFFLE2))
     fail(OCR_ERR_INVALID, "%s: the split-bf16 form exists for f32 PLAIN / PYR4 convs with NHWC or PHASE stores", d.name);
   if (d.Cin % bk != 0) fail(OCR_ERR_INVALID, "%s: Cin %d not a multiple of %d", d.name, d.Cin, bk);
   if (d.Cout % 64 != 0) fail(OCR_ERR_INVALID, "%s: Cout %d not a multiple of 64", d.name, d.Cout);
@@ -1167,6 +1167,7 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
     if (d.ks == 3 && d.stride == 1) return launch_x3<3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.ks == 3 && d.stride == 2) return launch_x3<3, 2, SRC_PLAIN, STORE_NHWC>(d, s);
     if (d.ks == 1 && d.stride == 1) return launch_x3<1, 1, SRC_PLAIN, STORE_NHWC>(d, s);
+    if (d.ks == 1 && d.stride == 2) return launch_x3<1, 2, SRC_PLAIN, STORE_NHWC>(d, s);
     fail(OCR_ERR_INVALID, "%s: no split-bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
   }
   if (d.in_bf16) {

@@ -459,6 +459,8 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   if (split_bf16_) {
     for (int l = 1; l < 4; ++l) add_split_weights(layer_[l][0][0]);   // the stride-2 3x3 convs
     add_split_weights(in_[3]);    // in5 (1x1, 512 -> 256 at H/32): few tiles, long K - MFMA-bound as well (0.040 -> 0.030 ms)
+    add_split_weights(in_[2]);    // in4 (1x1, 256 -> 256 at H/16, with the top-down sum as its second output)
+    for (int l = 1; l < 4; ++l) add_split_weights(down_[l]);   // the 1x1 stride-2 downsample convs
     if (fpn_composed_) {
       for (int l = 0; l < 2; ++l) add_split_weights(fpn_b_[l]);       // phase convs of p2 / p3
       for (int l = 0; l < 3; ++l) add_split_weights(bin_up_[l]);
@@ -803,7 +805,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     d.Wo = ex.store == STORE_PHASE ? win : (win + 2 * d.pad - cw.ks) / stride + 1;
     d.Cout = cw.cout;
     d.wgt = in_bf ? cw.w_bf16 : static_cast<const void*>(cw.w);
-    if (!bf && split_bf16_ && cw.w_x3 && !ex.cat4 && !ex.out2 && ex.store != STORE_SHUFFLE2 && !(ex.pyr4 && ex.pyr_nsrc != 3)) {
+    if (!bf && split_bf16_ && cw.w_x3 && !ex.cat4 && ex.store != STORE_SHUFFLE2 && !(ex.pyr4 && ex.pyr_nsrc != 3)) {
       d.x3 = 1;
       d.wgt = cw.w_x3;
       d.wgt_bytes = cw.w_bytes / 4 * 6;
