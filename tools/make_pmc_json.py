@@ -6,8 +6,10 @@ hold FETCH_SIZE and WRITE_SIZE together; no tracing besides --kernel-trace in a 
     write dir : --pmc WRITE_SIZE                                   KiB
     mops dir  : --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16      x 512 = MFMA FLOPs
     busy dir  : --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE     busy share = BUSY / (1024 SIMDs x GUI_ACTIVE / 8 XCDs)
-usage: make_pmc_json.py <f32|bf16> <fetch_dir> <write_dir> <mops_dir> <busy_dir> [round tag, default r03]
-       [<rec_fetch_dir> <rec_write_dir>]
+usage: make_pmc_json.py <f32|bf16> <fetch_dir> <write_dir> <mops_dir> <busy_dir> [round tag, default r04]
+       [<rec_fetch_dir> <rec_write_dir>] [--labels <layers table of tools/profile_layers.py for the same options>]
+--labels: name every dispatch of the forward by its position in the engine's launch order (one kernel per table row) instead of
+by its template arguments alone - several launch kinds share one instantiation (the batched Winograd GEMMs and the 1x1 laterals).
 Per kernel label (bench.py's names) and per launch, second (warm) forward of each run.  The extract is stamped with a hash
 of ocr-rs_amd/csrc (bench.csrc_hash): bench.py marks it stale when the kernel sources change afterwards."""
 import collections
@@ -85,8 +87,16 @@ def load(d, counter):
     return [per[k] for k in sorted(per)]
 
 
+LABELS = None
+
+
 def second_half(rows):
-    return rows[len(rows) // 2:]           # two identical forwards per run: keep the second (warm) one
+    rows = rows[len(rows) // 2:]           # two identical forwards per run: keep the second (warm) one
+    if LABELS is not None:
+        if len(rows) != len(LABELS):
+            raise SystemExit(f"--labels: {len(LABELS)} table rows for {len(rows)} dispatches of a forward")
+        rows = [(lab, val) for lab, (_, val) in zip(LABELS, rows)]
+    return rows
 
 
 def per_label(rows):
@@ -102,8 +112,12 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (csrc_hash)
 
 args = sys.argv[1:]
+if "--labels" in args:
+    i = args.index("--labels")
+    LABELS = [m.group(1) for m in (re.match(r"\s*\d+\s+(\S+)\s+[0-9.]+\s", ln) for ln in open(args[i + 1])) if m]
+    del args[i:i + 2]
 dtype, d_fetch, d_write, d_mops, d_busy = args[:5]
-tag = args[5] if len(args) > 5 else "r03"
+tag = args[5] if len(args) > 5 else "r04"
 fetch = per_label(second_half(load(d_fetch, "FETCH_SIZE")))
 write = per_label(second_half(load(d_write, "WRITE_SIZE")))
 mf32 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_F32")))
