@@ -161,6 +161,10 @@ def pmc_extract(dtype: str, n: int, s: int):
 
 def kernel_peak(name: str, dtype: str):
     """(matrix instruction, executed-FLOP multiplier, dense peak TFLOP/s) of a launch label."""
+    if name.startswith("stem_x3"):
+        # the benchmark's frames are raw luma (integers 0..255: exactly bf16), so every tile takes the stem's exact fast path:
+        # three of the six products have an all-zero operand plane and are skipped (bit-identical sum, stem_tail.hip)
+        return "v_mfma_f32_32x32x16_bf16 x3 (raw-luma pixels are exact in bf16; weights split three ways)", 3.0, BF16_MFMA_PEAK_TFLOPS
     if "_x3" in name:
         return "v_mfma_f32_32x32x16_bf16 x6 (3-way split f32 operands)", 6.0, BF16_MFMA_PEAK_TFLOPS
     if dtype == "bf16" and ("bf16" in name or name.startswith(("stem_", "tail_"))):

@@ -90,9 +90,9 @@ def load(d, counter):
 LABELS = None
 
 
-def second_half(rows):
+def second_half(rows, labelled=True):
     rows = rows[len(rows) // 2:]           # two identical forwards per run: keep the second (warm) one
-    if LABELS is not None:
+    if LABELS is not None and labelled:
         if len(rows) != len(LABELS):
             raise SystemExit(f"--labels: {len(LABELS)} table rows for {len(rows)} dispatches of a forward")
         rows = [(lab, val) for lab, (_, val) in zip(LABELS, rows)]
@@ -144,7 +144,7 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{dtype}.csv"), "w") as fcsv
                                "mfma_busy": None if share is None else round(share, 4)}
         fcsv.write(f'"{k}",{n},{f * 1024 * 2 / n:.0f},{w * 1024 / n:.0f},{ff / n:.0f},{fb / n:.0f},{"" if share is None else f"{share:.4f}"}\n')
 if len(args) > 7:   # recogniser passes (tools/profile_rec.py 65536): fetch dir, write dir
-    rf, rw = per_label(second_half(load(args[6], "FETCH_SIZE"))), per_label(second_half(load(args[7], "WRITE_SIZE")))
+    rf, rw = per_label(second_half(load(args[6], "FETCH_SIZE"), False)), per_label(second_half(load(args[7], "WRITE_SIZE"), False))
     entry["recogniser_b65536"] = {("rec_fc1" if k.startswith("conv_igemm") else k): {"launches": n, "hbm_bytes": round((f * 1024 * 2 + rw.get(k, [0.0, n])[0] * 1024) / n)}
                                   for k, (f, n) in rf.items()}
 path = os.path.join(ROOT, "profiles", "pmc.json")
