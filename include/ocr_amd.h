@@ -271,7 +271,12 @@ void ocr_rec_destroy(ocr_rec_t* rec);
 int ocr_rec_set_stream(ocr_rec_t* rec, void* hip_stream);
 int ocr_rec_synchronize(ocr_rec_t* rec);
 
-/* forward_t: crops N x 784 (28x28, values in [0,1]) -> logits N x 62.  Blocking. */
+/* forward_t: crops N x 784 (28x28, values in [0,1]) -> logits N x 62.  Blocking.
+ * Batch-size invariance: batches of up to 1 024 crops and larger ones take different kernels (latency- against throughput-
+ * optimised; the small-batch conv2 multiplies on the bf16 matrix cores from three-way split f32 operands).  Within a family a crop's
+ * logits are bit-identical whatever batch it arrives in; across the two they agree to rounding (|dlogit| < 1e-4, |dp| < 1e-6:
+ * tests/test_gpu_fullsize.py), so a crop whose two best classes tie within that margin may change label when the batch size
+ * crosses 1 024.  The reference itself gives no stronger guarantee (ATen's kernels differ with batch size too). */
 int ocr_rec_forward(ocr_rec_t* rec, const float* crops, int n, float* logits, int mem_kind);
 /* forward_t + softmax(-1, f64) + top-1: label index into VALUES (utils.rs:7) and
  * its probability.  logits may be NULL.  Device pointers; enqueues and returns. */
