@@ -366,6 +366,9 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
     "overlap=1", "overlap=2",                                      # second-stream schedules
     "mfma=f32",                                                    # every conv on the exact-f32 MFMA (no split-bf16 kernels)
     "mfma=f32;bin_pyr=0",
+    "winograd43_x3=1",                                             # the fused F(4x4) convs on the bf16 matrix cores too (winograd43_x3.hip)
+    "out4_fused=1",                                                # out4 on the fused kernel, out5 as a direct conv
+    "winograd43_x3=1;out4_fused=1",                                # ... out4 through the 256-channel instantiation of winograd43_x3.hip
 ])
 def test_engine_modes_agree(det, det_w, options):
     """Every graph-level option of the engine (ocr_det_create_with_options) computes the same
