@@ -357,6 +357,31 @@ def test_composed_fpn_matches_layerwise_graph(det, det_w, monkeypatch):
         det.debug_stage(5, (n, h // 4, w // 4, 256))
 
 
+def test_stem_exact_and_inexact_tiles(det, det_w):
+    """The split-bf16 stem skips the products of the mid / lo operand planes in tiles whose pixels are all exactly bf16 (raw luma) and
+    runs all six elsewhere, decided per tile: a frame that is integer-valued on the left and has fractional pixels on the right (plus
+    one lone fractional pixel in the integer part) against the oracle and against the exact-f32 engine."""
+    n, h, w = 2, 128, 192
+    x = W.synth_image_batch(61, n, h, w)
+    rng = np.random.default_rng(61)
+    x[:, :, :, w // 2:] += rng.random((n, 1, h, w - w // 2), dtype=np.float32)            # 24-bit mantissas
+    x[0, 0, 37, 11] += np.float32(0.3)
+    got = det.forward_host(x)
+    assert np.abs(got - T.det_forward(det_w, x)).max() < TOL
+    f32 = capi.Detector(W.pack_blob(det_w), 0, options="mfma=f32")
+    try:
+        assert np.abs(got - f32.forward_host(x)).max() < 1e-5
+    finally:
+        f32.close()
+    stem = det.debug_stage(0, (n, h // 4, w // 4, 64))
+    stages = {}
+    T.det_forward(det_w, x, stages)
+    ref = stages["stem"]
+    if stem.shape != ref.shape:
+        stem = np.transpose(stem, (0, 3, 1, 2))
+    assert np.abs(stem - ref).max() / np.abs(ref).max() < 2e-5
+
+
 @pytest.mark.parametrize("options", [
     "winograd_fused=0",                                            # direct convs on the large grids, unfused Winograd layer3/4
     "winograd=0;winograd_fused=0",                                 # no Winograd at all
