@@ -269,14 +269,20 @@ int ocr_rec_create(const void* weights, size_t weights_bytes, int device, ocr_re
 int ocr_rec_create_from_varstore(const char* path, int device, ocr_rec_t** out);
 void ocr_rec_destroy(ocr_rec_t* rec);
 int ocr_rec_set_stream(ocr_rec_t* rec, void* hip_stream);
+/* Options, "key=value;key=value" (NULL or "" changes nothing; an unknown key is OCR_ERR_INVALID):
+ *   small_batch=0|1   1 (default): batches of up to 1 024 crops take the latency-optimised kernels (see ocr_rec_forward);
+ *                     0: every batch takes the throughput kernels, every multiply on the f32 matrix instructions - a
+ *                     crop's logits are then bit-identical whatever the size of the batch it arrives in. */
+int ocr_rec_set_options(ocr_rec_t* rec, const char* options);
 int ocr_rec_synchronize(ocr_rec_t* rec);
 
 /* forward_t: crops N x 784 (28x28, values in [0,1]) -> logits N x 62.  Blocking.
  * Batch-size invariance: batches of up to 1 024 crops and larger ones take different kernels (latency- against throughput-
  * optimised; the small-batch conv2 multiplies on the bf16 matrix cores from three-way split f32 operands).  Within a family a crop's
- * logits are bit-identical whatever batch it arrives in; across the two they agree to rounding (|dlogit| < 1e-4, |dp| < 1e-6:
+ * logits are bit-identical whatever batch it arrives in; across the two they agree to rounding (|dlogit| < 1e-4, |dp| < 1e-5:
  * tests/test_gpu_fullsize.py), so a crop whose two best classes tie within that margin may change label when the batch size
- * crosses 1 024.  The reference itself gives no stronger guarantee (ATen's kernels differ with batch size too). */
+ * crosses 1 024 (ocr_rec_set_options "small_batch=0" removes the distinction).  The reference itself gives no stronger
+ * guarantee (ATen's kernels differ with batch size too). */
 int ocr_rec_forward(ocr_rec_t* rec, const float* crops, int n, float* logits, int mem_kind);
 /* forward_t + softmax(-1, f64) + top-1: label index into VALUES (utils.rs:7) and
  * its probability.  logits may be NULL.  Device pointers; enqueues and returns. */

@@ -28,7 +28,7 @@ EXPORTS = [
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_det_detect_pipelined", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
-    "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_synchronize",
+    "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_set_options", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet",
     "ocr_comm_unique_id", "ocr_comm_rccl_version", "ocr_comm_create", "ocr_comm_destroy",
     "ocr_comm_all_gather_polygons", "ocr_comm_all_gather_labels",
@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
         L.ocr_rec_destroy.restype = None
         L.ocr_rec_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.ocr_rec_synchronize.argtypes = [C.c_void_p]
+        L.ocr_rec_set_options.argtypes = [C.c_void_p, C.c_char_p]
         L.ocr_rec_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.ocr_rec_classify_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ocr_rec_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -532,12 +533,15 @@ class Recognizer:
     """Owns an ocr_rec_t.  Mirrors `Net::new(&weights.root())` + `weights.load(..)`
     (/root/reference/src/char_recognition/mod.rs:44-46)."""
 
-    def __init__(self, weights_blob: Optional[bytes], device: int = 0, varstore_path: Optional[str] = None):
+    def __init__(self, weights_blob: Optional[bytes], device: int = 0, varstore_path: Optional[str] = None,
+                 options: Optional[str] = None):
         self._h = C.c_void_p()
         if varstore_path is not None:
             check(lib().ocr_rec_create_from_varstore(os.fsencode(varstore_path), device, C.byref(self._h)))
         else:
             check(lib().ocr_rec_create(weights_blob, len(weights_blob), device, C.byref(self._h)))
+        if options:
+            self.set_options(options)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
@@ -555,6 +559,10 @@ class Recognizer:
 
     def synchronize(self) -> None:
         check(lib().ocr_rec_synchronize(self._h))
+
+    def set_options(self, options: str) -> None:
+        """`small_batch=0`: every batch on the throughput kernels (bit-exact batch-size invariance)."""
+        check(lib().ocr_rec_set_options(self._h, options.encode()))
 
     def forward_host(self, crops: np.ndarray) -> np.ndarray:
         crops = np.ascontiguousarray(crops, dtype=np.float32).reshape(-1, 784)

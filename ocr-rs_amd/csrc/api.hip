@@ -541,6 +541,12 @@ int ocr_rec_set_stream(ocr_rec_t* rec, void* s) {
     rec->impl.set_stream(static_cast<hipStream_t>(s));
   });
 }
+int ocr_rec_set_options(ocr_rec_t* rec, const char* options) {
+  return guard([&] {
+    if (!rec) ocr::fail(OCR_ERR_INVALID, "null handle");
+    rec->impl.set_options(options);
+  });
+}
 int ocr_rec_synchronize(ocr_rec_t* rec) {
   return guard([&] {
     if (!rec) ocr::fail(OCR_ERR_INVALID, "null handle");

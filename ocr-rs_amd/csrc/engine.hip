@@ -1231,6 +1231,25 @@ void Recognizer::synchronize() {
   OCR_HIP(hipStreamSynchronize(stream_));
 }
 
+// small_batch=0|1: whether batches of up to kRecSmallBatch crops take the latency-optimised kernels (default) or the same
+// kernels as larger batches - then a crop's logits are bit-identical whatever the size of the batch it arrives in.
+void Recognizer::set_options(const char* options) {
+  if (!options) return;
+  std::string s(options);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find_first_of(";,", pos);
+    if (end == std::string::npos) end = s.size();
+    std::string item = s.substr(pos, end - pos);
+    pos = end + 1;
+    item.erase(std::remove_if(item.begin(), item.end(), [](char c) { return c == ' ' || c == '\t'; }), item.end());
+    if (item.empty()) continue;
+    if (item == "small_batch=0") small_batch_ = false;
+    else if (item == "small_batch=1") small_batch_ = true;
+    else fail(OCR_ERR_INVALID, "unknown recogniser option '%s' (small_batch=0|1)", item.c_str());
+  }
+}
+
 void Recognizer::ensure_workspace(int n) {
   if (n <= ws_cap_) return;
   OCR_HIP(hipStreamSynchronize(stream_));
@@ -1251,7 +1270,7 @@ void Recognizer::classify(const float* crops, int n, float* logits, int32_t* lab
     const int nb = std::min(kChunk, n - b);
     ensure_workspace(nb);
     Recorder rec(prof, stream_);
-    const bool small = rec_small_batch(nb);
+    const bool small = small_batch_ && rec_small_batch(nb);
     if (small) {
       // configs[2]-sized batches: three launches built for latency (split-bf16 conv2, K-split fc1, 16-crop fc2 tiles)
       rec.begin();

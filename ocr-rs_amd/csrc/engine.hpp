@@ -227,6 +227,8 @@ class Recognizer {
   ~Recognizer();
   void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
   void synchronize();
+  // "key=value;..." (include/ocr_amd.h, ocr_rec_set_options): small_batch=0 keeps every batch on the throughput kernels
+  void set_options(const char* options);
   // device pointers; enqueues on the stream.  prof != null -> per-launch events (as Detector::forward)
   void classify(const float* crops_dev, int n, float* logits_dev, int32_t* labels_dev, double* probs_dev,
                 std::vector<ProfileEntry>* prof = nullptr);
@@ -244,6 +246,7 @@ class Recognizer {
   void ensure_workspace(int n);
   float *feat_ = nullptr, *hid_ = nullptr;  // [cap][1024], [cap][512]
   int ws_cap_ = 0;
+  bool small_batch_ = true;  // batches of up to kRecSmallBatch crops take the latency-optimised kernels
 };
 
 void check_device(int device);

@@ -105,6 +105,33 @@ def test_config2_recognition_4096_crops():
     rec.close()
 
 
+def test_recognition_small_batch_off_is_bit_exact_across_batch_sizes():
+    """`ocr_rec_set_options("small_batch=0")`: every batch takes the throughput kernels (f32 matrix instructions, one k-ordered
+    FMA chain per dot product whatever the tile shape), so a crop's logits, label and probability are BIT-identical whether it
+    arrives alone, in a configs[2]-sized batch or among thousands; results still match the oracle; unknown options are refused."""
+    rw = W.make_rec_weights(0)
+    rec = capi.Recognizer(W.pack_blob(rw), 0, options="small_batch=0")
+    crops = W.synth_crops(6, 4096)
+    logits = rec.forward_host(crops)
+    labels, probs = rec.classify_host(crops)
+    for lo, hi in ((100, 101), (40, 296), (3, 8), (0, 1025), (1100, 3100)):
+        lg = rec.forward_host(crops[lo:hi])
+        lb, pb = rec.classify_host(crops[lo:hi])
+        assert np.array_equal(lg, logits[lo:hi]), (lo, hi)
+        assert np.array_equal(lb, labels[lo:hi]) and np.array_equal(pb, probs[lo:hi]), (lo, hi)
+    sub = np.arange(0, 4096, 97)
+    assert np.abs(logits[sub] - T.rec_forward(rw, crops[sub])).max() < TOL
+    # back to the default: the latency kernels again (same results to rounding)
+    rec.set_options("small_batch=1")
+    l1, p1 = rec.classify_host(crops[40:296])
+    assert np.abs(p1 - probs[40:296]).max() < 1e-5   # 1.8e-6 observed over these 256 crops
+    with pytest.raises(capi.OcrError):
+        rec.set_options("small_batch=2")
+    with pytest.raises(capi.OcrError):
+        rec.set_options("latency=0")
+    rec.close()
+
+
 def test_recognition_large_batch_chunks_and_batch_independence():
     """65 536 + 19 crops: two passes of the recogniser's workspace (Recognizer::kChunk), the last one ragged.
     Size-independent property: a crop's label and probability do not depend on the batch around it (every dot
