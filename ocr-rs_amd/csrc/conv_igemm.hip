@@ -186,7 +186,13 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   constexpr int EBW = X3 ? 2 : EB;            // bytes per weight element (X3: bf16 planes)
   constexpr int BK = ROWB / EB;               // K elements per LDS row / K-step
   constexpr bool BF16 = EB == 2;
-  constexpr int A_BYTES = BM * ROWB;
+  // TS (tap sharing; bf16 3x3 stride-1 convs): the A operand of the three taps of a kernel row is ONE run of BM + 2 consecutive
+  // input pixels (linear order over N x H x W), staged once and read at a row shift of kw; pixels that the linear order drags in
+  // across a row / image boundary are zeroed in the fragment registers.  A third of the activation gathers of the tap-by-tap
+  // form - the part of the operand traffic that costs (weights: contiguous, L2-resident, free in the ablation).
+  constexpr bool TS = BF16 && !X3 && KS == 3 && STRIDE == 1 && SRC == SRC_PLAIN && STORE != STORE_PHASE;
+  constexpr int A_ROWS = TS ? BM + 8 : BM;   // TS: rows 0 .. BM + 1 hold the run (pixel m0 - 1 + row), up to BM + 7 are DMA granularity
+  constexpr int A_BYTES = A_ROWS * ROWB;
   constexpr int B_BYTES = X3 ? 3 * BN * 64 : BN * ROWB;   // X3: three bf16 planes of BN rows x 32 k (64-byte rows)
   constexpr int STAGE = A_BYTES + B_BYTES;    // bytes per LDS stage
   static_assert(!X3 || (BM == 128 && EB == 4 && (BN == 64 || BN == 128) && MT == 1), "X3 tile shapes");
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       for (int i = 0; i < AI; ++i) avoff[t][i] = tap_offset(s, t, i);
     }
   };
-  if constexpr (!(X3 && SRC == SRC_PYR4)) prep_source(0);
+  if constexpr (!(X3 && SRC == SRC_PYR4) && !TS) prep_source(0);
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds + (unsigned)(8 * wave * ROWB);
   auto issue_plain = [&](int stage, const unsigned (&av)[AI], int tap, int c, int kbase) {
     const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE));
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
           dma16(b_rsrc, sb + (unsigned)(pl * BN * 64 + i * 64 * 64), bvoff[i], (int)(pl * plane_bytes) + (tap * p.Cin + kbase) * EBW + c * 64);
     } else {
 #pragma unroll
-      for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (BM + 32 * i) * ROWB, bvoff[i], (tap * p.Cin + kbase) * EB + c * ROWB);
+      for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (A_ROWS + 32 * i) * ROWB, bvoff[i], (tap * p.Cin + kbase) * EB + c * ROWB);
     }
   };
 
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) xoff[g] = ((2 * g + (lane >> 5)) ^ fsw) * 16;
   const int a_row = (wm * WM + frow) * ROWB;
-  const int b_row = (BM + wn * WN + frow) * ROWB;
+  const int b_row = (A_ROWS + wn * WN + frow) * ROWB;
 
   // X3 B fragment: row (lane & 31) of column tile j, chunk 2 kk + (lane >> 5) in slot chunk ^ f(row)
   const int bx_row = A_BYTES + frow * 64;
@@ -701,6 +707,101 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       par ^= 1;
     }
     __syncthreads();
+  } else if constexpr (TS) {
+    // ---- tap-sharing loop.  Steps (channel chunk c, kernel row kh, kernel column kw); B stage = step parity, A stage = run parity
+    // (run = (c, kh), three steps).  The next run is requested in three pieces over the steps of the current one, the next
+    // step's weights at every step; one barrier per step as in the plain loop.
+    // run row j <-> input pixel m0 - 1 + j + (kh - 1) W of the linear order; everything that may be negative sits in the voffset
+    // (the range check covers the voffset only: a negative or too large one reads as zeros), the chunk in the soffset
+    int tsv[AI + 1];
+#pragma unroll
+    for (int i = 0; i <= AI; ++i) {
+      const int j = i < AI ? r + 32 * i : BM + (tid >> 3);   // the last instruction (rows BM ..) is wave 0's
+      tsv[i] = ((m0 - 1 + j) * p.Cin) * EB + gq * 16;
+    }
+    const int kh_bytes = p.Win * p.Cin * EB;
+    // validity of tap (kh, kw) for this lane's fragment rows: bit 3 kh + kw
+    unsigned vmask[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WM + i * 32 + frow;
+      vmask[i] = 0;
+      if (m < p.M) {
+        const int n = fast_div(m, p.mg_howo, p.sh_howo);
+        const int rem = m - n * HoWo;
+        const int oh = fast_div(rem, p.mg_wo, p.sh_wo);
+        const int ow = rem - oh * p.Wo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if ((unsigned)(oh + t / 3 - 1) < (unsigned)p.Hin && (unsigned)(ow + t % 3 - 1) < (unsigned)p.Win) vmask[i] |= 1u << t;
+      }
+    }
+    const unsigned a_dst = lds_base;                                                                   // + stage * STAGE + 32 i ROWB
+    const unsigned x_dst = (unsigned)(size_t)(lds_void*)lds + (unsigned)(BM * ROWB);                   // rows BM .. BM + 7
+    auto issue_a_piece = [&](int stage, int kh, int c, int kw) {   // piece kw of the run's AI (+ 1 for wave 0) instructions
+      const int khb = (kh - 1) * kh_bytes;
+#pragma unroll
+      for (int i = 0; i <= AI; ++i) {
+        if ((i * 3) / (AI + 1) != kw) continue;   // uniform
+        if (IGEMM_DBG(p, 1)) continue;
+        if (i < AI) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(a_dst + (unsigned)(stage * STAGE + 32 * i * ROWB)), (unsigned)(tsv[i] + khb), c * ROWB);
+        else if (wave == 0) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(x_dst + (unsigned)(stage * STAGE)), (unsigned)(tsv[i] + khb), c * ROWB);
+      }
+    };
+    auto issue_b = [&](int stage, int tap, int c) {
+      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE));
+#pragma unroll
+      for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (A_ROWS + 32 * i) * ROWB, bvoff[i], (tap * p.Cin) * EB + c * ROWB);
+    };
+    auto compute_ts = [&](int a_stage, int b_stage, int kw, int tap) {
+      const unsigned char* sa = lds + a_stage * STAGE + a_row + kw * ROWB;
+      const unsigned char* sb = lds + b_stage * STAGE;
+      const int fk = ((frow + kw) >> 1) & 7;
+      const unsigned bit = 1u << tap;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 af[MT], bf[NT];
+        const int xa = ((2 * g + (lane >> 5)) ^ fk) * 16;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * ROWB + xa);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + b_row + j * 32 * ROWB + xoff[g]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          if (!(vmask[i] & bit)) af[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // a pixel of another row / image / beyond the border
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      }
+    };
+    issue_a_piece(0, 0, 0, 0);
+    issue_a_piece(0, 0, 0, 1);
+    issue_a_piece(0, 0, 0, 2);
+    issue_b(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int run = 0, bpar = 0;
+    for (int c = 0; c < csteps; ++c) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh, ++run) {
+        const bool more_runs = kh < 2 || c + 1 < csteps;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = 3 * kh + kw;
+          // the next step's weights, a third of the next run
+          if (kw < 2) issue_b(bpar ^ 1, tap + 1, c);
+          else if (kh < 2) issue_b(bpar ^ 1, tap + 1, c);
+          else if (c + 1 < csteps) issue_b(bpar ^ 1, 0, c + 1);
+          if (more_runs) issue_a_piece((run + 1) & 1, kh < 2 ? kh + 1 : 0, kh < 2 ? c : c + 1, kw);
+          compute_ts(run & 1, bpar, kw, tap);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          bpar ^= 1;
+        }
+      }
+    }
   } else {
   issue_plain(0, avoff[0], 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

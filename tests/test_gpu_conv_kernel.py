@@ -77,6 +77,14 @@ CASES = [
     (1, 12, 12, 512, 256, 1, 1, False, False, False, False, True),  # in5
     (4, 256, 256, 64, 64, 3, 1, True, True, False, True, True),     # full-size tile (128x64) and XCD remap
     (8, 128, 128, 128, 256, 1, 1, False, False, True, False, True), # 128x128 tile with both outputs
+    # 3x3 stride-1 convs with 128 / 256 output channels: in bf16 the tap-sharing loop (one staged run of pixels for the three taps
+    # of a kernel row, out-of-row pixels zeroed in registers) on 128 x 128 and 128 x 64 tiles
+    (2, 20, 20, 256, 256, 3, 1, True, True, False, True, True),     # layer4-like: tiles span image rows and the image boundary
+    (3, 5, 3, 128, 128, 3, 1, True, False, False, False, True),     # rows of 3 pixels: a run wraps a row every third pixel
+    (1, 1, 1, 64, 128, 3, 1, False, False, False, False, True),     # a single pixel: every tap but the centre is padding
+    (2, 33, 17, 128, 256, 3, 1, True, True, False, True, True),     # odd grid, M = 1122: partial last tile
+    (1, 40, 128, 128, 128, 3, 1, False, False, False, True, True),  # rows as long as a tile: every tile starts at a row start
+    (1, 7, 130, 64, 192, 3, 1, True, False, False, True, True),     # rows of BM + 2 pixels, Cout = 192 (128 x 64 tiles)
 ]
 
 

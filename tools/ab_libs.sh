@@ -1,10 +1,10 @@
 #!/bin/bash
 # A/B of two builds of the library on ONE box: the layer table of each, alternating, three rounds.
-#   tools/ab_libs.sh <libdir A> <libdir B>   (directories under ocr-rs_amd/, e.g. lib_base lib)
-A=$1; B=$2; O=gpurun_out/ab; mkdir -p $O
+#   tools/ab_libs.sh <libdir A> <libdir B> [engine options]   (directories under ocr-rs_amd/, e.g. lib_base lib)
+A=$1; B=$2; OPT=$3; O=gpurun_out/ab; mkdir -p $O
 for r in 1 2 3; do
-  OCR_AMD_LIB=ocr-rs_amd/$A/libocr_amd.so timeout -k 10 200 python3 tools/profile_layers.py 32 640 5 > $O/a$r.txt 2>&1 || exit 1
-  OCR_AMD_LIB=ocr-rs_amd/$B/libocr_amd.so timeout -k 10 200 python3 tools/profile_layers.py 32 640 5 > $O/b$r.txt 2>&1 || exit 1
+  OCR_AMD_LIB=ocr-rs_amd/$A/libocr_amd.so timeout -k 10 200 python3 tools/profile_layers.py 32 640 5 0 "$OPT" > $O/a$r.txt 2>&1 || exit 1
+  OCR_AMD_LIB=ocr-rs_amd/$B/libocr_amd.so timeout -k 10 200 python3 tools/profile_layers.py 32 640 5 0 "$OPT" > $O/b$r.txt 2>&1 || exit 1
 done
 python3 - $O <<'PY'
 import sys, re, collections
