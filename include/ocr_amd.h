@@ -72,6 +72,8 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               F(2x2,3x3) (16 per 4); 0 = F(2x2) everywhere
  *   fpn_unfused=0|1      (0)    1 = layer-by-layer FPN (laterals, top-down sums, out_k, gathered bin_conv1) as model.rs writes it
  *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)
+ *   pyr_p2_direct=0|1    (1)    bf16 precision only: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv on top of the phase
+ *                               launch over p5, p4, p3 (0: all four sources in the phase launch)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches
  *   overlap=0|1|2        (0)    second stream for small independent launches (1) and the FPN branch (2)
  *   post_threads=<n>     (0)    host threads of the post-processing stages (contours, unclip), the calling thread included;

@@ -244,6 +244,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "winograd43") winograd43_min_cin_ = num() > 0 ? num() : (1 << 30);
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
+    else if (key == "pyr_p2_direct") pyr_p2_direct_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") overlap_ = num();
     else if (key == "post_threads") {
@@ -1035,7 +1036,18 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     py.pyr4 = true;
     py.store = STORE_PHASE;
     py.f32_out = !bf;  // bf16 precision: the fused head reads bf16
-    if (bf) {
+    if (bf && bin_p2_.w_bf16_c64 && pyr_p2_direct_) {
+      // bf16: the three upsampled sources in the phase launch, p2's 3x3 term on top as the patch-staged 64 -> 64 conv (bias + ReLU
+      // there).  p2's nine taps are more than half of the phase launch's gathers (one pixel row per cell, tap and phase - the part
+      // of that launch that costs); the direct kernel stages every p2 pixel once.  The partial sum passes through bf16 once more.
+      py.pyr_nsrc = 3;
+      ConvW up3 = bin_pyr_;
+      up3.bias = nullptr;
+      conv("bin_conv1.pyramid", up3, p_[3], h >> 5, w >> 5, 1, b1_, false, py);
+      ConvW p2 = bin_p2_;
+      p2.bias = bin1_.bias;
+      conv3x3("bin_conv1.p2", p2, p_[0], h4, w4, b1_, b1_, true);
+    } else if (bf) {
       // all four sources in the one phase launch (112.8 GF instead of the gathered conv's 241.6), bias + ReLU in its epilogue
       conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
     } else if (bin_p2_.wino43_fused) {

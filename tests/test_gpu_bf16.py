@@ -76,3 +76,23 @@ def test_bf16_postprocess_runs_on_f32_map(det):
     prob = det.forward_host(x)
     polys, scores = det.postprocess(prob, 2, 128, 128, np.ones((2, 2)), capi.MEM_HOST, capi.default_params(True))
     assert len(polys) == 2 and len(scores) == 2
+
+
+def test_bf16_bin_conv1_forms_meet_the_same_bars(det_w):
+    """bin_conv1 over the pyramid in bf16: p2's 3x3 term as the patch-staged 64 -> 64 conv on top of the phase launch (default)
+    or inside the phase launch (`pyr_p2_direct=0`).  One more bf16 rounding of a partial sum: both forms sit within the drift of
+    the restated bf16 arithmetic, and within it of each other."""
+    x = W.synth_image_batch(21, 2, 96, 160)
+    ref32, ref16 = T.det_forward(det_w, x), T.det_forward_bf16(det_w, x)
+    d_ref = np.abs(ref16 - ref32)
+    maps = []
+    for opt in ("precision=bf16", "precision=bf16;pyr_p2_direct=0"):
+        d = capi.Detector(W.pack_blob(det_w), 0, options=opt)
+        try:
+            maps.append(d.forward_host(x))
+        finally:
+            d.close()
+        assert np.abs(maps[-1] - ref32).max() <= DRIFT_FACTOR * d_ref.max(), opt
+        assert np.abs(maps[-1] - ref32).mean() <= DRIFT_FACTOR * d_ref.mean(), opt
+    assert not np.array_equal(maps[0], maps[1])   # two different schedules really ran
+    assert np.abs(maps[0] - maps[1]).max() <= DRIFT_FACTOR * d_ref.max()
