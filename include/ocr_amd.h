@@ -10,7 +10,10 @@
  * Tensors are dense row-major f32, NCHW as tch hands them to ATen.  Handles are
  * bound to one GPU and one HIP stream, are not thread-safe, and calls are
  * synchronous unless the name ends in _async (mirrors the reference's blocking,
- * single-threaded calls).
+ * single-threaded calls).  DIFFERENT handles are independent: the
+ * library keeps no shared mutable state, so threads that each own their handles
+ * (a serving process, or one thread per GPU) may call concurrently and get the
+ * bits they would get alone (tests/test_gpu_threads.py).
  */
 #ifndef OCR_AMD_H
 #define OCR_AMD_H
