@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <new>
 #include <tuple>
@@ -70,38 +71,34 @@ struct StepTable {
 static const StepTable kStep;
 
 // The working grid of the algorithm (0 background, 1 foreground, +-id once a border has passed) is kept as the
-// immutable foreground BIT image plus a label array that only border pixels ever touch: value(x, y) = fg ? (label ?
-// label : 1) : 0.  A pixel can only start a border at the first or last pixel of a horizontal foreground run (its
+// immutable foreground BIT image plus two label bit planes that only border pixels ever touch: value(x, y) = fg ? (seen ?
+// (neg ? -id : id) : 1) : 0 - the id itself is never read, only its sign and whether it is there.  A pixel can only start a border at the first or last pixel of a horizontal foreground run (its
 // left resp. right neighbour must be zero), so the raster scan walks run boundaries found with word-wide bit tricks
 // instead of testing every pixel - the cost is O(runs + border pixels), not O(H W).
 // bits: row-major, bit (x & 31) of word (y * w + x) >> 5 (w is a multiple of 32 on the product path; any w works).
 void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& out) {
   out.clear();
   const size_t npx = (size_t)h * w;
-  // the label array lives with the calling thread (a pool thread traces image after image) and is all zero between calls:
-  // only border pixels are ever written, and they are put back one by one - no 4 H W bytes of fresh pages per image
+  // The algorithm only ever asks two things of a border pixel's label: has a border passed here (label != 0), and did one leave it
+  // negative (label < 0: it was a right edge).  Two bit planes beside the foreground bits - 2 x H W / 8 bytes per thread, cache
+  // resident, cleared per image - instead of an int32 per pixel that only the scattered border pixels touch.
   struct Labels {
-    std::vector<int32_t> lab;
-    std::vector<uint32_t> touched;
+    std::vector<uint32_t> seen, neg;
     std::vector<Pt> pts;
   };
   thread_local Labels tl;
-  if (tl.lab.size() < npx) tl.lab.assign(npx, 0);
-  int32_t* lab = tl.lab.data();
-  std::vector<uint32_t>& touched = tl.touched;
-  touched.clear();
-  struct Restore {
-    int32_t* lab;
-    std::vector<uint32_t>& touched;
-    ~Restore() {
-      for (uint32_t i : touched) lab[i] = 0;
-    }
-  } restore{lab, touched};
+  const size_t nwords = (npx + 31) / 32;
+  if (tl.seen.size() < nwords) {
+    tl.seen.resize(nwords);
+    tl.neg.resize(nwords);
+  }
+  uint32_t* seen = tl.seen.data();
+  uint32_t* neg = tl.neg.data();
+  std::memset(seen, 0, nwords * sizeof(uint32_t));
+  std::memset(neg, 0, nwords * sizeof(uint32_t));
   auto fg = [&](size_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; };
   auto nz = [&](int x, int y) { return x >= 0 && x < w && y >= 0 && y < h && fg((size_t)y * w + x); };
-  int border = 1;
   auto trace = [&](int x, int y, int adjx) {
-    ++border;
     std::vector<Pt>& pts = tl.pts;   // grown once per thread; the contour leaves as an exactly sized copy
     pts.clear();
     const int start = dir_index(adjx - x, 0);
@@ -117,8 +114,9 @@ void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vec
     }
     if (!found) {
       pts.push_back({x, y});
-      if (lab[(size_t)y * w + x] == 0) touched.push_back((uint32_t)((size_t)y * w + x));
-      lab[(size_t)y * w + x] = -border;
+      const size_t i0 = (size_t)y * w + x;
+      seen[i0 >> 5] |= 1u << (i0 & 31);
+      neg[i0 >> 5] |= 1u << (i0 & 31);
     } else {
       int p3x = x, p3y = y;
       int base = dir_index(p1x - x, p1y - y);   // direction of the previous pixel as seen from the current one
@@ -148,10 +146,10 @@ void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vec
         }
         p4x = p3x + kDx[dn];
         p4y = p3y + kDy[dn];
-        int32_t& cell = lab[(size_t)p3y * w + p3x];
-        if (cell == 0) touched.push_back((uint32_t)((size_t)p3y * w + p3x));
-        if (p3x + 1 == w || right_edge) cell = -border;
-        else if (cell == 0) cell = border;
+        const size_t ic = (size_t)p3y * w + p3x;
+        const uint32_t bit = 1u << (ic & 31);
+        seen[ic >> 5] |= bit;                                 // label = border id (or -id below): only "non-zero" is ever read
+        if (p3x + 1 == w || right_edge) neg[ic >> 5] |= bit;  // label = -id, whatever it was
         if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
         p3x = p4x;
         p3y = p4y;
@@ -164,9 +162,9 @@ void find_contours_bits(const uint32_t* bits, int h, int w, std::vector<std::vec
   // start if value > 0 and the E neighbour is 0 (x + 1 < w)
   auto visit = [&](int x, int y) {
     const size_t i = (size_t)y * w + x;
-    const int32_t l = lab[i];
-    if (l == 0 && x > 0 && !fg(i - 1)) trace(x, y, x - 1);
-    else if (l >= 0 && x + 1 < w && !fg(i + 1)) trace(x, y, x + 1);
+    const uint32_t bit = 1u << (i & 31);
+    if (!(seen[i >> 5] & bit) && x > 0 && !fg(i - 1)) trace(x, y, x - 1);            // value == 1
+    else if (!(neg[i >> 5] & bit) && x + 1 < w && !fg(i + 1)) trace(x, y, x + 1);    // value > 0
   };
   for (int y = 0; y < h; ++y) {
     const size_t r0 = (size_t)y * w;
