@@ -1,0 +1,19 @@
+#!/bin/bash
+# Turns the outputs of tools/collect_profiles.sh (merged back under gpurun_out/) into the tracked files under profiles/:
+#   tools/publish_profiles.sh gpurun_out/r04/final3 r04
+set -e
+O=$1; T=${2:-r04}; P=profiles
+python3 tools/rocprof_stats_csv.py $O/stats > $P/${T}_bench_kernel_stats.csv
+python3 tools/rocprof_stats_csv.py $O/stats_headline > $P/${T}_bench_kernel_stats_headline.csv
+grep '^{' $O/bench_line.json | tail -1 > $P/${T}_bench_line_under_rocprof.json
+grep '^{' $O/bench_line_headline.json | tail -1 > $P/${T}_bench_line_headline_under_rocprof.json
+grep '^{' $O/bench_line_bf16.json | tail -1 > $P/${T}_bench_line_bf16.json
+grep '^{' $O/bench_line_plain.json | tail -1 > $P/${T}_bench_line.json
+cp $O/layers_f32.txt $P/${T}_layers_f32.txt
+cp $O/layers_bf16.txt $P/${T}_layers_bf16.txt
+cp $O/layers_f32_mfma_f32.txt $P/${T}_layers_f32_mfma_f32.txt
+cp $O/accuracy_modes.txt $P/${T}_accuracy_modes.txt
+cp $O/rec_batches.txt $P/${T}_rec_batches.txt
+python3 tools/make_pmc_json.py f32 $O/pmc_fetch_f32 $O/pmc_write_f32 $O/pmc_mops_f32 $O/pmc_busy_f32 $T $O/rec_fetch $O/rec_write --labels $O/layers_f32.txt > /dev/null
+python3 tools/make_pmc_json.py bf16 $O/pmc_fetch_bf16 $O/pmc_write_bf16 $O/pmc_mops_bf16 $O/pmc_busy_bf16 $T --labels $O/layers_bf16.txt > /dev/null
+echo "sources of the passes: $(cat $O/csrc_sha.txt); tree now: $(python3 -c 'import bench; print(bench.csrc_hash())')"
