@@ -518,7 +518,15 @@ void Detector::free_workspace() {
 
 Detector::~Detector() {
   (void)hipSetDevice(device_);
+  // every stream that may still hold work of this handle - the caller's (ocr_det_set_stream + an _async call) included - drains
+  // before anything it reads or writes is freed
+  if (stream_ && stream_ != own_stream_) (void)hipStreamSynchronize(stream_);
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
+  if (post_stream_) (void)hipStreamSynchronize(post_stream_);
+  if (copy_stream_) {
+    (void)hipStreamSynchronize(copy_stream_);
+    (void)hipStreamSynchronize(out_stream_);
+  }
   if (side_stream_) {
     (void)hipStreamSynchronize(side_stream_);
     (void)hipStreamDestroy(side_stream_);
@@ -1232,6 +1240,7 @@ Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(dev
 
 Recognizer::~Recognizer() {
   (void)hipSetDevice(device_);
+  if (stream_ && stream_ != own_stream_) (void)hipStreamSynchronize(stream_);   // the caller's stream may still run a classify_async
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   if (stage_) (void)hipFree(stage_);
   if (feat_) (void)hipFree(feat_);

@@ -63,3 +63,38 @@ def test_two_threads_two_handle_pairs_same_gpu_bit_identical():
     assert not errors, errors
     for t in range(2):
         assert _same(alone[t], results[t]), f"thread {t}: concurrent result differs from the same work done alone"
+
+
+def test_destroy_with_async_work_on_the_callers_stream():
+    """`ocr_det_set_stream` + `ocr_det_forward_async` / `ocr_rec_classify_async`, then destroy WITHOUT synchronising: the handle
+    drains the caller's stream before it frees the workspace those launches use - the results are complete and correct."""
+    import torch
+    det_w, rec_w = W.make_det_weights(0), W.make_rec_weights(0)
+    x = torch.from_numpy(W.synth_image_batch(3, 8, 320, 320)).cuda()
+    crops = torch.from_numpy(W.synth_crops(4, 2000)).cuda()
+    ref_det, ref_rec = capi.Detector(W.pack_blob(det_w), 0), capi.Recognizer(W.pack_blob(rec_w), 0)
+    want = torch.empty_like(x)
+    ref_det.forward_device(x.data_ptr(), 8, 320, 320, want.data_ptr())
+    ref_det.synchronize()
+    want_lab = torch.empty(2000, dtype=torch.int32, device="cuda")
+    want_pr = torch.empty(2000, dtype=torch.float64, device="cuda")
+    ref_rec.classify_device(crops.data_ptr(), 2000, 0, want_lab.data_ptr(), want_pr.data_ptr())
+    ref_rec.synchronize()
+    ref_det.close()
+    ref_rec.close()
+    stream = torch.cuda.Stream()
+    for _ in range(3):
+        det, rec = capi.Detector(W.pack_blob(det_w), 0), capi.Recognizer(W.pack_blob(rec_w), 0)
+        det.set_stream(stream.cuda_stream)
+        rec.set_stream(stream.cuda_stream)
+        got = torch.zeros_like(x)
+        lab = torch.zeros(2000, dtype=torch.int32, device="cuda")
+        pr = torch.zeros(2000, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):   # a queue of work behind the handle's back
+            det.forward_device(x.data_ptr(), 8, 320, 320, got.data_ptr())
+            rec.classify_device(crops.data_ptr(), 2000, 0, lab.data_ptr(), pr.data_ptr())
+        det.close()   # no synchronize
+        rec.close()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(lab, want_lab) and torch.equal(pr, want_pr)
