@@ -131,7 +131,12 @@ class Comm {
     OCR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     ncclUniqueId uid;
     std::memcpy(uid.internal, id, 128);
-    OCR_RCCL(r.CommInitRank(&comm_, world, uid, rank));
+    const int e = r.CommInitRank(&comm_, world, uid, rank);
+    if (e != ncclSuccess) {   // a constructor that throws runs no destructor: give the stream back first
+      (void)hipStreamDestroy(stream_);
+      stream_ = nullptr;
+      fail(OCR_ERR_HIP, "ncclCommInitRank failed: %s", r.GetErrorString(e));
+    }
   }
   ~Comm() {
     (void)hipSetDevice(device_);

@@ -713,13 +713,15 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     // step's weights at every step; one barrier per step as in the plain loop.
     // run row j <-> input pixel m0 - 1 + j + (kh - 1) W of the linear order; everything that may be negative sits in the voffset
     // (the range check covers the voffset only: a negative or too large one reads as zeros), the chunk in the soffset
-    int tsv[AI + 1];
+    // (unsigned arithmetic: pixel -1 of the first tile and the rows past the last pixel wrap modulo 2^32 to offsets at or beyond
+    // 2^31, the kh term is added modulo 2^32 as well)
+    unsigned tsv[AI + 1];
 #pragma unroll
     for (int i = 0; i <= AI; ++i) {
       const int j = i < AI ? r + 32 * i : BM + (tid >> 3);   // the last instruction (rows BM ..) is wave 0's
-      tsv[i] = ((m0 - 1 + j) * p.Cin) * EB + gq * 16;
+      tsv[i] = ((unsigned)(m0 - 1 + j) * (unsigned)p.Cin) * (unsigned)EB + (unsigned)(gq * 16);
     }
-    const int kh_bytes = p.Win * p.Cin * EB;
+    const unsigned kh_bytes = (unsigned)(p.Win * p.Cin * EB);
     // validity of tap (kh, kw) for this lane's fragment rows: bit 3 kh + kw
     unsigned vmask[MT];
 #pragma unroll
@@ -739,13 +741,13 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     const unsigned a_dst = lds_base;                                                                   // + stage * STAGE + 32 i ROWB
     const unsigned x_dst = (unsigned)(size_t)(lds_void*)lds + (unsigned)(BM * ROWB);                   // rows BM .. BM + 7
     auto issue_a_piece = [&](int stage, int kh, int c, int kw) {   // piece kw of the run's AI (+ 1 for wave 0) instructions
-      const int khb = (kh - 1) * kh_bytes;
+      const unsigned khb = (unsigned)(kh - 1) * kh_bytes;   // kh = 0: minus one image row, modulo 2^32
 #pragma unroll
       for (int i = 0; i <= AI; ++i) {
         if ((i * 3) / (AI + 1) != kw) continue;   // uniform
         if (IGEMM_DBG(p, 1)) continue;
-        if (i < AI) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(a_dst + (unsigned)(stage * STAGE + 32 * i * ROWB)), (unsigned)(tsv[i] + khb), c * ROWB);
-        else if (wave == 0) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(x_dst + (unsigned)(stage * STAGE)), (unsigned)(tsv[i] + khb), c * ROWB);
+        if (i < AI) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(a_dst + (unsigned)(stage * STAGE + 32 * i * ROWB)), tsv[i] + khb, c * ROWB);
+        else if (wave == 0) dma16(a_rsrc, __builtin_amdgcn_readfirstlane(x_dst + (unsigned)(stage * STAGE)), tsv[i] + khb, c * ROWB);
       }
     };
     auto issue_b = [&](int stage, int tap, int c) {
