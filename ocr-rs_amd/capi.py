@@ -692,6 +692,36 @@ def host_contour_candidates(bitmap01: np.ndarray) -> List[List[Tuple[int, int]]]
     return out
 
 
+def _contours_call(fn, bitmap01, extra_status=False, max_pts=1 << 20, max_polys=1 << 16):
+    bm = np.ascontiguousarray(bitmap01, dtype=np.uint8)
+    h, w = bm.shape
+    xy = np.empty(2 * max_pts, np.int32)
+    cnt = np.empty(max_polys, np.int32)
+    n, st = C.c_int(0), C.c_int(0)
+    args = [_ptr(bm), h, w, _ptr(xy), _ptr(cnt), max_pts, max_polys, C.byref(n)] + ([C.byref(st)] if extra_status else [])
+    check(fn(*args))
+    out, pos = [], 0
+    for k in range(n.value):
+        c = int(cnt[k])
+        out.append([(int(xy[2 * (pos + i)]), int(xy[2 * (pos + i) + 1])) for i in range(c)])
+        pos += c
+    return (out, st.value) if extra_status else out
+
+
+def host_contours(bitmap01: np.ndarray):
+    """Raw contours of the host tracer (postproc_geom.cpp::find_contours)."""
+    L = test_lib()
+    L.ocr_test_host_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    return _contours_call(L.ocr_test_host_contours, bitmap01)
+
+
+def device_contours(bitmap01: np.ndarray, max_pts: int = 1 << 20, max_polys: int = 1 << 16):
+    """Raw contours of the device tracer (contours.hip) and its status (0 ok, 1 buffers too small, 2 guard)."""
+    L = test_lib()
+    L.ocr_test_device_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return _contours_call(L.ocr_test_device_contours, bitmap01, True, max_pts, max_polys)
+
+
 def host_expand_polygon(pts: Sequence[Tuple[int, int]], factor: float = 2.0):
     a = np.asarray(pts, dtype=np.int32).reshape(-1)
     out = np.empty(8192, np.int32)

@@ -44,17 +44,56 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   }
   uint32_t* bits_dev = reinterpret_cast<uint32_t*>(scratch + off_bits);
   launch_binarize_pack(prob_dev, bits_dev, (float)prm.thresh, n, hw, s);  // metrics.rs:41,129
-  std::vector<uint32_t> bits((size_t)n * wpi);
-  OCR_HIP(hipMemcpyAsync(bits.data(), bits_dev, bits.size() * 4, hipMemcpyDeviceToHost, s));
-  OCR_HIP(hipStreamSynchronize(s));
-#ifdef POSTPROC_TIMING
-  T1 = tnow();
-#endif
-
-  // contour tracing + Douglas-Peucker (metrics.rs:78-98)
   ThreadPool& pool = det.pool();
   std::vector<std::vector<std::vector<geom::Pt>>> cands(n);
-  pool.parallel_for(n, [&](int b) { geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]); });
+  std::vector<uint32_t> bits;
+  if (det.device_contours() && contour_trace_fits(h, w)) {
+    // contour tracing on the device (contours.hip: every image of the batch at once, one wave each), Douglas-Peucker on the pool.
+    // An image that overflows the buffers (noise: thousands of contours) takes the host tracer below.
+    constexpr int CAP = 1 << 15, MAXC = 4096;   // points / contours per image (a dense page: 12 k / 60)
+    const size_t o_pts = 0, o_st = o_pts + align256((size_t)n * CAP * 4), o_hdr = o_st + align256((size_t)n * (MAXC + 1) * 4),
+                 o_pk = o_hdr + align256((size_t)n * 16), o_ln = o_pk + align256((size_t)n * CAP * 4), total = o_ln + align256((size_t)n * MAXC * 4);
+    char* cs = static_cast<char*>(det.scratch(2, total));
+    launch_contour_trace(bits_dev, wpi, n, h, w, reinterpret_cast<uint32_t*>(cs + o_pts), CAP, reinterpret_cast<int*>(cs + o_st), MAXC,
+                         reinterpret_cast<int*>(cs + o_hdr), reinterpret_cast<uint32_t*>(cs + o_pk), reinterpret_cast<int*>(cs + o_ln), s);
+    std::vector<int32_t> hdr((size_t)n * 4);
+    OCR_HIP(hipMemcpyAsync(hdr.data(), cs + o_hdr, hdr.size() * 4, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
+    std::vector<size_t> p_at(n + 1, 0), c_at(n + 1, 0);
+    int failed = 0;
+    for (int b = 0; b < n; ++b) {
+      const bool ok = hdr[4 * b + 2] == 0;
+      failed += !ok;
+      c_at[b + 1] = c_at[b] + (ok ? (size_t)hdr[4 * b] : 0);
+      p_at[b + 1] = p_at[b] + (ok ? (size_t)hdr[4 * b + 1] : 0);
+    }
+    std::vector<uint32_t> cpts(p_at[n]);
+    std::vector<int32_t> clens(c_at[n]);
+    if (!cpts.empty()) OCR_HIP(hipMemcpyAsync(cpts.data(), cs + o_pk, cpts.size() * 4, hipMemcpyDeviceToHost, s));
+    if (!clens.empty()) OCR_HIP(hipMemcpyAsync(clens.data(), cs + o_ln, clens.size() * 4, hipMemcpyDeviceToHost, s));
+    if (failed) {
+      bits.resize((size_t)n * wpi);
+      for (int b = 0; b < n; ++b)
+        if (hdr[4 * b + 2] != 0) OCR_HIP(hipMemcpyAsync(bits.data() + (size_t)b * wpi, bits_dev + (size_t)b * wpi, wpi * 4, hipMemcpyDeviceToHost, s));
+    }
+    OCR_HIP(hipStreamSynchronize(s));
+#ifdef POSTPROC_TIMING
+    T1 = tnow();
+#endif
+    pool.parallel_for(n, [&](int b) {
+      if (hdr[4 * b + 2] == 0) geom::contour_candidates_packed(cpts.data() + p_at[b], clens.data() + c_at[b], hdr[4 * b], cands[b]);
+      else geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]);
+    });
+  } else {
+    bits.resize((size_t)n * wpi);
+    OCR_HIP(hipMemcpyAsync(bits.data(), bits_dev, bits.size() * 4, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
+#ifdef POSTPROC_TIMING
+    T1 = tnow();
+#endif
+    // contour tracing + Douglas-Peucker (metrics.rs:78-98)
+    pool.parallel_for(n, [&](int b) { geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]); });
+  }
 #ifdef POSTPROC_TIMING
   T2 = tnow();
 #endif

@@ -137,6 +137,12 @@ void launch_binarize(const float* prob, uint8_t* bitmap, float thresh, size_t n,
 // binarize_pack_words(px) 32-bit words): what the host contour tracer reads
 size_t binarize_pack_words(size_t px_per_image);
 void launch_binarize_pack(const float* prob, uint32_t* bits, float thresh, int n_images, size_t px_per_image, hipStream_t s);
+// contours.hip: Suzuki-Abe border following of the packed bit images on the device, one wave per image (maps whose bit image and
+// two label planes fit a CU's LDS: contour_trace_fits).  pts [n][cap] (y << 16 | x), starts [n][maxc + 1], hdr [n][4] =
+// {contours, points, status, 0}; pts_packed / lens_packed: the status-0 images' points and contour lengths, densely in image order
+bool contour_trace_fits(int h, int w);
+void launch_contour_trace(const uint32_t* bits, size_t words_per_image, int n, int h, int w, uint32_t* pts, int cap, int* starts, int maxc, int* hdr,
+                          uint32_t* pts_packed, int* lens_packed, hipStream_t s);
 
 // preprocess_image (image_ops.rs:188-220): Triangle resize + luma + zero pad, preprocess.hip
 void resize_dimensions(int width, int height, int nwidth, int nheight, int* ow, int* oh);

@@ -1,0 +1,223 @@
+// Contour tracing on the device (/root/reference/src/text_detection/metrics.rs:78, imageproc::contours::find_contours):
+// the Suzuki-Abe border following of postproc_geom.cpp::find_contours_bits, statement for statement, one wave per image.
+//
+// The algorithm is sequential inside an image - whether a pixel starts a border depends on the labels every earlier border left
+// behind - and that order is part of the contract (start points and the order of the contours decide what Douglas-Peucker keeps),
+// so it is NOT re-derived in a parallel form: an image's packed bit map and its two label bit planes (has a border passed / did
+// one leave the pixel negative) live in the wave's LDS (3 x H W / 8 bytes: 150 KB at 640 x 640), the 64 lanes find the run
+// boundaries of a row together (the only pixels that can start a border), and the border following itself runs wave-uniform on
+// scalar values - every step ONE round trip to LDS (the three rows of the 3 x 3 neighbourhood, read together), the search for the
+// next border pixel as bit arithmetic on the neighbour byte, two fire-and-forget label bit ORs and one 4-byte store of the point.
+// What it buys is not latency and not throughput either: a single wave issues an instruction every four to five cycles, a step of
+// the walk is ~60 dependent scalar instructions and one LDS round trip - 0.44 us per border pixel measured, against 13-20 ns on a
+// host core.  All images of a batch trace at once (one CU each), which makes the whole stage worth about ONE host core per GPU; it
+// runs beside the next batch's forward and leaves the host threads Douglas-Peucker and the unclip.  Hence an OPTION
+// (device_contours=1, include/ocr_amd.h), off by default, for hosts that cannot spare a core per GPU.
+//
+// Outputs per image: points (y << 16 | x) in tracing order, the start offset of every contour (+ a sentinel), a header
+// {contours, points, status}.  status != 0 (more contours / points than the buffers hold, or the iteration guard) sends that image
+// to the host tracer; a second kernel packs the good images' points and contour lengths densely for one copy home.
+#include "common.hpp"
+
+namespace ocr {
+namespace {
+
+constexpr int kLdsWords = 39936;            // 156 KB of the CU's 160
+constexpr unsigned DXP = 0u | 0u << 2 | 1u << 4 | 2u << 6 | 2u << 8 | 2u << 10 | 1u << 12 | 0u << 14;   // kDx[d] + 1, two bits per direction
+constexpr unsigned DYP = 1u | 0u << 2 | 0u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 2u << 12 | 2u << 14;   // kDy[d] + 1
+__device__ __forceinline__ int ddx(int d) { return (int)((DXP >> (2 * d)) & 3u) - 1; }   // W NW N NE E SE S SW (clockwise, y down)
+__device__ __forceinline__ int ddy(int d) { return (int)((DYP >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ __launch_bounds__(64) void contour_trace_kernel(const uint32_t* __restrict__ bits_all, int wpi, int h, int w, uint32_t* __restrict__ pts_all, int cap,
+                                                          int* __restrict__ starts_all, int maxc, int* __restrict__ hdr_all) {
+  __shared__ uint32_t lds[kLdsWords];
+  const int img = blockIdx.x, lane = threadIdx.x;
+  const unsigned npx = (unsigned)h * (unsigned)w, nw = (npx + 31) / 32;
+  uint32_t* bits = lds;                       // nw + 1 words (get3 reads the word behind as well)
+  volatile uint32_t* seen = lds + nw + 1;     // a border has passed this pixel
+  volatile uint32_t* neg = lds + 2 * nw + 1;  // ... and left it negative (it was a right edge)
+  const uint32_t* g = bits_all + (size_t)img * wpi;
+  for (unsigned i = lane; i < nw; i += 64) {
+    bits[i] = g[i];
+    seen[i] = 0;
+    neg[i] = 0;
+  }
+  if (lane == 0) bits[nw] = 0;
+  __syncthreads();
+
+  uint32_t* pts = pts_all + (size_t)img * cap;
+  int* starts = starts_all + (size_t)img * (maxc + 1);
+  int ncont = 0, npts = 0, status = 0;
+  auto fg = [&](unsigned i) -> unsigned { return (bits[i >> 5] >> (i & 31)) & 1u; };
+  auto nz = [&](int x, int y) -> bool { return x >= 0 && x < w && y >= 0 && y < h && fg((unsigned)y * w + x); };
+  // bits s, s + 1, s + 2: both words unconditionally (no branch between the three rows' reads: one wait for all of them)
+  auto get3 = [&](unsigned s) -> unsigned {
+    const unsigned q = s >> 5, sh = s & 31;
+    const unsigned long long v = (unsigned long long)bits[q] | ((unsigned long long)bits[q + 1] << 32);
+    return (unsigned)(v >> sh) & 7u;
+  };
+  auto emit = [&](int x, int y) {
+    if (npts >= cap) {
+      status = 1;
+      return;
+    }
+    if (lane == 0) pts[npts] = ((uint32_t)y << 16) | (uint32_t)x;
+    ++npts;
+  };
+  auto mark = [&](int x, int y, bool negative) {
+    const unsigned i = (unsigned)y * w + x;
+    if (lane == 0) {   // ds_or_b32 without return: nothing waits for it; LDS executes a wave's operations in order
+      atomicOr(const_cast<uint32_t*>(seen) + (i >> 5), 1u << (i & 31));
+      if (negative) atomicOr(const_cast<uint32_t*>(neg) + (i >> 5), 1u << (i & 31));
+    }
+  };
+  const int guard = (int)(8u * npx + 64u);   // a border passes a pixel at most a few times: an exit every wave reaches
+  auto trace = [&](int x, int y, int start) {   // start: direction of the adjacent zero pixel (0 = W, 4 = E)
+    if (ncont >= maxc) {
+      status = 1;
+      return;
+    }
+    if (lane == 0) starts[ncont] = npts;
+    ++ncont;
+    int p1x = 0, p1y = 0, d1 = 0;
+    bool found = false;
+    for (int k = 0; k < 8 && !found; ++k) {   // clockwise from the adjacent zero pixel
+      const int d = (start + k) & 7;
+      if (nz(x + ddx(d), y + ddy(d))) {
+        p1x = x + ddx(d);
+        p1y = y + ddy(d);
+        d1 = d;
+        found = true;
+      }
+    }
+    found = uni(found);
+    if (!found) {
+      emit(x, y);
+      mark(x, y, true);
+      return;
+    }
+    p1x = uni(p1x);
+    p1y = uni(p1y);
+    // the walk: position and direction are wave-uniform (scalar registers); per step one round trip to LDS for the neighbourhood,
+    // and ONE lane-0 region with the point store and the label ORs
+    int p3x = x, p3y = y, base = uni(d1);
+    for (int it = 0;; ++it) {
+      if (it > guard || npts >= cap) {
+        status = npts >= cap ? 1 : 2;
+        return;
+      }
+      const unsigned i3 = (unsigned)p3y * w + p3x;
+      int dn = 0;
+      bool right_edge = false;
+      if (p3x > 0 && p3y > 0 && p3x + 1 < w && p3y + 1 < h) {
+        const unsigned top = get3(i3 - w - 1), mid = get3(i3 - 1), bot = get3(i3 + w - 1);
+        const unsigned m = (mid & 1u) | (top & 1u) << 1 | (top & 2u) << 1 | (top & 4u) << 1 | (mid & 4u) << 2 | (bot & 4u) << 3 | (bot & 2u) << 5 | (bot & 1u) << 7;
+        // the step table of postproc_geom.cpp (StepTable) as arithmetic: bit j of r = neighbour (base + j) & 7; the search goes
+        // counter-clockwise from base - 1, i.e. j = 7, 6, ... 0 (j = 0 is the pixel we came from: set) - the first hit is r's
+        // highest set bit; the E neighbour (j_E) counts as examined-and-zero when it lies above that bit
+        const unsigned mu = (unsigned)uni((int)m);
+        const unsigned r = (((mu | mu << 8) >> base) & 0xffu) | 1u;
+        const int j = 31 - __builtin_clz(r);
+        dn = (base + j) & 7;
+        right_edge = ((4 - base) & 7) > j;
+      } else {
+        for (int k = 1; k <= 8; ++k) {   // counter-clockwise, starting just after the previous pixel's direction
+          const int d = (base - k) & 7;
+          if (nz(p3x + ddx(d), p3y + ddy(d))) {
+            dn = d;
+            break;
+          }
+          if (d == 4) right_edge = true;
+        }
+        dn = uni(dn);
+        right_edge = uni(right_edge);
+      }
+      if (lane == 0) {
+        pts[npts] = ((uint32_t)p3y << 16) | (uint32_t)p3x;
+        atomicOr(const_cast<uint32_t*>(seen) + (i3 >> 5), 1u << (i3 & 31));
+        if (p3x + 1 == w || right_edge) atomicOr(const_cast<uint32_t*>(neg) + (i3 >> 5), 1u << (i3 & 31));
+      }
+      ++npts;
+      const int p4x = p3x + ddx(dn), p4y = p3y + ddy(dn);
+      if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
+      p3x = p4x;
+      p3y = p4y;
+      base = (dn + 4) & 7;
+    }
+  };
+
+  // raster scan over the run boundaries: 64 lanes take the words of a row (w <= 2048, a multiple of 32)
+  const int wr = w >> 5;
+  for (int y = 0; y < h && !status; ++y) {
+    uint32_t cand = 0;
+    if (lane < wr) {
+      const uint32_t* row = bits + (size_t)y * wr;
+      const uint32_t cur = row[lane];
+      const uint32_t lbit = lane > 0 ? row[lane - 1] >> 31 : 0u;
+      const uint32_t rbit = lane + 1 < wr ? row[lane + 1] & 1u : 0u;
+      cand = (cur & ~((cur << 1) | lbit)) | (cur & ~((cur >> 1) | (rbit << 31)));   // first and last pixel of every run
+    }
+    unsigned long long words = __ballot(cand != 0);
+    while (words && !status) {
+      const int wi = uni(__builtin_ctzll(words));
+      words &= words - 1;
+      uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, wi);
+      while (c && !status) {
+        const int x = wi * 32 + uni(__builtin_ctz(c));
+        c &= c - 1;
+        const unsigned i = (unsigned)y * w + x;
+        const unsigned sb = uni((int)((seen[i >> 5] >> (i & 31)) & 1u)), nb = uni((int)((neg[i >> 5] >> (i & 31)) & 1u));
+        if (!sb && x > 0 && !uni((int)fg(i - 1))) trace(x, y, 0);                     // value == 1, W neighbour 0: outer border
+        else if (!nb && x + 1 < w && !uni((int)fg(i + 1))) trace(x, y, 4);            // value > 0, E neighbour 0: hole border
+      }
+    }
+  }
+  if (lane == 0) {
+    if (ncont <= maxc) starts[ncont] = npts;
+    int* hdr = hdr_all + 4 * img;
+    hdr[0] = ncont;
+    hdr[1] = npts;
+    hdr[2] = status;
+    hdr[3] = 0;
+  }
+}
+
+// the good images' points and contour lengths, densely in image order (offsets recomputed from the headers by every block)
+__global__ __launch_bounds__(256) void contour_compact_kernel(const int* __restrict__ hdr_all, const uint32_t* __restrict__ pts_all, int cap,
+                                                            const int* __restrict__ starts_all, int maxc, uint32_t* __restrict__ pts_out, int* __restrict__ lens_out) {
+  const int img = blockIdx.x;
+  const int* hdr = hdr_all + 4 * img;
+  if (hdr[2] != 0) return;
+  size_t po = 0, co = 0;
+  for (int j = 0; j < img; ++j)
+    if (hdr_all[4 * j + 2] == 0) {
+      co += hdr_all[4 * j];
+      po += hdr_all[4 * j + 1];
+    }
+  const uint32_t* src = pts_all + (size_t)img * cap;
+  const int* st = starts_all + (size_t)img * (maxc + 1);
+  for (int i = threadIdx.x; i < hdr[1]; i += 256) pts_out[po + i] = src[i];
+  for (int k = threadIdx.x; k < hdr[0]; k += 256) lens_out[co + k] = st[k + 1] - st[k];
+}
+
+}  // namespace
+
+bool contour_trace_fits(int h, int w) {
+  if (h <= 0 || w <= 0 || (w & 31) || w > 2048 || h > 65535) return false;
+  const size_t nw = ((size_t)h * w + 31) / 32;
+  return 3 * nw + 1 <= (size_t)kLdsWords;
+}
+
+void launch_contour_trace(const uint32_t* bits, size_t words_per_image, int n, int h, int w, uint32_t* pts, int cap, int* starts, int maxc, int* hdr,
+                          uint32_t* pts_packed, int* lens_packed, hipStream_t s) {
+  if (n <= 0) return;
+  if (!contour_trace_fits(h, w)) fail(OCR_ERR_INTERNAL, "contour_trace: a %dx%d map does not fit the wave's LDS", h, w);
+  if (cap <= 0 || maxc <= 0 || words_per_image > 0x7fffffffu) fail(OCR_ERR_INTERNAL, "contour_trace: bad capacities");
+  hipLaunchKernelGGL(contour_trace_kernel, dim3((unsigned)n), dim3(64), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr);
+  OCR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(contour_compact_kernel, dim3((unsigned)n), dim3(256), 0, s, hdr, pts, cap, starts, maxc, pts_packed, lens_packed);
+  OCR_HIP(hipGetLastError());
+}
+
+}  // namespace ocr

@@ -251,6 +251,7 @@ void Detector::parse_options(const char* options) {
       post_threads_ = num();
       if (post_threads_ < 0 || post_threads_ > 256) fail(OCR_ERR_INVALID, "detector option post_threads: %d (0 = automatic, at most 256)", post_threads_);
     }
+    else if (key == "device_contours") device_contours_ = num() != 0;
     else if (key == "mfma") {
       if (val == "split_bf16") split_bf16_ = true;
       else if (val == "f32") split_bf16_ = false;
@@ -621,7 +622,7 @@ void Detector::synchronize() {
 }
 
 void* Detector::scratch(int slot, size_t bytes) {
-  if (slot < 0 || slot > 1) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
+  if (slot < 0 || slot > 2) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
   if (bytes > scratch_bytes_[slot]) {
     OCR_HIP(hipStreamSynchronize(stream_));
     if (scratch_[slot]) OCR_HIP(hipFree(scratch_[slot]));

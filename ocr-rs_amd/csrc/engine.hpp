@@ -93,7 +93,10 @@ class Detector {
   void mark_before_forward();
   hipEvent_t before_forward_event() const { return ev_before_fwd_; }
   int post_threads() const;      // host threads of the post-processing stages (option post_threads, default min(16, CPU share))
-  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results.
+  // contours on the device (contours.hip)?  option device_contours=1; off by default: a wave follows a border at about the speed of
+  // ONE host core per batch (measured), so it pays only where no host core can be spared
+  bool device_contours() const { return device_contours_; }
+  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
   // host threads of the post-processing stages (created on first use, one image per task)
@@ -207,8 +210,8 @@ class Detector {
   hipStream_t post_stream_ = nullptr;
   hipEvent_t pipe_ev_[2] = {nullptr, nullptr};
   int pipe_ev_next_ = 0;
-  void* scratch_[2] = {nullptr, nullptr};
-  size_t scratch_bytes_[2] = {0, 0};
+  void* scratch_[3] = {nullptr, nullptr, nullptr};
+  size_t scratch_bytes_[3] = {0, 0, 0};
   struct Staging {
     void* in[2] = {nullptr, nullptr};
     float* out[2] = {nullptr, nullptr};
@@ -220,6 +223,7 @@ class Detector {
   hipStream_t copy_stream_ = nullptr, out_stream_ = nullptr;
   hipEvent_t ev_before_fwd_ = nullptr;
   int post_threads_ = 0;   // option post_threads: 0 = automatic
+  bool device_contours_ = false;   // option device_contours
 };
 
 class Recognizer {

@@ -704,6 +704,16 @@ void contour_candidates_bits(const uint32_t* bits, int h, int w, std::vector<std
   candidates_of(contours, cands);
 }
 
+void contour_candidates_packed(const uint32_t* pts, const int32_t* lens, int n_contours, std::vector<std::vector<Pt>>& cands) {
+  std::vector<std::vector<Pt>> contours((size_t)std::max(n_contours, 0));
+  size_t at = 0;
+  for (int k = 0; k < n_contours; ++k) {
+    contours[k].resize((size_t)lens[k]);
+    for (int i = 0; i < lens[k]; ++i, ++at) contours[k][i] = {(int)(pts[at] & 0xffffu), (int)(pts[at] >> 16)};
+  }
+  candidates_of(contours, cands);
+}
+
 static void candidates_of(const std::vector<std::vector<Pt>>& contours, std::vector<std::vector<Pt>>& cands) {
   cands.clear();
   std::vector<Pt> pts;

@@ -45,6 +45,8 @@ void combine_results(const MetricsItem* r, int n, double* precision, double* rec
 // contours -> Douglas-Peucker polygons with >= 4 points (metrics.rs:78-98)
 void contour_candidates(const uint8_t* bitmap01, int h, int w, std::vector<std::vector<Pt>>& cands);
 void contour_candidates_bits(const uint32_t* bits, int h, int w, std::vector<std::vector<Pt>>& cands);
+// the same from contours traced elsewhere (contours.hip): points packed as y << 16 | x, one length per contour
+void contour_candidates_packed(const uint32_t* pts, const int32_t* lens, int n_contours, std::vector<std::vector<Pt>>& cands);
 // score threshold, unclip, min-size filter, round(p/adj) as u32 (metrics.rs:100-123).
 // Appends x,y pairs to xy_out and returns true when the polygon is kept.
 bool finish_polygon(const std::vector<Pt>& cand, double score, double adj_x, double adj_y,

@@ -40,6 +40,63 @@ int ocr_test_contour_candidates(const uint8_t* bitmap01, int h, int w, int32_t* 
     *n_polys = np;
   });
 }
+// the device tracer (contours.hip) on one 0/1 bitmap: raw contours (not the Douglas-Peucker candidates); status = the kernel's
+// (0 ok, 1 buffers too small, 2 iteration guard).  max_pts / max_polys double as the kernel's capacities.
+int ocr_test_device_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_out, int32_t* counts_out, int max_pts, int max_polys,
+                             int* n_polys, int* status) {
+  return guard([&] {
+    if (!ocr::contour_trace_fits(h, w)) ocr::fail(OCR_ERR_INVALID, "device contours: %dx%d does not fit", h, w);
+    const size_t npx = (size_t)h * w, wpi = ocr::binarize_pack_words(npx);
+    std::vector<uint32_t> bits(wpi, 0u);
+    for (size_t i = 0; i < npx; ++i)
+      if (bitmap01[i]) bits[i >> 5] |= 1u << (i & 31);
+    uint32_t *d_bits = nullptr, *d_pts = nullptr, *d_pk = nullptr;
+    int *d_st = nullptr, *d_hdr = nullptr, *d_ln = nullptr;
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_bits), wpi * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_pts), (size_t)max_pts * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_pk), (size_t)max_pts * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_st), ((size_t)max_polys + 1) * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_ln), (size_t)max_polys * 4));
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_hdr), 16));
+    OCR_HIP(hipMemcpy(d_bits, bits.data(), wpi * 4, hipMemcpyHostToDevice));
+    ocr::launch_contour_trace(d_bits, wpi, 1, h, w, d_pts, max_pts, d_st, max_polys, d_hdr, d_pk, d_ln, nullptr);
+    int hdr[4];
+    OCR_HIP(hipMemcpy(hdr, d_hdr, 16, hipMemcpyDeviceToHost));
+    *status = hdr[2];
+    *n_polys = 0;
+    if (hdr[2] == 0) {
+      std::vector<uint32_t> pts((size_t)hdr[1]);
+      std::vector<int32_t> lens((size_t)hdr[0]);
+      if (hdr[1]) OCR_HIP(hipMemcpy(pts.data(), d_pk, pts.size() * 4, hipMemcpyDeviceToHost));
+      if (hdr[0]) OCR_HIP(hipMemcpy(lens.data(), d_ln, lens.size() * 4, hipMemcpyDeviceToHost));
+      for (int k = 0; k < hdr[0]; ++k) counts_out[k] = lens[k];
+      for (int i = 0; i < hdr[1]; ++i) {
+        xy_out[2 * i] = (int32_t)(pts[i] & 0xffffu);
+        xy_out[2 * i + 1] = (int32_t)(pts[i] >> 16);
+      }
+      *n_polys = hdr[0];
+    }
+    for (void* q : {(void*)d_bits, (void*)d_pts, (void*)d_pk, (void*)d_st, (void*)d_ln, (void*)d_hdr}) (void)hipFree(q);
+  });
+}
+// the host tracer's raw contours, for the same comparison
+int ocr_test_host_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_out, int32_t* counts_out, int max_pts, int max_polys, int* n_polys) {
+  return guard([&] {
+    std::vector<std::vector<ocr::geom::Pt>> cs;
+    ocr::geom::find_contours(bitmap01, h, w, cs);
+    int np = 0, used = 0;
+    for (const auto& c : cs) {
+      if (np >= max_polys || used + (int)c.size() > max_pts) ocr::fail(OCR_ERR_INVALID, "test buffer too small");
+      counts_out[np++] = (int)c.size();
+      for (const auto& q : c) {
+        xy_out[2 * used] = q.x;
+        xy_out[2 * used + 1] = q.y;
+        ++used;
+      }
+    }
+    *n_polys = np;
+  });
+}
 int ocr_test_expand_polygon(const int32_t* xy, int n, double factor, int32_t* xy_out, int max_out, int* n_out,
                             double* sside_out) {
   return guard([&] {

@@ -1,0 +1,99 @@
+"""The device contour tracer (contours.hip) against the host tracer it restates (postproc_geom.cpp, itself pinned to
+imageproc's find_contours through the reference's known answers): the SAME contours, point for point, in the same order - start
+pixels and order decide what Douglas-Peucker keeps - and the same polygons out of ocr_det_postprocess whichever tracer ran."""
+import numpy as np
+import pytest
+
+import bench
+import ocr_rs_amd  # noqa: F401
+from ocr_rs_amd import capi
+from ocr_rs_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    out = []
+    for h, w, p in ((32, 32, 0.5), (64, 96, 0.3), (96, 64, 0.7), (160, 160, 0.5), (33, 64, 0.45), (7, 32, 0.6), (200, 224, 0.1)):
+        out.append((f"noise {h}x{w} p={p}", (rng.random((h, w)) < p).astype(np.uint8)))
+    m = rng.random((256, 256))
+    for _ in range(4):
+        m = (m + np.roll(m, 1, 0) + np.roll(m, 1, 1) + np.roll(m, -1, 0) + np.roll(m, -1, 1)) / 5
+    out.append(("smooth blobs", (m > np.median(m)).astype(np.uint8)))
+    ring = np.zeros((96, 128), np.uint8)
+    ring[10:40, 10:50] = 1; ring[11:39, 11:49] = 0          # one pixel thick: outer and hole border share every pixel
+    ring[50:90, 20:100] = 1; ring[55:85, 25:95] = 0; ring[60:80, 30:90] = 1; ring[65:75, 35:85] = 0   # nested
+    ring[5, 60:120] = 1; ring[5:45, 120] = 1                # thin lines
+    out.append(("rings and lines", ring))
+    out.append(("full", np.ones((64, 64), np.uint8)))
+    out.append(("empty", np.zeros((64, 64), np.uint8)))
+    edge = np.zeros((64, 96), np.uint8)
+    edge[0, :] = 1; edge[:, 0] = 1; edge[-1, 3:40] = 1; edge[10:30, -1] = 1; edge[20:25, 90:] = 1; edge[40, 40] = 1; edge[63, 95] = 1
+    out.append(("touching every border", edge))
+    out.append(("checkerboard", ((np.add.outer(np.arange(64), np.arange(64))) % 2).astype(np.uint8)))
+    out.append(("stripes", (np.arange(128)[None, :] % 3 == 0).astype(np.uint8).repeat(40, 0)))
+    out.append(("diagonals", (np.add.outer(np.arange(96), np.arange(96)) % 7 < 2).astype(np.uint8)))
+    out.append(("text-like 640", (bench.text_like_maps(1, 640, 3)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("dense 640", (bench.dense_text_maps(1, 640, 4)[0, 0] > 0.6).astype(np.uint8)))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_device_contours_equal_host_contours(case):
+    name, bm = case
+    want = capi.host_contours(bm)
+    got, status = capi.device_contours(bm)
+    assert status == 0
+    assert len(got) == len(want), (len(got), len(want))
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a == b, f"contour {k} differs"
+
+
+def test_device_contours_report_overflow_and_guard():
+    bm = (np.random.default_rng(3).random((64, 64)) < 0.4).astype(np.uint8)
+    want = capi.host_contours(bm)
+    assert len(want) > 8
+    _, status = capi.device_contours(bm, max_pts=1 << 16, max_polys=8)       # more contours than the buffer holds
+    assert status == 1
+    _, status = capi.device_contours(bm, max_pts=16, max_polys=1 << 12)      # more points
+    assert status == 1
+    with pytest.raises(capi.OcrError):
+        capi.device_contours(np.zeros((800, 800), np.uint8))                  # three bit planes of 800 x 800 do not fit a CU's LDS
+
+
+def _post(det, maps, adj):
+    p = capi.default_params(skip_degenerate=True)
+    return det.postprocess(maps, maps.shape[0], maps.shape[2], maps.shape[3], adj, capi.MEM_HOST, p)
+
+
+def test_postprocess_is_the_same_with_either_tracer():
+    """ocr_det_postprocess with device_contours=1 / 0 (16 and 2 pool threads): identical polygon lists and
+    scores on text-like and dense maps, on noise whose thousands of contours overflow the device buffers (those images fall back to the
+    host tracer inside the call), on a mixed batch, and on a size the device tracer does not take."""
+    blob = W.pack_blob(W.make_det_weights(0))
+    host = capi.Detector(blob, 0, options="device_contours=0")
+    dev = capi.Detector(blob, 0, options="device_contours=1")
+    dev2 = capi.Detector(blob, 0, options="device_contours=1;post_threads=2")
+    rng = np.random.default_rng(5)
+    noise = (rng.random((2, 1, 640, 640)) * 0.9).astype(np.float32)         # ~ 40 k contours per image: overflow -> host fallback
+    smooth = rng.random((2, 1, 320, 320)).astype(np.float32)
+    for _ in range(5):
+        smooth = (smooth + np.roll(smooth, 1, 2) + np.roll(smooth, 1, 3) + np.roll(smooth, -1, 2) + np.roll(smooth, -1, 3)) / 5
+    smooth = ((smooth - smooth.min()) / (smooth.max() - smooth.min())).astype(np.float32)
+    mixed = np.concatenate([bench.dense_text_maps(2, 640, 7), noise[:1], bench.text_like_maps(1, 640, 8)])
+    for name, maps in (("text", bench.text_like_maps(4, 640, 1)), ("dense", bench.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
+                       ("mixed", mixed), ("800", bench.text_like_maps(1, 800, 9))):
+        adj = np.ones((maps.shape[0], 2)) * np.array([1.25, 0.8])
+        want = _post(host, maps, adj)
+        for d in (dev, dev2):
+            got = _post(d, maps, adj)
+            assert got[0] == want[0], name
+            assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got[1], want[1])), name
+    for d in (host, dev, dev2):
+        d.close()
+    with pytest.raises(capi.OcrError):
+        capi.Detector(blob, 0, options="device_contours=maybe")
