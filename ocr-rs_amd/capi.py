@@ -692,13 +692,13 @@ def host_contour_candidates(bitmap01: np.ndarray) -> List[List[Tuple[int, int]]]
     return out
 
 
-def _contours_call(fn, bitmap01, extra_status=False, max_pts=1 << 20, max_polys=1 << 16):
+def _contours_call(fn, bitmap01, extra_status=False, max_pts=1 << 20, max_polys=1 << 16, tail=()):
     bm = np.ascontiguousarray(bitmap01, dtype=np.uint8)
     h, w = bm.shape
     xy = np.empty(2 * max_pts, np.int32)
     cnt = np.empty(max_polys, np.int32)
     n, st = C.c_int(0), C.c_int(0)
-    args = [_ptr(bm), h, w, _ptr(xy), _ptr(cnt), max_pts, max_polys, C.byref(n)] + ([C.byref(st)] if extra_status else [])
+    args = [_ptr(bm), h, w, _ptr(xy), _ptr(cnt), max_pts, max_polys, C.byref(n)] + ([C.byref(st)] if extra_status else []) + list(tail)
     check(fn(*args))
     out, pos = [], 0
     for k in range(n.value):
@@ -715,11 +715,12 @@ def host_contours(bitmap01: np.ndarray):
     return _contours_call(L.ocr_test_host_contours, bitmap01)
 
 
-def device_contours(bitmap01: np.ndarray, max_pts: int = 1 << 20, max_polys: int = 1 << 16):
-    """Raw contours of the device tracer (contours.hip) and its status (0 ok, 1 buffers too small, 2 guard)."""
+def device_contours(bitmap01: np.ndarray, max_pts: int = 1 << 20, max_polys: int = 1 << 16, sequential: bool = False):
+    """Raw contours of the device tracer (contours.hip; the parallel form, or the one-wave-per-image form) and its status
+    (0 ok, 1 buffers too small, 2 guard, 3 parallel form: a start outside its list of plausible starts)."""
     L = test_lib()
-    L.ocr_test_device_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    return _contours_call(L.ocr_test_device_contours, bitmap01, True, max_pts, max_polys)
+    L.ocr_test_device_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    return _contours_call(L.ocr_test_device_contours, bitmap01, True, max_pts, max_polys, tail=(int(sequential),))
 
 
 def host_expand_polygon(pts: Sequence[Tuple[int, int]], factor: float = 2.0):

@@ -19,10 +19,54 @@ using ocr::guard;
 using ocr::PolygonsOwned;
 using ocr::align256;
 
+// device contours (contours.hip): where the pieces live inside one scratch slot, and the launches that fill them
+struct ContourBuffers {
+  static constexpr int CAP = 1 << 15, MAXC = 4096;   // points / contours per image (a dense page: 12 k / 60)
+  char* base = nullptr;
+  size_t o_bits = 0, o_pts = 0, o_st = 0, o_hdr = 0, o_pk = 0, o_ln = 0, o_sp = 0, total = 0, wpi = 0;
+  ContourBuffers(int n, size_t hw) {
+    wpi = ocr::binarize_pack_words(hw);
+    o_pts = o_bits + align256((size_t)n * wpi * 4);
+    o_st = o_pts + align256((size_t)n * CAP * 4);
+    o_hdr = o_st + align256((size_t)n * (MAXC + 1) * 4);
+    o_pk = o_hdr + align256((size_t)n * 16);
+    o_ln = o_pk + align256((size_t)n * CAP * 4);
+    o_sp = o_ln + align256((size_t)n * MAXC * 4);
+    total = o_sp + align256(ocr::contour_spec_bytes(n));
+  }
+  uint32_t* bits() const { return reinterpret_cast<uint32_t*>(base + o_bits); }
+};
+// binarize + pack + trace of a batch whose map is (or will be, stream order) on the device: everything on `s`, nothing waits
+static ContourBuffers enqueue_contours(ocr::Detector& det, int slot, const float* prob_dev, int n, int h, int w, float thresh, hipStream_t s) {
+  using namespace ocr;
+  ContourBuffers cb(n, (size_t)h * w);
+  cb.base = static_cast<char*>(det.scratch(slot, cb.total));
+  launch_binarize_pack(prob_dev, cb.bits(), thresh, n, (size_t)h * w, s);
+  launch_contour_trace(cb.bits(), cb.wpi, n, h, w, reinterpret_cast<uint32_t*>(cb.base + cb.o_pts), ContourBuffers::CAP, reinterpret_cast<int*>(cb.base + cb.o_st),
+                       ContourBuffers::MAXC, reinterpret_cast<int*>(cb.base + cb.o_hdr), reinterpret_cast<uint32_t*>(cb.base + cb.o_pk),
+                       reinterpret_cast<int*>(cb.base + cb.o_ln), cb.base + cb.o_sp, det.device_contours() == 2, s);
+  return cb;
+}
+
+// device_contours in the pipelined calls: the contours of the batch that was just queued are requested right away - behind its
+// forward, on a stream of their own - so that the call which brings its polygons back finds them done instead of waiting
+static void pretrace_pending(ocr::Detector& d) {
+  using namespace ocr;
+  if (!d.has_pending() || !d.device_contours()) return;
+  Detector::Pending& p = d.pending();
+  if (!contour_trace_fits(p.h, p.w)) return;
+  hipStream_t ts = d.trace_stream();   // not the post-processing stream: crops of the batch that just came back must not queue behind this forward
+  OCR_HIP(hipStreamWaitEvent(ts, p.event, 0));
+  enqueue_contours(d, 3, p.prob, p.n, p.h, p.w, (float)p.params.thresh, ts);
+  OCR_HIP(hipEventRecord(d.trace_done_event(), ts));
+  p.pretraced = true;
+}
+
 // get_boxes_and_box_scores (metrics.rs:37-56) over the whole batch.  Dense, regular work on the GPU (binarisation into
 // a packed bit image, box scores), irregular work on the detector's host thread pool, one image per task.
+// pretraced: the batch's contours were requested on `s` earlier (enqueue_contours into scratch slot 3): only read them
 void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
-                 const ocr_postproc_params_t& prm, ocr_polygons_t** out, hipStream_t s) {
+                 const ocr_postproc_params_t& prm, ocr_polygons_t** out, hipStream_t s, bool pretraced = false) {
   using namespace ocr;
 #ifdef POSTPROC_TIMING
   auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -34,28 +78,32 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   OCR_HIP(hipSetDevice(det.device()));
   const size_t hw = (size_t)h * w, px = (size_t)n * hw;
   const size_t wpi = binarize_pack_words(hw);  // 32-bit words per packed image
+  const bool dev_trace = pretraced || (det.device_contours() && contour_trace_fits(h, w));
   // scratch: [prob copy if host] [packed bitmaps]
   const size_t off_bits = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
   char* scratch = static_cast<char*>(det.scratch(0, off_bits + align256((size_t)n * wpi * 4)));
   const float* prob_dev = prob;
   if (mem_kind == OCR_MEM_HOST) {
+    if (pretraced) fail(OCR_ERR_INTERNAL, "postprocess: a pretraced batch lives on the device");
     OCR_HIP(hipMemcpyAsync(scratch, prob, px * 4, hipMemcpyHostToDevice, s));
     prob_dev = reinterpret_cast<const float*>(scratch);
   }
   uint32_t* bits_dev = reinterpret_cast<uint32_t*>(scratch + off_bits);
-  launch_binarize_pack(prob_dev, bits_dev, (float)prm.thresh, n, hw, s);  // metrics.rs:41,129
   ThreadPool& pool = det.pool();
   std::vector<std::vector<std::vector<geom::Pt>>> cands(n);
   std::vector<uint32_t> bits;
-  if (det.device_contours() && contour_trace_fits(h, w)) {
-    // contour tracing on the device (contours.hip: every image of the batch at once, one wave each), Douglas-Peucker on the pool.
-    // An image that overflows the buffers (noise: thousands of contours) takes the host tracer below.
-    constexpr int CAP = 1 << 15, MAXC = 4096;   // points / contours per image (a dense page: 12 k / 60)
-    const size_t o_pts = 0, o_st = o_pts + align256((size_t)n * CAP * 4), o_hdr = o_st + align256((size_t)n * (MAXC + 1) * 4),
-                 o_pk = o_hdr + align256((size_t)n * 16), o_ln = o_pk + align256((size_t)n * CAP * 4), total = o_ln + align256((size_t)n * MAXC * 4);
-    char* cs = static_cast<char*>(det.scratch(2, total));
-    launch_contour_trace(bits_dev, wpi, n, h, w, reinterpret_cast<uint32_t*>(cs + o_pts), CAP, reinterpret_cast<int*>(cs + o_st), MAXC,
-                         reinterpret_cast<int*>(cs + o_hdr), reinterpret_cast<uint32_t*>(cs + o_pk), reinterpret_cast<int*>(cs + o_ln), s);
+  if (dev_trace) {
+    // contour tracing on the device (contours.hip), Douglas-Peucker on the pool.  An image the device gives up on (buffers too
+    // small - noise: thousands of contours - or a start outside the parallel form's list) takes the host tracer below.
+    ContourBuffers cb(n, hw);
+    if (pretraced) {   // filled when the batch was queued
+      cb.base = static_cast<char*>(det.scratch(3, cb.total));
+      OCR_HIP(hipStreamWaitEvent(s, det.trace_done_event(), 0));
+    }
+    else cb = enqueue_contours(det, 2, prob_dev, n, h, w, (float)prm.thresh, s);
+    bits_dev = cb.bits();
+    char* cs = cb.base;
+    const size_t o_hdr = cb.o_hdr, o_pk = cb.o_pk, o_ln = cb.o_ln;
     std::vector<int32_t> hdr((size_t)n * 4);
     OCR_HIP(hipMemcpyAsync(hdr.data(), cs + o_hdr, hdr.size() * 4, hipMemcpyDeviceToHost, s));
     OCR_HIP(hipStreamSynchronize(s));
@@ -85,6 +133,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
       else geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]);
     });
   } else {
+    launch_binarize_pack(prob_dev, bits_dev, (float)prm.thresh, n, hw, s);  // metrics.rs:41,129
     bits.resize((size_t)n * wpi);
     OCR_HIP(hipMemcpyAsync(bits.data(), bits_dev, bits.size() * 4, hipMemcpyDeviceToHost, s));
     OCR_HIP(hipStreamSynchronize(s));
@@ -492,8 +541,9 @@ int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, i
     if (prev.valid) {
       hipStream_t ps = d.post_stream();
       OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
-      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps, prev.pretraced);
     }
+    pretrace_pending(d);
   });
 }
 
@@ -511,7 +561,7 @@ int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem
       OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
       if (prev.prob_host)   // the caller asked for the map too: it leaves on the same stream, ahead of the bit image
         OCR_HIP(hipMemcpyAsync(prev.prob_host, prev.prob, (size_t)prev.n * prev.h * prev.w * 4, hipMemcpyDeviceToHost, ps));
-      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps);
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps, prev.pretraced);
     };
     Detector::Pending next;
     if (x_host) {
@@ -550,6 +600,7 @@ int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem
     }
     Detector::Pending prev = d.swap_pending(next);
     if (prev.valid) finish(prev);
+    pretrace_pending(d);
   });
 }
 

@@ -141,8 +141,11 @@ void launch_binarize_pack(const float* prob, uint32_t* bits, float thresh, int n
 // two label planes fit a CU's LDS: contour_trace_fits).  pts [n][cap] (y << 16 | x), starts [n][maxc + 1], hdr [n][4] =
 // {contours, points, status, 0}; pts_packed / lens_packed: the status-0 images' points and contour lengths, densely in image order
 bool contour_trace_fits(int h, int w);
+// spec: contour_spec_bytes(n) bytes of scratch for the parallel form (plausible starts walked by a lane each, the raster scan only
+// replays the label tests); sequential != 0 or spec == nullptr or h > 1024: the one-wave-per-image form
+size_t contour_spec_bytes(int n);
 void launch_contour_trace(const uint32_t* bits, size_t words_per_image, int n, int h, int w, uint32_t* pts, int cap, int* starts, int maxc, int* hdr,
-                          uint32_t* pts_packed, int* lens_packed, hipStream_t s);
+                          uint32_t* pts_packed, int* lens_packed, void* spec, int sequential, hipStream_t s);
 
 // preprocess_image (image_ops.rs:188-220): Triangle resize + luma + zero pad, preprocess.hip
 void resize_dimensions(int width, int height, int nwidth, int nheight, int* ow, int* oh);

@@ -8,11 +8,9 @@
 // boundaries of a row together (the only pixels that can start a border), and the border following itself runs wave-uniform on
 // scalar values - every step ONE round trip to LDS (the three rows of the 3 x 3 neighbourhood, read together), the search for the
 // next border pixel as bit arithmetic on the neighbour byte, two fire-and-forget label bit ORs and one 4-byte store of the point.
-// What it buys is not latency and not throughput either: a single wave issues an instruction every four to five cycles, a step of
-// the walk is ~60 dependent scalar instructions and one LDS round trip - 0.44 us per border pixel measured, against 13-20 ns on a
-// host core.  All images of a batch trace at once (one CU each), which makes the whole stage worth about ONE host core per GPU; it
-// runs beside the next batch's forward and leaves the host threads Douglas-Peucker and the unclip.  Hence an OPTION
-// (device_contours=1, include/ocr_amd.h), off by default, for hosts that cannot spare a core per GPU.
+// One wave walks at 0.44 us per border pixel (an instruction every four to five cycles, ~60 dependent scalar instructions and one LDS
+// round trip per step) against 13-20 ns on a host core: 5-6 ms for a batch of dense maps.  The parallel form further down is what
+// the engine uses (option device_contours=1; =2 is this form); both are off by default - DESIGN.md section 4 has the measurements.
 //
 // Outputs per image: points (y << 16 | x) in tracing order, the start offset of every contour (+ a sentinel), a header
 // {contours, points, status}.  status != 0 (more contours / points than the buffers hold, or the iteration guard) sends that image
@@ -22,7 +20,8 @@
 namespace ocr {
 namespace {
 
-constexpr int kLdsWords = 39936;            // 156 KB of the CU's 160
+constexpr int kLdsWords = 39808;            // 155.5 KB of the CU's 160 (the parallel form adds 4 KB of scan scratch)
+constexpr int kContourPool = 1 << 17;       // points of the speculative walks per image (parallel form)
 constexpr unsigned DXP = 0u | 0u << 2 | 1u << 4 | 2u << 6 | 2u << 8 | 2u << 10 | 1u << 12 | 0u << 14;   // kDx[d] + 1, two bits per direction
 constexpr unsigned DYP = 1u | 0u << 2 | 0u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 2u << 12 | 2u << 14;   // kDy[d] + 1
 __device__ __forceinline__ int ddx(int d) { return (int)((DXP >> (2 * d)) & 3u) - 1; }   // W NW N NE E SE S SW (clockwise, y down)
@@ -183,6 +182,280 @@ __global__ __launch_bounds__(64) void contour_trace_kernel(const uint32_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same contours, most of the walking done in parallel.  A border is a pure function of the bit image and its start (pixel,
+// type); what is sequential is only WHICH candidates start one - the label tests of the raster scan.  So:
+//   A  every thread of a 1024-thread workgroup takes a row and lists its PLAUSIBLE starts in raster order - the first pixel of a run
+//      with no foreground above it (the only place a component's first pixel can be: an outer border) and the last pixel of a run
+//      whose gap to the next run has no background above it (the only place the pixel left of a hole's first pixel can be: a hole
+//      border) - then each listed start is walked by its own lane, once for the length and once, behind a prefix sum, for the points
+//      (bit 31 of a point: this visit leaves the pixel negative);
+//   B  wave 0 replays the raster scan of the sequential kernel over ALL run boundaries with the label planes; a candidate that
+//      passes its label test takes its border from the list - 64 lanes OR the labels in and copy the points out - instead of walking.
+// A candidate that passes its test and is NOT in the list (Suzuki-Abe says there is none; the implementation's x > 0 rule for outer
+// starts makes some for components whose first pixel sits in column 0) ends the image with status 3: it goes to the host tracer like an
+// overflow.  Exact by construction: the same decisions on the same labels, the same walks.
+constexpr int kMaxStarts = 8192;     // plausible starts per image
+__device__ __forceinline__ bool span_any(const uint32_t* row, int xa, int xb) {   // a set bit in [xa, xb]
+  for (int q = xa >> 5; q <= (xb >> 5); ++q) {
+    uint32_t m = ~0u;
+    if (q == (xa >> 5)) m &= ~0u << (xa & 31);
+    if (q == (xb >> 5)) m &= ~0u >> (31 - (xb & 31));
+    if (row[q] & m) return true;
+  }
+  return false;
+}
+__device__ __forceinline__ bool span_all(const uint32_t* row, int xa, int xb) {   // every bit of [xa, xb] set
+  for (int q = xa >> 5; q <= (xb >> 5); ++q) {
+    uint32_t m = ~0u;
+    if (q == (xa >> 5)) m &= ~0u << (xa & 31);
+    if (q == (xb >> 5)) m &= ~0u >> (31 - (xb & 31));
+    if ((row[q] & m) != m) return false;
+  }
+  return true;
+}
+// first set (want = 1) / clear (want = 0) bit of the row at or after x, or w
+__device__ __forceinline__ int next_bit(const uint32_t* row, int w, int x, int want) {
+  while (x < w) {
+    uint32_t v = row[x >> 5];
+    if (!want) v = ~v;
+    v &= ~0u << (x & 31);
+    if (v) return min((x & ~31) + __builtin_ctz(v), w);
+    x = (x & ~31) + 32;
+  }
+  return w;
+}
+// the plausible starts of row y in raster order: key = 2 * pixel index + type (0 outer, 1 hole); out == nullptr: count only
+__device__ int row_starts(const uint32_t* bits, int h, int w, int y, int* out) {
+  const uint32_t* row = bits + (size_t)y * (w >> 5);
+  const uint32_t* up = y > 0 ? row - (w >> 5) : nullptr;
+  int n = 0, prev_x1 = -1, x = 0;
+  while (x < w) {
+    const int x0 = next_bit(row, w, x, 1);
+    if (x0 >= w) break;
+    const int x1 = next_bit(row, w, x0, 0) - 1;
+    if (prev_x1 >= 0 && up && span_all(up, prev_x1 + 1, x0 - 1)) {   // the gap is the top row of a hole
+      if (out) out[n] = 2 * (y * w + prev_x1) + 1;
+      ++n;
+    }
+    if (x0 > 0 && (!up || !span_any(up, max(x0 - 1, 0), min(x1 + 1, w - 1)))) {   // nothing of the component above this run
+      if (out) out[n] = 2 * (y * w + x0);
+      ++n;
+    }
+    prev_x1 = x1;
+    x = x1 + 1;
+  }
+  return n;
+}
+// one border walked by one lane: its length (-1: longer than limit); with out != nullptr the points too
+__device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int start, uint32_t* out, int limit) {
+  auto fg = [&](unsigned i) -> unsigned { return (bits[i >> 5] >> (i & 31)) & 1u; };
+  auto nz = [&](int xx, int yy) -> bool { return xx >= 0 && xx < w && yy >= 0 && yy < h && fg((unsigned)yy * w + xx); };
+  auto get3 = [&](unsigned s) -> unsigned {
+    const unsigned q = s >> 5, sh = s & 31;
+    const unsigned long long v = (unsigned long long)bits[q] | ((unsigned long long)bits[q + 1] << 32);
+    return (unsigned)(v >> sh) & 7u;
+  };
+  int p1x = 0, p1y = 0, d1 = 0;
+  bool found = false;
+  for (int k = 0; k < 8 && !found; ++k) {
+    const int d = (start + k) & 7;
+    if (nz(x + ddx(d), y + ddy(d))) {
+      p1x = x + ddx(d);
+      p1y = y + ddy(d);
+      d1 = d;
+      found = true;
+    }
+  }
+  if (!found) {
+    if (out) out[0] = ((uint32_t)y << 16) | (uint32_t)x | 0x80000000u;
+    return 1;
+  }
+  int p3x = x, p3y = y, base = d1, n = 0;
+  for (;;) {
+    if (n >= limit) return -1;
+    const unsigned i3 = (unsigned)p3y * w + p3x;
+    int dn = 0;
+    bool right_edge = false;
+    if (p3x > 0 && p3y > 0 && p3x + 1 < w && p3y + 1 < h) {
+      const unsigned top = get3(i3 - w - 1), mid = get3(i3 - 1), bot = get3(i3 + w - 1);
+      const unsigned m = (mid & 1u) | (top & 1u) << 1 | (top & 2u) << 1 | (top & 4u) << 1 | (mid & 4u) << 2 | (bot & 4u) << 3 | (bot & 2u) << 5 | (bot & 1u) << 7;
+      const unsigned r = (((m | m << 8) >> base) & 0xffu) | 1u;
+      const int j = 31 - __builtin_clz(r);
+      dn = (base + j) & 7;
+      right_edge = ((4 - base) & 7) > j;
+    } else {
+      for (int k = 1; k <= 8; ++k) {
+        const int d = (base - k) & 7;
+        if (nz(p3x + ddx(d), p3y + ddy(d))) {
+          dn = d;
+          break;
+        }
+        if (d == 4) right_edge = true;
+      }
+    }
+    if (out) out[n] = ((uint32_t)p3y << 16) | (uint32_t)p3x | ((p3x + 1 == w || right_edge) ? 0x80000000u : 0u);
+    ++n;
+    const int p4x = p3x + ddx(dn), p4y = p3y + ddy(dn);
+    if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
+    p3x = p4x;
+    p3y = p4y;
+    base = (dn + 4) & 7;
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* __restrict__ bits_all, int wpi, int h, int w, uint32_t* __restrict__ pts_all, int cap,
+                                                              int* __restrict__ starts_all, int maxc, int* __restrict__ hdr_all, int* __restrict__ spec_all,
+                                                              uint32_t* __restrict__ pool_all, int pool_cap) {
+  __shared__ uint32_t lds[kLdsWords];
+  __shared__ int sc[1024];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned npx = (unsigned)h * (unsigned)w, nw = (npx + 31) / 32;
+  uint32_t* bits = lds;
+  volatile uint32_t* seen = lds + nw + 1;
+  volatile uint32_t* neg = lds + 2 * nw + 1;
+  const uint32_t* g = bits_all + (size_t)img * wpi;
+  for (unsigned i = tid; i < nw; i += 1024) {
+    bits[i] = g[i];
+    seen[i] = 0;
+    neg[i] = 0;
+  }
+  if (tid == 0) bits[nw] = 0;
+  __syncthreads();
+  int* keys = spec_all + (size_t)img * 3 * kMaxStarts;
+  int* rlen = keys + kMaxStarts;
+  int* roff = rlen + kMaxStarts;
+  uint32_t* pool = pool_all + (size_t)img * pool_cap;
+  int status = 0;
+  // block-wide exclusive prefix sum of one int per thread (Hillis-Steele in sc); returns the total through `total`
+  auto block_scan = [&](int v, int& total) -> int {
+    sc[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int t = tid >= d ? sc[tid - d] : 0;
+      __syncthreads();
+      sc[tid] += t;
+      __syncthreads();
+    }
+    const int incl = sc[tid];
+    total = sc[1023];
+    __syncthreads();
+    return incl - v;
+  };
+  // ---- A1: plausible starts, row by row (h <= 1024: one row per thread)
+  const int mine = tid < h ? row_starts(bits, h, w, tid, nullptr) : 0;
+  int K = 0;
+  const int kbase = block_scan(mine, K);
+  if (K > kMaxStarts) status = 1;
+  if (!status && tid < h && mine) row_starts(bits, h, w, tid, keys + kbase);
+  __syncthreads();
+  // ---- A2: lengths
+  const int guard = (int)min(8u * npx + 64u, (unsigned)pool_cap);
+  int bad = 0;
+  if (!status)
+    for (int k = tid; k < K; k += 1024) {
+      const int key = keys[k], px = key >> 1;
+      const int len = walk_border(bits, h, w, px % w, px / w, (key & 1) ? 4 : 0, nullptr, guard);
+      rlen[k] = len;
+      bad |= len < 0;
+    }
+  bad = __syncthreads_or(bad);
+  if (bad) status = 1;
+  // ---- A3: offsets (eight consecutive entries per thread)
+  int T = 0;
+  {
+    int local[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * tid + j;
+      local[j] = (!status && k < K) ? rlen[k] : 0;
+      sum += local[j];
+    }
+    int off = block_scan(sum, T);
+    if (!status && T <= pool_cap) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * tid + j;
+        if (k < K) roff[k] = off;
+        off += local[j];
+      }
+    }
+  }
+  if (T > pool_cap) status = 1;
+  __syncthreads();
+  // ---- A4: points
+  if (!status)
+    for (int k = tid; k < K; k += 1024) {
+      const int key = keys[k], px = key >> 1;
+      walk_border(bits, h, w, px % w, px / w, (key & 1) ? 4 : 0, pool + roff[k], guard);
+    }
+  __syncthreads();
+  if (wave != 0) return;
+  // ---- B: the raster scan with the label tests; borders come from the list
+  uint32_t* pts = pts_all + (size_t)img * cap;
+  int* starts = starts_all + (size_t)img * (maxc + 1);
+  int ncont = 0, npts = 0, ka = 0;
+  auto fg = [&](unsigned i) -> unsigned { return (bits[i >> 5] >> (i & 31)) & 1u; };
+  const int wr = w >> 5;
+  for (int y = 0; y < h && !status; ++y) {
+    uint32_t cand = 0;
+    if (lane < wr) {
+      const uint32_t* row = bits + (size_t)y * wr;
+      const uint32_t cur = row[lane];
+      const uint32_t lbit = lane > 0 ? row[lane - 1] >> 31 : 0u;
+      const uint32_t rbit = lane + 1 < wr ? row[lane + 1] & 1u : 0u;
+      cand = (cur & ~((cur << 1) | lbit)) | (cur & ~((cur >> 1) | (rbit << 31)));
+    }
+    unsigned long long words = __ballot(cand != 0);
+    while (words && !status) {
+      const int wi = uni(__builtin_ctzll(words));
+      words &= words - 1;
+      uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, wi);
+      while (c && !status) {
+        const int x = wi * 32 + uni(__builtin_ctz(c));
+        c &= c - 1;
+        const unsigned i = (unsigned)y * w + x;
+        const unsigned sb = uni((int)((seen[i >> 5] >> (i & 31)) & 1u)), nb = uni((int)((neg[i >> 5] >> (i & 31)) & 1u));
+        int type = -1;
+        if (!sb && x > 0 && !uni((int)fg(i - 1))) type = 0;
+        else if (!nb && x + 1 < w && !uni((int)fg(i + 1))) type = 1;
+        if (type < 0) continue;
+        const int key = 2 * (int)i + type;
+        while (ka < K && uni(keys[ka]) < key) ++ka;
+        if (ka >= K || uni(keys[ka]) != key) {   // a start the list does not hold: this image goes to the host tracer
+          status = 3;
+          break;
+        }
+        const int len = uni(rlen[ka]), off = uni(roff[ka]);
+        if (ncont >= maxc || npts + len > cap) {
+          status = 1;
+          break;
+        }
+        if (lane == 0) starts[ncont] = npts;
+        ++ncont;
+        for (int q = lane; q < len; q += 64) {
+          const uint32_t p = pool[off + q];
+          const unsigned pi = ((p >> 16) & 0x7fffu) * (unsigned)w + (p & 0xffffu);
+          atomicOr(const_cast<uint32_t*>(seen) + (pi >> 5), 1u << (pi & 31));
+          if (p >> 31) atomicOr(const_cast<uint32_t*>(neg) + (pi >> 5), 1u << (pi & 31));
+          pts[npts + q] = p & 0x7fffffffu;
+        }
+        npts += len;
+      }
+    }
+  }
+  if (lane == 0) {
+    if (ncont <= maxc) starts[ncont] = npts;
+    int* hdr = hdr_all + 4 * img;
+    hdr[0] = ncont;
+    hdr[1] = npts;
+    hdr[2] = status;
+    hdr[3] = K;
+  }
+}
+
 // the good images' points and contour lengths, densely in image order (offsets recomputed from the headers by every block)
 __global__ __launch_bounds__(256) void contour_compact_kernel(const int* __restrict__ hdr_all, const uint32_t* __restrict__ pts_all, int cap,
                                                             const int* __restrict__ starts_all, int maxc, uint32_t* __restrict__ pts_out, int* __restrict__ lens_out) {
@@ -204,17 +477,26 @@ __global__ __launch_bounds__(256) void contour_compact_kernel(const int* __restr
 }  // namespace
 
 bool contour_trace_fits(int h, int w) {
-  if (h <= 0 || w <= 0 || (w & 31) || w > 2048 || h > 65535) return false;
+  if (h <= 0 || w <= 0 || (w & 31) || w > 2048 || h > 32767) return false;
   const size_t nw = ((size_t)h * w + 31) / 32;
   return 3 * nw + 1 <= (size_t)kLdsWords;
 }
 
+size_t contour_spec_bytes(int n) { return (size_t)n * (3 * (size_t)kMaxStarts * 4 + (size_t)kContourPool * 4); }
+
 void launch_contour_trace(const uint32_t* bits, size_t words_per_image, int n, int h, int w, uint32_t* pts, int cap, int* starts, int maxc, int* hdr,
-                          uint32_t* pts_packed, int* lens_packed, hipStream_t s) {
+                          uint32_t* pts_packed, int* lens_packed, void* spec, int sequential, hipStream_t s) {
   if (n <= 0) return;
   if (!contour_trace_fits(h, w)) fail(OCR_ERR_INTERNAL, "contour_trace: a %dx%d map does not fit the wave's LDS", h, w);
   if (cap <= 0 || maxc <= 0 || words_per_image > 0x7fffffffu) fail(OCR_ERR_INTERNAL, "contour_trace: bad capacities");
-  hipLaunchKernelGGL(contour_trace_kernel, dim3((unsigned)n), dim3(64), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr);
+  if (sequential || h > 1024 || !spec) {
+    hipLaunchKernelGGL(contour_trace_kernel, dim3((unsigned)n), dim3(64), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr);
+  } else {
+    int* spec_i = static_cast<int*>(spec);
+    uint32_t* pool = reinterpret_cast<uint32_t*>(spec_i + (size_t)n * 3 * kMaxStarts);
+    hipLaunchKernelGGL(contour_parallel_kernel, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool,
+                       kContourPool);
+  }
   OCR_HIP(hipGetLastError());
   hipLaunchKernelGGL(contour_compact_kernel, dim3((unsigned)n), dim3(256), 0, s, hdr, pts, cap, starts, maxc, pts_packed, lens_packed);
   OCR_HIP(hipGetLastError());

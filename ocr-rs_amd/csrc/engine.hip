@@ -251,7 +251,10 @@ void Detector::parse_options(const char* options) {
       post_threads_ = num();
       if (post_threads_ < 0 || post_threads_ > 256) fail(OCR_ERR_INVALID, "detector option post_threads: %d (0 = automatic, at most 256)", post_threads_);
     }
-    else if (key == "device_contours") device_contours_ = num() != 0;
+    else if (key == "device_contours") {
+      device_contours_ = num();
+      if (device_contours_ < 0 || device_contours_ > 2) fail(OCR_ERR_INVALID, "detector option device_contours: %d (0, 1 or 2)", device_contours_);
+    }
     else if (key == "mfma") {
       if (val == "split_bf16") split_bf16_ = true;
       else if (val == "f32") split_bf16_ = false;
@@ -524,6 +527,7 @@ Detector::~Detector() {
   if (stream_ && stream_ != own_stream_) (void)hipStreamSynchronize(stream_);
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   if (post_stream_) (void)hipStreamSynchronize(post_stream_);
+  if (trace_stream_) (void)hipStreamSynchronize(trace_stream_);
   if (copy_stream_) {
     (void)hipStreamSynchronize(copy_stream_);
     (void)hipStreamSynchronize(out_stream_);
@@ -541,6 +545,8 @@ Detector::~Detector() {
     (void)hipStreamSynchronize(post_stream_);
     (void)hipStreamDestroy(post_stream_);
   }
+  if (trace_stream_) (void)hipStreamDestroy(trace_stream_);
+  if (trace_done_) (void)hipEventDestroy(trace_done_);
   for (hipEvent_t ev : pipe_ev_)
     if (ev) (void)hipEventDestroy(ev);
   free_workspace();
@@ -609,6 +615,15 @@ hipStream_t Detector::post_stream() {
   return post_stream_;
 }
 
+hipStream_t Detector::trace_stream() {
+  if (!trace_stream_) OCR_HIP(hipStreamCreateWithFlags(&trace_stream_, hipStreamNonBlocking));
+  return trace_stream_;
+}
+hipEvent_t Detector::trace_done_event() {
+  if (!trace_done_) OCR_HIP(hipEventCreateWithFlags(&trace_done_, hipEventDisableTiming));
+  return trace_done_;
+}
+
 hipEvent_t Detector::pipeline_event() {
   hipEvent_t& e = pipe_ev_[pipe_ev_next_];
   pipe_ev_next_ ^= 1;
@@ -622,7 +637,7 @@ void Detector::synchronize() {
 }
 
 void* Detector::scratch(int slot, size_t bytes) {
-  if (slot < 0 || slot > 2) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
+  if (slot < 0 || slot > 3) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
   if (bytes > scratch_bytes_[slot]) {
     OCR_HIP(hipStreamSynchronize(stream_));
     if (scratch_[slot]) OCR_HIP(hipFree(scratch_[slot]));

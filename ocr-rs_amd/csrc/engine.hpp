@@ -95,8 +95,8 @@ class Detector {
   int post_threads() const;      // host threads of the post-processing stages (option post_threads, default min(16, CPU share))
   // contours on the device (contours.hip)?  option device_contours=1; off by default: a wave follows a border at about the speed of
   // ONE host core per batch (measured), so it pays only where no host core can be spared
-  bool device_contours() const { return device_contours_; }
-  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours.
+  int device_contours() const { return device_contours_; }   // 0 off, 1 parallel form, 2 one wave per image
+  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours, slot 3: the same for the batch a pipelined call left pending.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
   // host threads of the post-processing stages (created on first use, one image per task)
@@ -110,14 +110,20 @@ class Detector {
     std::vector<double> adj;
     ocr_postproc_params_t params{};
     hipEvent_t event = nullptr;
+    // device_contours: the bit images and contours of this batch were requested on the post-processing stream when the batch was
+    // queued (scratch slot 3, layout of api.hip::ContourBuffers): the call that brings the polygons back only reads them
+    bool pretraced = false;
   };
   bool has_pending() const { return pending_.valid; }
+  Pending& pending() { return pending_; }
   Pending swap_pending(Pending& next) {
     Pending prev = std::move(pending_);
     pending_ = std::move(next);
     return prev;
   }
   hipStream_t post_stream();     // second stream: post-processing kernels and copies next to the following forward
+  hipStream_t trace_stream();    // third stream: the device contours of the pending batch (device_contours), behind its forward
+  hipEvent_t trace_done_event(); // ... and the event that marks them done
   hipEvent_t pipeline_event();   // alternating pair of events marking the end of a pipelined forward
   // test hook: NHWC intermediate of the last forward (0 stem, 1-4 layer1-4, 5-8 in2-5,
   // 9-12 p2-p5 (before upsampling), 13 bin_conv1, 14 bin_conv_tr1)
@@ -208,10 +214,12 @@ class Detector {
   std::unique_ptr<ThreadPool> pool_;
   Pending pending_;
   hipStream_t post_stream_ = nullptr;
+  hipStream_t trace_stream_ = nullptr;
+  hipEvent_t trace_done_ = nullptr;
   hipEvent_t pipe_ev_[2] = {nullptr, nullptr};
   int pipe_ev_next_ = 0;
-  void* scratch_[3] = {nullptr, nullptr, nullptr};
-  size_t scratch_bytes_[3] = {0, 0, 0};
+  void* scratch_[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes_[4] = {0, 0, 0, 0};
   struct Staging {
     void* in[2] = {nullptr, nullptr};
     float* out[2] = {nullptr, nullptr};
@@ -223,7 +231,7 @@ class Detector {
   hipStream_t copy_stream_ = nullptr, out_stream_ = nullptr;
   hipEvent_t ev_before_fwd_ = nullptr;
   int post_threads_ = 0;   // option post_threads: 0 = automatic
-  bool device_contours_ = false;   // option device_contours
+  int device_contours_ = 0;   // option device_contours
 };
 
 class Recognizer {

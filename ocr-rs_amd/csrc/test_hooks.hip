@@ -41,9 +41,9 @@ int ocr_test_contour_candidates(const uint8_t* bitmap01, int h, int w, int32_t* 
   });
 }
 // the device tracer (contours.hip) on one 0/1 bitmap: raw contours (not the Douglas-Peucker candidates); status = the kernel's
-// (0 ok, 1 buffers too small, 2 iteration guard).  max_pts / max_polys double as the kernel's capacities.
+// (0 ok, 1 buffers too small, 2 iteration guard, 3 parallel form only: a start outside its list).  max_pts / max_polys double as the kernel's capacities.
 int ocr_test_device_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_out, int32_t* counts_out, int max_pts, int max_polys,
-                             int* n_polys, int* status) {
+                             int* n_polys, int* status, int sequential) {
   return guard([&] {
     if (!ocr::contour_trace_fits(h, w)) ocr::fail(OCR_ERR_INVALID, "device contours: %dx%d does not fit", h, w);
     const size_t npx = (size_t)h * w, wpi = ocr::binarize_pack_words(npx);
@@ -58,8 +58,10 @@ int ocr_test_device_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_
     OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_st), ((size_t)max_polys + 1) * 4));
     OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_ln), (size_t)max_polys * 4));
     OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d_hdr), 16));
+    void* d_spec = nullptr;
+    OCR_HIP(hipMalloc(&d_spec, ocr::contour_spec_bytes(1)));
     OCR_HIP(hipMemcpy(d_bits, bits.data(), wpi * 4, hipMemcpyHostToDevice));
-    ocr::launch_contour_trace(d_bits, wpi, 1, h, w, d_pts, max_pts, d_st, max_polys, d_hdr, d_pk, d_ln, nullptr);
+    ocr::launch_contour_trace(d_bits, wpi, 1, h, w, d_pts, max_pts, d_st, max_polys, d_hdr, d_pk, d_ln, d_spec, sequential, nullptr);
     int hdr[4];
     OCR_HIP(hipMemcpy(hdr, d_hdr, 16, hipMemcpyDeviceToHost));
     *status = hdr[2];
@@ -76,7 +78,7 @@ int ocr_test_device_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_
       }
       *n_polys = hdr[0];
     }
-    for (void* q : {(void*)d_bits, (void*)d_pts, (void*)d_pk, (void*)d_st, (void*)d_ln, (void*)d_hdr}) (void)hipFree(q);
+    for (void* q : {(void*)d_bits, (void*)d_pts, (void*)d_pk, (void*)d_st, (void*)d_ln, (void*)d_hdr, d_spec}) (void)hipFree(q);
   });
 }
 // the host tracer's raw contours, for the same comparison

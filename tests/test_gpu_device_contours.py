@@ -18,9 +18,12 @@ def _cases():
     for h, w, p in ((32, 32, 0.5), (64, 96, 0.3), (96, 64, 0.7), (160, 160, 0.5), (33, 64, 0.45), (7, 32, 0.6), (200, 224, 0.1)):
         out.append((f"noise {h}x{w} p={p}", (rng.random((h, w)) < p).astype(np.uint8)))
     m = rng.random((256, 256))
-    for _ in range(4):
+    for _ in range(40):
         m = (m + np.roll(m, 1, 0) + np.roll(m, 1, 1) + np.roll(m, -1, 0) + np.roll(m, -1, 1)) / 5
-    out.append(("smooth blobs", (m > np.median(m)).astype(np.uint8)))
+    blobs = (m > np.median(m)).astype(np.uint8)
+    out.append(("smooth blobs", blobs.copy()))
+    blobs[:, 0] = 0
+    out.append(("smooth blobs, column 0 clear", blobs))
     ring = np.zeros((96, 128), np.uint8)
     ring[10:40, 10:50] = 1; ring[11:39, 11:49] = 0          # one pixel thick: outer and hole border share every pixel
     ring[50:90, 20:100] = 1; ring[55:85, 25:95] = 0; ring[60:80, 30:90] = 1; ring[65:75, 35:85] = 0   # nested
@@ -36,31 +39,57 @@ def _cases():
     out.append(("diagonals", (np.add.outer(np.arange(96), np.arange(96)) % 7 < 2).astype(np.uint8)))
     out.append(("text-like 640", (bench.text_like_maps(1, 640, 3)[0, 0] > 0.6).astype(np.uint8)))
     out.append(("dense 640", (bench.dense_text_maps(1, 640, 4)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("text-like 640 b", (bench.text_like_maps(1, 640, 13)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("dense 320", (bench.dense_text_maps(1, 320, 14)[0, 0] > 0.6).astype(np.uint8)))
     return out
 
 
 CASES = _cases()
 
 
+@pytest.mark.parametrize("sequential", [False, True], ids=["parallel", "one-wave"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_device_contours_equal_host_contours(case):
+def test_device_contours_equal_host_contours(case, sequential):
     name, bm = case
     want = capi.host_contours(bm)
-    got, status = capi.device_contours(bm)
+    got, status = capi.device_contours(bm, sequential=sequential)
+    if status == 3:
+        # the parallel form met a start outside its list of plausible starts and gave the image up (the engine sends it to the host
+        # tracer): only where the implementation's x > 0 rule moves a component's outer start - foreground in column 0
+        assert not sequential and bm[:, 0].any(), name
+        return
+    if status == 1 and not sequential:
+        # ... or its speculative walks outgrew their pool: noise, where thousands of plausible starts sit on one giant border
+        assert name.startswith("noise") or name in ("checkerboard", "diagonals", "smooth blobs"), name
+        return
     assert status == 0
     assert len(got) == len(want), (len(got), len(want))
     for k, (a, b) in enumerate(zip(got, want)):
         assert a == b, f"contour {k} differs"
 
 
+def test_parallel_form_takes_the_usual_maps():
+    """... and does not give up (status 3) on maps without foreground in column 0: noise, blobs, rings, text-like and dense maps."""
+    taken = 0
+    for name, bm in CASES:
+        if bm[:, 0].any() or bm.shape[0] > 1024 or name.startswith("noise") or name in ("checkerboard", "diagonals"):
+            continue
+        _, status = capi.device_contours(bm)
+        assert status == 0, name
+        taken += 1
+    assert taken >= 5
+
+
 def test_device_contours_report_overflow_and_guard():
     bm = (np.random.default_rng(3).random((64, 64)) < 0.4).astype(np.uint8)
+    bm[:, 0] = 0   # (foreground in column 0 makes the parallel form give up with status 3 before anything overflows)
     want = capi.host_contours(bm)
     assert len(want) > 8
-    _, status = capi.device_contours(bm, max_pts=1 << 16, max_polys=8)       # more contours than the buffer holds
-    assert status == 1
-    _, status = capi.device_contours(bm, max_pts=16, max_polys=1 << 12)      # more points
-    assert status == 1
+    for seq in (False, True):
+        _, status = capi.device_contours(bm, max_pts=1 << 16, max_polys=8, sequential=seq)       # more contours than the buffer holds
+        assert status == 1
+        _, status = capi.device_contours(bm, max_pts=16, max_polys=1 << 12, sequential=seq)      # more points
+        assert status == 1
     with pytest.raises(capi.OcrError):
         capi.device_contours(np.zeros((800, 800), np.uint8))                  # three bit planes of 800 x 800 do not fit a CU's LDS
 
@@ -71,13 +100,13 @@ def _post(det, maps, adj):
 
 
 def test_postprocess_is_the_same_with_either_tracer():
-    """ocr_det_postprocess with device_contours=1 / 0 (16 and 2 pool threads): identical polygon lists and
+    """ocr_det_postprocess with device_contours=1 (parallel form) / 2 (one wave per image) / 0: identical polygon lists and
     scores on text-like and dense maps, on noise whose thousands of contours overflow the device buffers (those images fall back to the
     host tracer inside the call), on a mixed batch, and on a size the device tracer does not take."""
     blob = W.pack_blob(W.make_det_weights(0))
     host = capi.Detector(blob, 0, options="device_contours=0")
     dev = capi.Detector(blob, 0, options="device_contours=1")
-    dev2 = capi.Detector(blob, 0, options="device_contours=1;post_threads=2")
+    dev2 = capi.Detector(blob, 0, options="device_contours=2;post_threads=2")     # the one-wave-per-image form
     rng = np.random.default_rng(5)
     noise = (rng.random((2, 1, 640, 640)) * 0.9).astype(np.float32)         # ~ 40 k contours per image: overflow -> host fallback
     smooth = rng.random((2, 1, 320, 320)).astype(np.float32)
@@ -96,4 +125,4 @@ def test_postprocess_is_the_same_with_either_tracer():
     for d in (host, dev, dev2):
         d.close()
     with pytest.raises(capi.OcrError):
-        capi.Detector(blob, 0, options="device_contours=maybe")
+        capi.Detector(blob, 0, options="device_contours=3")
