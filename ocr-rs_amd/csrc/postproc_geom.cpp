@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <numeric>
 #include <tuple>
 
 namespace ocr {
@@ -473,6 +474,14 @@ static NodeKey make_key(i128 xn, i128 yn, i128 den) {
     yn = -yn;
     den = -den;
   }
+  if (den == 1) return {xn, yn, 1};   // a ring vertex: reduced as it stands (the 128-bit gcd loop was most of the general path's time)
+  constexpr i128 kLim = (i128)1 << 62;
+  if (xn > -kLim && xn < kLim && yn > -kLim && yn < kLim && den < kLim) {   // the usual case: 64-bit arithmetic, the same reduced key
+    const long long a = (long long)xn, b = (long long)yn, c = (long long)den;
+    long long g = std::gcd(std::gcd(a < 0 ? -a : a, b < 0 ? -b : b), c);
+    if (g == 0) g = 1;
+    return {(i128)(a / g), (i128)(b / g), (i128)(c / g)};
+  }
   i128 g = gcd128(gcd128(xn, yn), den);
   if (g == 0) g = 1;
   return {xn / g, yn / g, den / g};
@@ -487,11 +496,13 @@ static int winding(const std::vector<Pt>& ring, long double qx, long double qy) 
   int wn = 0;
   const size_t n = ring.size();
   for (size_t i = 0; i < n; ++i) {
-    const Pt &a = ring[i], &b = ring[(i + 1) % n];
+    const Pt &a = ring[i], &b = ring[i + 1 == n ? 0 : i + 1];
+    const bool a_below = (long double)a.y <= qy, b_below = (long double)b.y <= qy;
+    if (a_below == b_below) continue;   // only an edge that straddles the ray's height can count (the same two tests as below)
     const long double cr = (long double)(b.x - a.x) * (qy - a.y) - (qx - a.x) * (long double)(b.y - a.y);
-    if ((long double)a.y <= qy) {
-      if ((long double)b.y > qy && cr > 0) ++wn;
-    } else if ((long double)b.y <= qy && cr < 0) --wn;
+    if (a_below) {
+      if (cr > 0) ++wn;
+    } else if (cr < 0) --wn;
   }
   return wn;
 }
@@ -542,19 +553,32 @@ void positive_union_outer(const std::vector<Pt>& ring_in, std::vector<Pt>& out) 
     if (shoelace2(ring) <= 0) return;
     pts = ring;
   } else {
-  std::map<NodeKey, int> node_id;
-  std::vector<long double> node_x, node_y;
+  // a few dozen nodes at most: a flat list searched front to back (ids in order of first appearance, as a map would give them)
+  // (the containers of this path live with the calling thread: a pool thread runs it for polygon after polygon)
+  struct Scratch {
+    std::vector<NodeKey> node_key;
+    std::vector<long double> node_x, node_y;
+    std::vector<std::vector<Split>> splits;
+  };
+  static thread_local Scratch sc;
+  std::vector<NodeKey>& node_key = sc.node_key;
+  std::vector<long double>&node_x = sc.node_x, &node_y = sc.node_y;
+  node_key.clear();
+  node_x.clear();
+  node_y.clear();
   auto get_node = [&](i128 xn, i128 yn, i128 den) {
     const NodeKey k = make_key(xn, yn, den);
-    auto it = node_id.find(k);
-    if (it != node_id.end()) return it->second;
+    for (size_t id = 0; id < node_key.size(); ++id)
+      if (node_key[id].xn == k.xn && node_key[id].yn == k.yn && node_key[id].den == k.den) return (int)id;
     const int id = (int)node_x.size();
-    node_id.emplace(k, id);
+    node_key.push_back(k);
     node_x.push_back((long double)k.xn / (long double)k.den);
     node_y.push_back((long double)k.yn / (long double)k.den);
     return id;
   };
-  std::vector<std::vector<Split>> splits(n);
+  std::vector<std::vector<Split>>& splits = sc.splits;
+  if ((int)splits.size() < n) splits.resize(n);
+  for (int i = 0; i < n; ++i) splits[i].clear();
   for (int i = 0; i < n; ++i) {
     const Pt &a = ring[i], &b = ring[(i + 1) % n];
     splits[i].push_back({0, 1, get_node(a.x, a.y, 1)});
@@ -607,8 +631,6 @@ void positive_union_outer(const std::vector<Pt>& ring_in, std::vector<Pt>& out) 
     }
   }
   if (edges.empty()) return;
-  std::multimap<int, int> out_of;
-  for (size_t e = 0; e < edges.size(); ++e) out_of.emplace(edges[e].a, (int)e);
   std::vector<std::vector<int>> loops;
   for (size_t e0 = 0; e0 < edges.size(); ++e0) {
     if (edges[e0].used) continue;
@@ -620,12 +642,10 @@ void positive_union_outer(const std::vector<Pt>& ring_in, std::vector<Pt>& out) 
       const int at = edges[cur].b;
       int best = -1;
       double best_turn = 0;
-      auto range = out_of.equal_range(at);
       const double inx = (double)(node_x[edges[cur].b] - node_x[edges[cur].a]);
       const double iny = (double)(node_y[edges[cur].b] - node_y[edges[cur].a]);
-      for (auto it = range.first; it != range.second; ++it) {
-        const int c = it->second;
-        if (edges[c].used) continue;
+      for (int c = 0; c < (int)edges.size(); ++c) {   // the edges leaving this node, in the order they were made
+        if (edges[c].a != at || edges[c].used) continue;
         const double ox = (double)(node_x[edges[c].b] - node_x[edges[c].a]);
         const double oy = (double)(node_y[edges[c].b] - node_y[edges[c].a]);
         const double turn = std::atan2(inx * oy - iny * ox, inx * ox + iny * oy);
