@@ -14,7 +14,7 @@ dev = {k: torch.from_numpy(v).cuda() for k, v in pages.items()}
 pr = [torch.empty_like(dev["text"]), torch.empty_like(dev["text"])]
 blob = W.pack_blob(W.make_det_weights_text())
 for threads in (1, 2, 4):
-    for dc in (0, 1, 2):
+    for dc in (0, 1):
         det = capi.Detector(blob, 0, options=f"post_threads={threads};device_contours={dc}")
         out = []
         for kind in ("text", "dense"):
