@@ -126,3 +126,52 @@ def test_postprocess_is_the_same_with_either_tracer():
         d.close()
     with pytest.raises(capi.OcrError):
         capi.Detector(blob, 0, options="device_contours=3")
+
+
+def test_pipelined_calls_with_pretraced_contours_return_the_same_polygons():
+    """device_contours in the pipelined calls: the contours of a batch are requested when the batch is queued (own stream, behind its
+    forward) and only read by the call that brings its polygons back.  Same polygons and scores as the host tracer, batch after
+    batch: device frames and host frames, batches of changing size (the scratch slot and the staging slots grow while a batch is
+    pending), a crop extraction between two calls, a flush, and an ordinary ocr_det_postprocess in between."""
+    import torch
+    det_w = W.make_det_weights_text()
+    blob = W.pack_blob(det_w)
+    params = capi.default_params(skip_degenerate=True)
+    sizes = [3, 5, 2, 8, 8, 1]
+    pages = [W.synth_text_pages(300 + i, n, 640, 640, dense=bool(i & 1))[0] for i, n in enumerate(sizes)]
+    results = {}
+    for dc in (0, 1, 2):
+        det = capi.Detector(blob, 0, options=f"device_contours={dc};post_threads=2")
+        got = []
+        # device frames
+        dev = [torch.from_numpy(p).cuda() for p in pages]
+        prob = [torch.empty_like(d) for d in dev]
+        crops = torch.empty((4096, 784), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for i, d in enumerate(dev):
+            n = d.shape[0]
+            blk = det.detect_pipelined_block(d.data_ptr(), n, 640, 640, prob[i].data_ptr(), np.ones((n, 2)), params)
+            if blk is not None:
+                pn = dev[i - 1].shape[0]
+                det.extract_crops_block(blk, dev[i - 1].data_ptr(), pn, 640, 640, np.ones((pn, 2)), crops.data_ptr())   # between two calls
+                got.append(capi.polygons_to_python(blk))
+                det.free_block(blk)
+            if i == 2:   # an ordinary post-processing call while a pretraced batch is pending
+                m = np.ascontiguousarray(prob[0].cpu().numpy())
+                got.append(det.postprocess(m, m.shape[0], 640, 640, np.ones((m.shape[0], 2)), capi.MEM_HOST, params))
+        got.append(det.detect_pipelined(0, 0, 0, 0, 0))
+        # host frames (u8, then f32: the staging slots grow)
+        for i, p in enumerate(pages[:4]):
+            x = np.clip(np.rint(p), 0, 255).astype(np.uint8) if i < 2 else np.ascontiguousarray(np.rint(p).astype(np.float32))
+            r = det.detect_pipelined_host(x, adjust_values=np.ones((x.shape[0], 2)), params=params)
+            if r is not None:
+                got.append(r)
+        got.append(det.detect_pipelined_host(None))
+        det.close()
+        results[dc] = got
+    assert len(results[0]) == len(results[1]) == len(results[2]) and len(results[0]) >= 10
+    for dc in (1, 2):
+        for k, (a, b) in enumerate(zip(results[0], results[dc])):
+            assert a[0] == b[0], (dc, k)
+            assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a[1], b[1])), (dc, k)
+    assert sum(len(p) for r in results[0] for p in r[0]) > 100   # there was something to compare
