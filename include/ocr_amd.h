@@ -110,7 +110,9 @@ int ocr_det_create_from_varstore(const char* path, int device, ocr_det_t** out);
 void ocr_det_destroy(ocr_det_t* det);
 
 /* Run all later work of this handle on an existing hipStream_t (e.g. the stream
- * of a torch.cuda.Stream).  NULL restores the handle's own stream. */
+ * of a torch.cuda.Stream).  NULL restores the handle's own stream.
+ * Lifetime: the stream must outlive the handle, or be reset to NULL before it is destroyed - ocr_det_destroy
+ * (and ocr_rec_destroy) wait for the work they queued on it before freeing the buffers that work touches. */
 int ocr_det_set_stream(ocr_det_t* det, void* hip_stream);
 
 /* Arithmetic of the detector (the reference runs f32 only; BASELINE config 5 names bf16 as the optional
@@ -279,6 +281,7 @@ int ocr_rec_create(const void* weights, size_t weights_bytes, int device, ocr_re
  * mapped onto conv1 / conv2 / fc1 / fc2 by shape (all eight shapes differ).  conv1.weight ... names work too. */
 int ocr_rec_create_from_varstore(const char* path, int device, ocr_rec_t** out);
 void ocr_rec_destroy(ocr_rec_t* rec);
+/* Same contract as ocr_det_set_stream, including the lifetime rule. */
 int ocr_rec_set_stream(ocr_rec_t* rec, void* hip_stream);
 /* Options, "key=value;key=value" (NULL or "" changes nothing; an unknown key is OCR_ERR_INVALID):
  *   small_batch=0|1   1 (default): batches of up to 1 024 crops take the latency-optimised kernels (see ocr_rec_forward);

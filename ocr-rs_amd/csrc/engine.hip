@@ -639,7 +639,11 @@ void Detector::synchronize() {
 void* Detector::scratch(int slot, size_t bytes) {
   if (slot < 0 || slot > 3) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
   if (bytes > scratch_bytes_[slot]) {
+    // every stream that may read or write a slot drains before a growing slot is freed (slot 2: post_stream_; slot 3: written on
+    // trace_stream_, read on post_stream_)
     OCR_HIP(hipStreamSynchronize(stream_));
+    if (post_stream_) OCR_HIP(hipStreamSynchronize(post_stream_));
+    if (trace_stream_) OCR_HIP(hipStreamSynchronize(trace_stream_));
     if (scratch_[slot]) OCR_HIP(hipFree(scratch_[slot]));
     scratch_[slot] = nullptr;
     scratch_bytes_[slot] = 0;

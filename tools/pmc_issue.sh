@@ -1,6 +1,7 @@
+#!/bin/bash
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/pmc_issue
 mkdir -p $O
 cd $R
