@@ -175,41 +175,6 @@ def kernel_peak(name: str, dtype: str):
     return "v_mfma_f32 (f32 operands)", 1.0, F32_MFMA_PEAK_TFLOPS
 
 
-def text_like_maps(n: int, s: int, seed: int):
-    """Probability maps with text-like blobs (the reference's gt_shrinked fixtures, cropped to s x s and
-    jittered): random-weight network outputs are noise, which is not what post-processing sees in use."""
-    import numpy as np
-    from PIL import Image
-    rng = np.random.RandomState(seed)
-    names = ["gt_shrinked_img55.png", "gt_shrinked_img224.png", "gt_shrinked_img494.png", "gt_shrinked_img545.png"]
-    base = [np.array(Image.open(os.path.join(ROOT, "tests", "golden", nm)).convert("L")) for nm in names]
-    out = []
-    for i in range(n):
-        g = base[i % 4]
-        o = (800 - s) // 2
-        g = g[o:o + s, o:o + s] if s <= 800 else np.pad(g, ((0, s - 800), (0, s - 800)))
-        out.append(np.where(g > 127, 0.8 + 0.2 * rng.rand(s, s), 0.1 * rng.rand(s, s)).astype(np.float32))
-    return np.ascontiguousarray(np.stack(out)[:, None])
-
-
-def dense_text_maps(n: int, s: int, seed: int):
-    """Post-processing stress maps: a grid of word-sized slanted boxes (about 50 per 640 x 640 frame)."""
-    import numpy as np
-    rng = np.random.RandomState(seed)
-    out = np.empty((n, 1, s, s), np.float32)
-    yy, xx = np.mgrid[0:s, 0:s]
-    for i in range(n):
-        m = np.zeros((s, s), bool)
-        for gy in range(20, s - 40, 64):
-            for gx in range(16, s - 90, 104):
-                w, h = 60 + rng.randint(0, 30), 18 + rng.randint(0, 14)
-                sl = rng.uniform(-0.15, 0.15)
-                x0, y0 = gx + rng.randint(0, 8), gy + rng.randint(0, 8)
-                m |= (xx >= x0) & (xx < x0 + w) & (yy >= y0 + sl * (xx - x0)) & (yy < y0 + h + sl * (xx - x0))
-        out[i, 0] = np.where(m, 0.8 + 0.2 * rng.rand(s, s), 0.1 * rng.rand(s, s))
-    return out
-
-
 def host_cores() -> int:
     """CPU share of this container: cgroup quota if any (a 1-GPU box gets 16), else affinity."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -263,7 +228,7 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
     # unclip - all on host threads; pinned to the reference's known answers by tests/test_oracle_postproc.py), one thread
     # and all cores, on the text-like maps the GPU leg uses
     from oracle import postproc_cpu as PC
-    maps = text_like_maps(32, size, 7)
+    maps = W.text_like_maps(32, size, 7)
     ones = np.ones((32, 2))
     PC.get_boxes_and_box_scores(maps[:2], ones[:2], threads=1, skip_degenerate=True, counts_only=True)
 
@@ -623,7 +588,7 @@ def main():
     polys = scores = pm = adj = params = gathered = None
     try:
         params = capi.default_params(skip_degenerate=True)
-        maps = text_like_maps(n, s, seed=rank)
+        maps = W.text_like_maps(n, s, seed=rank)
         pm = torch.from_numpy(maps).to(x.device)
         adj = np.ones((n, 2))
         torch.cuda.synchronize()
@@ -635,7 +600,7 @@ def main():
         post = {"postprocess_images_per_s": round(n * reps / (time.perf_counter() - t1), 1),
                 "postprocess_polygons_per_image": round(sum(len(p) for p in polys) / n, 2)}
         if rank == 0 and not a.no_extras:
-            dm = torch.from_numpy(dense_text_maps(n, s, 5)).to(x.device)
+            dm = torch.from_numpy(W.dense_text_maps(n, s, 5)).to(x.device)
             npoly, _ = det.postprocess_counts(dm, n, s, s, adj, capi.MEM_DEVICE, params)
             t1 = time.perf_counter()
             for _ in range(reps):

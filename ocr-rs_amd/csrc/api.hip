@@ -180,12 +180,22 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   first_job[n] = (int)jobs.size();
   const int nj = (int)jobs.size();
   std::vector<double> sums(nj), counts(nj);
+  // unclip on the device behind the box score (unclip.hip): per candidate a status, and for the ones it settles the adjusted polygon
+  const bool dev_unclip = det.device_unclip();
+  std::vector<int32_t> ustatus, ulen;
+  std::vector<uint32_t> uxy;
   if (nj > 0) {
+    const size_t npts = pts.size() / 2;
     const size_t o_jobs = 0;
     const size_t o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
     const size_t o_sum = o_pts + align256(pts.size() * 4);
     const size_t o_cnt = o_sum + align256((size_t)nj * 8);
-    const size_t total = o_cnt + align256((size_t)nj * 8);
+    const size_t o_adj = o_cnt + align256((size_t)nj * 8);
+    const size_t o_st = o_adj + align256((size_t)n * 16);
+    const size_t o_len = o_st + align256((size_t)nj * 4);
+    const size_t o_oxy = o_len + align256((size_t)nj * 4);
+    const size_t o_work = o_oxy + align256(dev_unclip ? 3 * npts * 8 : 0);
+    const size_t total = o_work + align256(dev_unclip ? unclip_work_bytes(npts, nj) : 0);
     scratch = static_cast<char*>(det.scratch(1, total));  // slot 0 (map copy) stays valid
     OCR_HIP(hipMemcpyAsync(scratch + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
     OCR_HIP(hipMemcpyAsync(scratch + o_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice, s));
@@ -194,6 +204,20 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
                       reinterpret_cast<double*>(scratch + o_cnt), s);
     OCR_HIP(hipMemcpyAsync(sums.data(), scratch + o_sum, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
     OCR_HIP(hipMemcpyAsync(counts.data(), scratch + o_cnt, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
+    if (dev_unclip) {
+      OCR_HIP(hipMemcpyAsync(scratch + o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
+      const UnclipParams up{prm.box_thresh, prm.unclip_ratio, prm.min_size};
+      launch_unclip(reinterpret_cast<const BoxScoreJob*>(scratch + o_jobs), reinterpret_cast<const int32_t*>(scratch + o_pts), nullptr, nj, npts,
+                    reinterpret_cast<const double*>(scratch + o_sum), reinterpret_cast<const double*>(scratch + o_cnt),
+                    reinterpret_cast<const double*>(scratch + o_adj), up, scratch + o_work, reinterpret_cast<uint32_t*>(scratch + o_oxy),
+                    reinterpret_cast<int32_t*>(scratch + o_len), reinterpret_cast<int32_t*>(scratch + o_st), s);
+      ustatus.resize(nj);
+      ulen.resize(nj);
+      uxy.resize(3 * npts * 2);
+      OCR_HIP(hipMemcpyAsync(ustatus.data(), scratch + o_st, (size_t)nj * 4, hipMemcpyDeviceToHost, s));
+      OCR_HIP(hipMemcpyAsync(ulen.data(), scratch + o_len, (size_t)nj * 4, hipMemcpyDeviceToHost, s));
+      OCR_HIP(hipMemcpyAsync(uxy.data(), scratch + o_oxy, uxy.size() * 4, hipMemcpyDeviceToHost, s));
+    }
     OCR_HIP(hipStreamSynchronize(s));
   }
 #ifdef POSTPROC_TIMING
@@ -212,12 +236,20 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     int j = first_job[b];
     for (const auto& c : cands[b]) {
       const double score = sums[j] / counts[j];
-      ++j;
-      const size_t before = r.xy.size();
-      if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, r.xy)) {
-        r.lens.push_back((int32_t)((r.xy.size() - before) / 2));
+      const int st = dev_unclip ? ustatus[j] : (int)UNCLIP_HOST;
+      if (st == UNCLIP_KEEP) {   // settled on the device
+        const uint32_t* o = uxy.data() + 6 * (size_t)jobs[j].pt_offset;
+        r.xy.insert(r.xy.end(), o, o + 2 * (size_t)ulen[j]);
+        r.lens.push_back(ulen[j]);
         r.scores.push_back(score);
+      } else if (st == UNCLIP_HOST) {
+        const size_t before = r.xy.size();
+        if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, r.xy)) {
+          r.lens.push_back((int32_t)((r.xy.size() - before) / 2));
+          r.scores.push_back(score);
+        }
       }
+      ++j;
     }
   });
   auto res = std::make_unique<PolygonsOwned>();

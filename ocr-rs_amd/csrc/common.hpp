@@ -209,4 +209,18 @@ void launch_box_scores(const float* prob, int H, int W, const BoxScoreJob* jobs_
                        const int32_t* pts_xy_dev, int n_jobs, double* sums_dev, double* counts_dev,
                        hipStream_t s);
 
+// unclip behind the box score (unclip.hip): score threshold, miter offset, the union's simple-ring case, min-size test, adjustment -
+// one lane per candidate.  status: UNCLIP_DROP (filtered out), UNCLIP_KEEP (out_len[j] adjusted points at out_xy + 6 * pt_offset),
+// UNCLIP_HOST (the host finishes this one with postproc_geom.cpp: non-simple ring, squared-off corner, short side within 3 px of min_size, ...)
+struct UnclipParams {
+  double box_thresh, unclip_ratio, min_size;
+};
+enum { UNCLIP_DROP = 0, UNCLIP_KEEP = 1, UNCLIP_HOST = 2 };
+constexpr int kUnclipMaxPts = 256;   // candidates with more vertices go to the host
+size_t unclip_work_bytes(size_t total_pts, int n_jobs);
+// n_jobs_dev: optional device-side job count (the launch covers n_jobs lanes, lanes beyond *n_jobs_dev exit)
+void launch_unclip(const BoxScoreJob* jobs_dev, const int32_t* pts_xy_dev, const int* n_jobs_dev, int n_jobs, size_t total_pts, const double* sums_dev,
+                   const double* counts_dev, const double* adj_dev, const UnclipParams& prm, void* work_dev, uint32_t* out_xy_dev,
+                   int32_t* out_len_dev, int32_t* status_dev, hipStream_t s);
+
 }  // namespace ocr

@@ -247,6 +247,10 @@ void Detector::parse_options(const char* options) {
     else if (key == "pyr_p2_direct") pyr_p2_direct_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") overlap_ = num();
+    else if (key == "w43_cus") {
+      w43_cus_ = num();
+      if (w43_cus_ < 0 || w43_cus_ > 4096) fail(OCR_ERR_INVALID, "detector option w43_cus: %d", w43_cus_);
+    }
     else if (key == "post_threads") {
       post_threads_ = num();
       if (post_threads_ < 0 || post_threads_ > 256) fail(OCR_ERR_INVALID, "detector option post_threads: %d (0 = automatic, at most 256)", post_threads_);
@@ -255,6 +259,7 @@ void Detector::parse_options(const char* options) {
       device_contours_ = num();
       if (device_contours_ < 0 || device_contours_ > 2) fail(OCR_ERR_INVALID, "detector option device_contours: %d (0, 1 or 2)", device_contours_);
     }
+    else if (key == "device_unclip") device_unclip_ = num() != 0;
     else if (key == "mfma") {
       if (val == "split_bf16") split_bf16_ = true;
       else if (val == "f32") split_bf16_ = false;
@@ -890,7 +895,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       {
         rec.begin();
         launch_winograd43_fused(static_cast<const float*>(src), cw.wino43_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
-                                relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, num_cus_, cs);
+                                relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, w43_cus_ > 0 ? w43_cus_ : num_cus_, cs);
         const double px43 = (double)n * hh * ww;
         rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : cw.cin == 128 ? "winograd43_fused<c128>" : "winograd43_fused<c256>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
                 px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 4);

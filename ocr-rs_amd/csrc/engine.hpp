@@ -96,6 +96,9 @@ class Detector {
   // contours on the device (contours.hip)?  option device_contours=1; off by default: a wave follows a border at about the speed of
   // ONE host core per batch (measured), so it pays only where no host core can be spared
   int device_contours() const { return device_contours_; }   // 0 off, 1 parallel form, 2 one wave per image
+  // unclip (score threshold, miter offset, simple-ring union, min-size test, adjustment) on the device behind the box score
+  // (unclip.hip; option device_unclip=0 keeps all of it on the host pool)
+  bool device_unclip() const { return device_unclip_; }
   // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours, slot 3: the same for the batch a pipelined call left pending.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
@@ -144,6 +147,7 @@ class Detector {
   // 3x3 s2 conv1, out5 next to in4 / out4); =2: also the FPN branch (p2, p3) next to layer3 / layer4.
   // forward_profile always runs one stream (clean per-launch timing).
   int overlap_ = 0;
+  int w43_cus_ = 0;        // option w43_cus (tuning): size the fused Winograd kernels' persistent grids for this many CUs (0 = the device's)
   hipStream_t side_stream_ = nullptr;
   hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena arena_;
@@ -232,6 +236,7 @@ class Detector {
   hipEvent_t ev_before_fwd_ = nullptr;
   int post_threads_ = 0;   // option post_threads: 0 = automatic
   int device_contours_ = 0;   // option device_contours
+  bool device_unclip_ = true; // option device_unclip
 };
 
 class Recognizer {

@@ -13,6 +13,7 @@
 // descriptions; the reference's known-answer tests
 // (metrics.rs:406-646) are reproduced by tests/test_capi_cpu.py.
 #include "postproc_geom.hpp"
+#include "hypot_glibc.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -705,6 +706,17 @@ bool expand_polygon(const std::vector<Pt>& pts, double factor, std::vector<Pt>& 
   raw_offset_ring(pts, d, raw);
   positive_union_outer(raw, out);
   return !out.empty();
+}
+
+// the device code's hypot (hypot_glibc.hpp) against this machine's libm on every integer pair up to `limit`: mismatches
+long long hypot_port_mismatches(int limit) {
+  long long bad = 0;
+  for (int a = 0; a <= limit; ++a)
+    for (int b = 0; b <= a; ++b) {
+      if (std::hypot((double)a, (double)b) != hypot_glibc((double)a, (double)b)) ++bad;
+      if (std::hypot((double)-b, (double)a) != hypot_glibc((double)-b, (double)a)) ++bad;
+    }
+  return bad;
 }
 
 // ---------------------------------------------------------------------------

@@ -29,6 +29,7 @@ double offset_distance(const std::vector<Pt>& poly, double factor);
 void raw_offset_ring(const std::vector<Pt>& poly, double delta, std::vector<Pt>& out);
 void positive_union_outer(const std::vector<Pt>& ring, std::vector<Pt>& out);
 bool expand_polygon(const std::vector<Pt>& pts, double factor, std::vector<Pt>& out);
+long long hypot_port_mismatches(int limit);   // hypot_glibc.hpp against std::hypot (test hook)
 
 // eval metrics (eval_metrics.cpp): metrics.rs:229-394
 struct MetricsItem {  // metrics.rs:22-30

@@ -354,6 +354,185 @@ int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, 
     OCR_HIP(hipMemcpy(out, d_y, out_e * 4, hipMemcpyDeviceToHost));
   });
 }
+
+// Two kernels of complementary families on two streams (tuning aid): A = the fused F(4x4,3x3) kernel (f32 MFMA)
+// on n x 160 x 160 x 64 with its persistent grid sized for `w43_cus` CUs (two workgroups each; 128 -> one workgroup per CU), B = one
+// split-bf16 conv_igemm launch (which_b: 0 = 3x3 s2 64 -> 128 from 160 x 160, 1 = 3x3 s2 128 -> 256 from 80 x 80, 2 = the 36 batched
+// Winograd GEMMs of layer3, 3 = 3x3 s2 256 -> 512 from 40 x 40).  ms_out: [0] A alone (per launch), [1] B alone (per launch), [2] wall
+// time of reps_a launches of A on one stream beside reps_b launches of B on another, [3] the same 2 queues on ONE stream.
+int ocr_test_dual_stream_bench(ocr_det_t* det, int n, int which_b, int w43_cus, int reps_a, int reps_b, float* ms_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !ms_out) fail(OCR_ERR_INVALID, "null argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    std::vector<void*> allocs;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    uint32_t st = 4242u;
+    auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    auto dev_rand = [&](size_t elems, float amp) -> float* {
+      std::vector<float> hbuf(elems);
+      for (auto& v : hbuf) v = amp * rnd();
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, elems * 4));
+      allocs.push_back(d);
+      OCR_HIP(hipMemcpy(d, hbuf.data(), elems * 4, hipMemcpyHostToDevice));
+      return static_cast<float*>(d);
+    };
+    auto dev_bytes = [&](const void* src, size_t bytes) -> void* {
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, bytes));
+      allocs.push_back(d);
+      if (src) OCR_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+      return d;
+    };
+    // A
+    const int ha = 160, wa = 160, ca = 64;
+    float* ax = dev_rand((size_t)n * ha * wa * ca, 1.0f);
+    float* ay = static_cast<float*>(dev_bytes(nullptr, (size_t)n * ha * wa * ca * 4));
+    std::vector<float> wg((size_t)ca * 9 * ca);
+    for (auto& v : wg) v = 0.05f * rnd();
+    const std::vector<float> ufr = winograd43_fragments(winograd_weights(wg.data(), ca, ca, 4), ca, ca);
+    float* auf = static_cast<float*>(dev_bytes(ufr.data(), ufr.size() * 4));
+    // B
+    ConvDesc d{};
+    d.x3 = 1;
+    d.src_mode = SRC_PLAIN;
+    d.store_mode = STORE_NHWC;
+    d.relu = 1;
+    d.name = "dual";
+    size_t in_e, w_e, out_e;
+    if (which_b == 2) {
+      const size_t T = (size_t)n * 10 * 10;
+      in_e = 36 * T * 256; w_e = (size_t)36 * 256 * 256; out_e = 36 * T * 256;
+      d.batch = 36; d.N = 1; d.Hin = d.Ho = 1; d.Win = d.Wo = (int)T; d.Cin = 256; d.Cout = 256; d.ks = 1; d.stride = 1; d.pad = 0;
+    } else {
+      const int hb = which_b == 0 ? 160 : which_b == 1 ? 80 : 40, cb = which_b == 0 ? 64 : which_b == 1 ? 128 : 256;
+      in_e = (size_t)n * hb * hb * cb; w_e = (size_t)2 * cb * 9 * cb; out_e = (size_t)n * (hb / 2) * (hb / 2) * 2 * cb;
+      d.N = n; d.Hin = d.Win = hb; d.Ho = d.Wo = hb / 2; d.Cin = cb; d.Cout = 2 * cb; d.ks = 3; d.stride = 2; d.pad = 1;
+    }
+    d.src[0] = dev_rand(in_e, 1.0f);
+    d.src_bytes = in_e * 4;
+    std::vector<float> hw(w_e);
+    for (auto& v : hw) v = 0.05f * rnd();
+    const std::vector<uint16_t> planes = split3_weights(hw.data(), w_e);
+    d.wgt = dev_bytes(planes.data(), planes.size() * 2);
+    d.wgt_bytes = w_e * 6;
+    d.out = dev_bytes(nullptr, out_e * 4);
+    hipStream_t sa, sb;
+    OCR_HIP(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    OCR_HIP(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipEvent_t e0, e1, e2;
+    OCR_HIP(hipEventCreate(&e0));
+    OCR_HIP(hipEventCreate(&e1));
+    OCR_HIP(hipEventCreate(&e2));
+    auto run_a = [&](hipStream_t s) { launch_winograd43_fused(ax, auf, nullptr, nullptr, nullptr, 1, ay, n, ha, wa, ca, ca, w43_cus, s); };
+    auto run_b = [&](hipStream_t s) { launch_conv_igemm(d, s); };
+    float ms = 0.f;
+    for (int i = 0; i < 3; ++i) { run_a(sa); run_b(sa); }
+    OCR_HIP(hipEventRecord(e0, sa));
+    for (int i = 0; i < reps_a; ++i) run_a(sa);
+    OCR_HIP(hipEventRecord(e1, sa));
+    for (int i = 0; i < reps_b; ++i) run_b(sa);
+    OCR_HIP(hipEventRecord(e2, sa));
+    OCR_HIP(hipStreamSynchronize(sa));
+    OCR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    ms_out[0] = ms / reps_a;
+    OCR_HIP(hipEventElapsedTime(&ms, e1, e2));
+    ms_out[1] = ms / reps_b;
+    OCR_HIP(hipEventElapsedTime(&ms, e0, e2));
+    ms_out[3] = ms;
+    // together: both streams start behind e0, the end is when both have drained
+    OCR_HIP(hipEventRecord(e0, sa));
+    OCR_HIP(hipStreamWaitEvent(sb, e0, 0));
+    for (int i = 0; i < std::max(reps_a, reps_b); ++i) {   // interleaved submission
+      if (i < reps_a) run_a(sa);
+      if (i < reps_b) run_b(sb);
+    }
+    OCR_HIP(hipEventRecord(e1, sb));
+    OCR_HIP(hipStreamWaitEvent(sa, e1, 0));
+    OCR_HIP(hipEventRecord(e2, sa));
+    OCR_HIP(hipStreamSynchronize(sa));
+    OCR_HIP(hipEventElapsedTime(&ms, e0, e2));
+    ms_out[2] = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    (void)hipStreamDestroy(sa); (void)hipStreamDestroy(sb);
+  });
+}
+
+// unclip.hip against postproc_geom.cpp::finish_polygon on caller polygons (one image, given scores): every polygon the device settles
+// (UNCLIP_KEEP / UNCLIP_DROP) must be what the host does with it; counts how many it hands back (UNCLIP_HOST).  stats: keep, host, drop, mismatches.
+int ocr_test_unclip_compare(ocr_det_t* det, const int32_t* xy, const int32_t* counts, int n_polys, const double* scores, double adj_x,
+                            double adj_y, double box_thresh, double unclip_ratio, double min_size, int32_t* stats, int32_t* status_out,
+                            int32_t* len_out, uint32_t* xy_out) {   // the three optional: per polygon status, length, and 3 x its input points of (x, y) room
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !xy || !counts || !scores || !stats || n_polys <= 0) fail(OCR_ERR_INVALID, "bad argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    std::vector<BoxScoreJob> jobs(n_polys);
+    std::vector<double> sums(scores, scores + n_polys), cnts(n_polys, 1.0);
+    size_t npts = 0;
+    for (int k = 0; k < n_polys; ++k) {
+      jobs[k] = BoxScoreJob{0, (int)npts, counts[k], 0, 0, 1, 1};
+      npts += (size_t)counts[k];
+    }
+    std::vector<void*> allocs;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    auto dev = [&](const void* src, size_t bytes) -> void* {
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+      allocs.push_back(d);
+      if (src) OCR_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+      return d;
+    };
+    const double adj[2] = {adj_x, adj_y};
+    auto* d_jobs = static_cast<BoxScoreJob*>(dev(jobs.data(), jobs.size() * sizeof(BoxScoreJob)));
+    auto* d_pts = static_cast<int32_t*>(dev(xy, npts * 8));
+    auto* d_sum = static_cast<double*>(dev(sums.data(), sums.size() * 8));
+    auto* d_cnt = static_cast<double*>(dev(cnts.data(), cnts.size() * 8));
+    auto* d_adj = static_cast<double*>(dev(adj, 16));
+    void* d_work = dev(nullptr, unclip_work_bytes(npts, n_polys));
+    auto* d_oxy = static_cast<uint32_t*>(dev(nullptr, 3 * npts * 8));
+    auto* d_len = static_cast<int32_t*>(dev(nullptr, (size_t)n_polys * 4));
+    auto* d_st = static_cast<int32_t*>(dev(nullptr, (size_t)n_polys * 4));
+    const UnclipParams up{box_thresh, unclip_ratio, min_size};
+    launch_unclip(d_jobs, d_pts, nullptr, n_polys, npts, d_sum, d_cnt, d_adj, up, d_work, d_oxy, d_len, d_st, s);
+    OCR_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> st(n_polys), len(n_polys);
+    std::vector<uint32_t> oxy(3 * npts * 2);
+    OCR_HIP(hipMemcpy(st.data(), d_st, st.size() * 4, hipMemcpyDeviceToHost));
+    OCR_HIP(hipMemcpy(len.data(), d_len, len.size() * 4, hipMemcpyDeviceToHost));
+    OCR_HIP(hipMemcpy(oxy.data(), d_oxy, oxy.size() * 4, hipMemcpyDeviceToHost));
+    ocr_postproc_params_t prm{};
+    ocr_postproc_default_params(&prm);
+    prm.box_thresh = box_thresh;
+    prm.unclip_ratio = unclip_ratio;
+    prm.min_size = min_size;
+    prm.skip_degenerate = 1;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (status_out) std::copy(st.begin(), st.end(), status_out);
+    if (len_out) std::copy(len.begin(), len.end(), len_out);
+    if (xy_out) std::copy(oxy.begin(), oxy.end(), xy_out);
+    for (int k = 0; k < n_polys; ++k) {
+      std::vector<geom::Pt> c((size_t)counts[k]);
+      for (int i = 0; i < counts[k]; ++i) c[i] = {xy[2 * (jobs[k].pt_offset + i)], xy[2 * (jobs[k].pt_offset + i) + 1]};
+      std::vector<uint32_t> hxy;
+      const bool kept = geom::finish_polygon(c, scores[k], adj_x, adj_y, prm, hxy);
+      if (st[k] == UNCLIP_KEEP) {
+        ++stats[0];
+        const uint32_t* o = oxy.data() + 6 * (size_t)jobs[k].pt_offset;
+        if (!kept || hxy.size() != 2 * (size_t)len[k] || !std::equal(hxy.begin(), hxy.end(), o)) ++stats[3];
+      } else if (st[k] == UNCLIP_HOST) {
+        ++stats[1];
+      } else {
+        ++stats[2];
+        if (kept || !(box_thresh > scores[k])) ++stats[3];
+      }
+    }
+  });
+}
+// no GPU: the device code's restatement of glibc's hypot against std::hypot on all integer pairs up to `limit`
+long long ocr_test_hypot_port_mismatches(int limit) { return ocr::geom::hypot_port_mismatches(limit); }
 int ocr_test_set_conv_debug(int d) {
   ocr::set_conv_debug(d);
   return OCR_OK;

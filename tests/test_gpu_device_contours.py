@@ -4,10 +4,10 @@ pixels and order decide what Douglas-Peucker keeps - and the same polygons out o
 import numpy as np
 import pytest
 
-import bench
 import ocr_rs_amd  # noqa: F401
 from ocr_rs_amd import capi
 from ocr_rs_amd import weights as W
+from oracle import postproc_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -37,10 +37,10 @@ def _cases():
     out.append(("checkerboard", ((np.add.outer(np.arange(64), np.arange(64))) % 2).astype(np.uint8)))
     out.append(("stripes", (np.arange(128)[None, :] % 3 == 0).astype(np.uint8).repeat(40, 0)))
     out.append(("diagonals", (np.add.outer(np.arange(96), np.arange(96)) % 7 < 2).astype(np.uint8)))
-    out.append(("text-like 640", (bench.text_like_maps(1, 640, 3)[0, 0] > 0.6).astype(np.uint8)))
-    out.append(("dense 640", (bench.dense_text_maps(1, 640, 4)[0, 0] > 0.6).astype(np.uint8)))
-    out.append(("text-like 640 b", (bench.text_like_maps(1, 640, 13)[0, 0] > 0.6).astype(np.uint8)))
-    out.append(("dense 320", (bench.dense_text_maps(1, 320, 14)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("text-like 640", (W.text_like_maps(1, 640, 3)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("dense 640", (W.dense_text_maps(1, 640, 4)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("text-like 640 b", (W.text_like_maps(1, 640, 13)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("dense 320", (W.dense_text_maps(1, 320, 14)[0, 0] > 0.6).astype(np.uint8)))
     return out
 
 
@@ -66,6 +66,13 @@ def test_device_contours_equal_host_contours(case, sequential):
     assert len(got) == len(want), (len(got), len(want))
     for k, (a, b) in enumerate(zip(got, want)):
         assert a == b, f"contour {k} differs"
+    # ... and the ORACLE's contours (oracle/postproc_oracle.py: the restatement of imageproc's find_contours that the reference's
+    # known answers pin), not only the product's host tracer; the pure-Python walk is kept to the maps it finishes in seconds
+    if bm.size <= 160 * 160 or name in ("rings and lines", "touching every border", "text-like 640", "dense 320"):
+        oracle = [[(int(x), int(y)) for x, y in c] for c in O.find_contours(bm * 255)]
+        assert len(got) == len(oracle), (len(got), len(oracle))
+        for k, (a, b) in enumerate(zip(got, oracle)):
+            assert [tuple(q) for q in a] == b, f"contour {k} differs from the oracle's"
 
 
 def test_parallel_form_takes_the_usual_maps():
@@ -113,9 +120,9 @@ def test_postprocess_is_the_same_with_either_tracer():
     for _ in range(5):
         smooth = (smooth + np.roll(smooth, 1, 2) + np.roll(smooth, 1, 3) + np.roll(smooth, -1, 2) + np.roll(smooth, -1, 3)) / 5
     smooth = ((smooth - smooth.min()) / (smooth.max() - smooth.min())).astype(np.float32)
-    mixed = np.concatenate([bench.dense_text_maps(2, 640, 7), noise[:1], bench.text_like_maps(1, 640, 8)])
-    for name, maps in (("text", bench.text_like_maps(4, 640, 1)), ("dense", bench.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
-                       ("mixed", mixed), ("800", bench.text_like_maps(1, 800, 9))):
+    mixed = np.concatenate([W.dense_text_maps(2, 640, 7), noise[:1], W.text_like_maps(1, 640, 8)])
+    for name, maps in (("text", W.text_like_maps(4, 640, 1)), ("dense", W.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
+                       ("mixed", mixed), ("800", W.text_like_maps(1, 800, 9))):
         adj = np.ones((maps.shape[0], 2)) * np.array([1.25, 0.8])
         want = _post(host, maps, adj)
         for d in (dev, dev2):

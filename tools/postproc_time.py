@@ -4,7 +4,6 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-import bench
 import ocr_rs_amd  # noqa
 from ocr_rs_amd import capi, weights as W
 pt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -13,7 +12,7 @@ det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0, options=f"post_thread
 n, s = 32, 640
 params = capi.default_params(skip_degenerate=True)
 adj = np.ones((n, 2))
-for name, maps in (("text-like", bench.text_like_maps(n, s, 0)), ("dense", bench.dense_text_maps(n, s, 5))):
+for name, maps in (("text-like", W.text_like_maps(n, s, 0)), ("dense", W.dense_text_maps(n, s, 5))):
     pm = torch.from_numpy(maps).cuda(); torch.cuda.synchronize()
     polys, _ = det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
     best = 1e9
