@@ -63,7 +63,10 @@ static void pretrace_pending(ocr::Detector& d) {
 }
 
 // get_boxes_and_box_scores (metrics.rs:37-56) over the whole batch.  Dense, regular work on the GPU (binarisation into
-// a packed bit image, box scores), irregular work on the detector's host thread pool, one image per task.
+// a packed bit image, box scores, unclip), irregular work on the detector's host thread pool, one image per task.
+// With device contours AND device polygons (options device_contours, device_polygons) a square map's whole chain runs on the
+// device - trace, Douglas-Peucker, job list, box scores, unclip - and the host only collects results; it still finishes the polygons
+// the unclip kernel hands back (UNCLIP_HOST) and takes, from the bit image on, the images the tracer gave up.
 // pretraced: the batch's contours were requested on `s` earlier (enqueue_contours into scratch slot 3): only read them
 void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
                  const ocr_postproc_params_t& prm, ocr_polygons_t** out, hipStream_t s, bool pretraced = false) {
@@ -79,6 +82,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   const size_t hw = (size_t)h * w, px = (size_t)n * hw;
   const size_t wpi = binarize_pack_words(hw);  // 32-bit words per packed image
   const bool dev_trace = pretraced || (det.device_contours() && contour_trace_fits(h, w));
+  const bool dev_chain = dev_trace && det.device_polygons() && det.device_unclip() && h == w;
   // scratch: [prob copy if host] [packed bitmaps]
   const size_t off_bits = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
   char* scratch = static_cast<char*>(det.scratch(0, off_bits + align256((size_t)n * wpi * 4)));
@@ -90,9 +94,128 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   }
   uint32_t* bits_dev = reinterpret_cast<uint32_t*>(scratch + off_bits);
   ThreadPool& pool = det.pool();
+  struct PerImage {
+    std::vector<uint32_t> xy;
+    std::vector<int32_t> lens;
+    std::vector<double> scores;
+  };
+  std::vector<PerImage> per(n);
   std::vector<std::vector<std::vector<geom::Pt>>> cands(n);
+  std::vector<int> todo;            // images whose candidates the host has (or must make): box scores + unclip in the second part
   std::vector<uint32_t> bits;
-  if (dev_trace) {
+  const bool dev_unclip = det.device_unclip();
+  const UnclipParams up{prm.box_thresh, prm.unclip_ratio, prm.min_size};
+  // a device-settled or host-finished candidate into its image's lists
+  auto take = [&](PerImage& r, int st, const uint32_t* o, int olen, const std::vector<geom::Pt>& c, double score, int b) {
+    if (st == UNCLIP_KEEP) {
+      r.xy.insert(r.xy.end(), o, o + 2 * (size_t)olen);
+      r.lens.push_back(olen);
+      r.scores.push_back(score);
+    } else if (st == UNCLIP_HOST) {
+      const size_t before = r.xy.size();
+      if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, r.xy)) {
+        r.lens.push_back((int32_t)((r.xy.size() - before) / 2));
+        r.scores.push_back(score);
+      }
+    }
+  };
+
+  if (dev_chain) {
+    // ---- everything on the device (contours.hip, candidates.hip, box_score.hip, unclip.hip); ONE round trip of small headers,
+    // one of results
+    ContourBuffers cb(n, hw);
+    if (pretraced) {   // filled when the batch was queued
+      cb.base = static_cast<char*>(det.scratch(3, cb.total));
+      OCR_HIP(hipStreamWaitEvent(s, det.trace_done_event(), 0));
+    } else {
+      cb = enqueue_contours(det, 2, prob_dev, n, h, w, (float)prm.thresh, s);
+    }
+    bits_dev = cb.bits();
+    const int max_jobs = n * 1024, max_pts = n * 8192;   // a dense page: 60 - 130 candidates of 4 - 12 points; more -> host path
+    const size_t o_jobs = 0;
+    const size_t o_pts = o_jobs + align256((size_t)max_jobs * sizeof(BoxScoreJob));
+    const size_t o_sum = o_pts + align256((size_t)max_pts * 8);
+    const size_t o_cnt = o_sum + align256((size_t)max_jobs * 8);
+    const size_t o_adj = o_cnt + align256((size_t)max_jobs * 8);
+    const size_t o_st = o_adj + align256((size_t)n * 16);
+    const size_t o_len = o_st + align256((size_t)max_jobs * 4);
+    const size_t o_oxy = o_len + align256((size_t)max_jobs * 4);
+    const size_t o_work = o_oxy + align256(3 * (size_t)max_pts * 8);
+    const size_t o_tot = o_work + align256(unclip_work_bytes((size_t)max_pts, max_jobs));
+    const size_t o_hd = o_tot + align256((size_t)n * 8);
+    const size_t o_cs = o_hd + 256;
+    const size_t total = o_cs + candidates_scratch_bytes(n, ContourBuffers::CAP, ContourBuffers::MAXC);
+    char* sc = static_cast<char*>(det.scratch(1, total));
+    auto* d_jobs = reinterpret_cast<BoxScoreJob*>(sc + o_jobs);
+    auto* d_pts = reinterpret_cast<int32_t*>(sc + o_pts);
+    auto* d_sum = reinterpret_cast<double*>(sc + o_sum);
+    auto* d_cnt = reinterpret_cast<double*>(sc + o_cnt);
+    int* d_totals = reinterpret_cast<int*>(sc + o_hd);
+    OCR_HIP(hipMemcpyAsync(sc + o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    launch_candidates(reinterpret_cast<const int*>(cb.base + cb.o_hdr), reinterpret_cast<const uint32_t*>(cb.base + cb.o_pts), ContourBuffers::CAP,
+                      reinterpret_cast<const int*>(cb.base + cb.o_st), ContourBuffers::MAXC, n, h, w, sc + o_cs, d_jobs, max_jobs, d_pts, max_pts,
+                      reinterpret_cast<int*>(sc + o_tot), d_totals, s);
+    launch_box_scores_counted(prob_dev, h, w, d_jobs, d_pts, d_totals, std::min(max_jobs, 4096), d_sum, d_cnt, s);
+    launch_unclip(d_jobs, d_pts, d_totals, max_jobs, (size_t)max_pts, d_sum, d_cnt, reinterpret_cast<const double*>(sc + o_adj), up, sc + o_work,
+                  reinterpret_cast<uint32_t*>(sc + o_oxy), reinterpret_cast<int32_t*>(sc + o_len), reinterpret_cast<int32_t*>(sc + o_st), s);
+    std::vector<int32_t> tot((size_t)n * 2);
+    int32_t totals[4] = {0, 0, 0, 0};
+    OCR_HIP(hipMemcpyAsync(tot.data(), sc + o_tot, tot.size() * 4, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipMemcpyAsync(totals, d_totals, 12, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
+#ifdef POSTPROC_TIMING
+    T1 = T2 = tnow();
+#endif
+    if (totals[2] != 0) {
+      for (int b = 0; b < n; ++b) todo.push_back(b);   // the lists overflowed: the host path takes the batch
+    } else {
+      const int tj = totals[0];
+      const size_t tp = (size_t)totals[1];
+      std::vector<BoxScoreJob> jobs(tj);
+      std::vector<double> sums(tj), counts(tj);
+      std::vector<int32_t> ustatus(tj), ulen(tj), pts(tp * 2);
+      std::vector<uint32_t> uxy(3 * tp * 2);
+      if (tj > 0) {
+        OCR_HIP(hipMemcpyAsync(jobs.data(), d_jobs, (size_t)tj * sizeof(BoxScoreJob), hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(sums.data(), d_sum, (size_t)tj * 8, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(counts.data(), d_cnt, (size_t)tj * 8, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(ustatus.data(), sc + o_st, (size_t)tj * 4, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(ulen.data(), sc + o_len, (size_t)tj * 4, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(pts.data(), d_pts, tp * 8, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(uxy.data(), sc + o_oxy, uxy.size() * 4, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipStreamSynchronize(s));
+      }
+      std::vector<int> first_job(n + 1, 0);
+      {
+        int at = 0;
+        for (int b = 0; b < n; ++b) {
+          first_job[b] = at;
+          if (tot[2 * b] > 0) at += tot[2 * b];
+          if (tot[2 * b] < 0) todo.push_back(b);
+        }
+        first_job[n] = at;
+        if (at != tj) fail(OCR_ERR_INTERNAL, "postprocess: device job list holds %d jobs, its image table %d", tj, at);
+      }
+      pool.parallel_for(n, [&](int b) {
+        std::vector<geom::Pt> c;
+        for (int j = first_job[b]; j < first_job[b + 1]; ++j) {
+          const BoxScoreJob& jb = jobs[j];
+          const double score = sums[j] / counts[j];
+          if (ustatus[j] == UNCLIP_HOST) {
+            c.resize((size_t)jb.n_pts);
+            for (int i = 0; i < jb.n_pts; ++i) c[i] = {pts[2 * ((size_t)jb.pt_offset + i)], pts[2 * ((size_t)jb.pt_offset + i) + 1]};
+          }
+          take(per[b], ustatus[j], uxy.data() + 6 * (size_t)jb.pt_offset, ulen[j], c, score, b);
+        }
+      });
+    }
+    if (!todo.empty()) {   // the images the device gave up: bit image to the host, host tracer + Douglas-Peucker
+      bits.resize((size_t)n * wpi);
+      for (int b : todo) OCR_HIP(hipMemcpyAsync(bits.data() + (size_t)b * wpi, bits_dev + (size_t)b * wpi, wpi * 4, hipMemcpyDeviceToHost, s));
+      OCR_HIP(hipStreamSynchronize(s));
+      pool.parallel_for((int)todo.size(), [&](int k) { geom::contour_candidates_bits(bits.data() + (size_t)todo[k] * wpi, h, w, cands[todo[k]]); });
+    }
+  } else if (dev_trace) {
     // contour tracing on the device (contours.hip), Douglas-Peucker on the pool.  An image the device gives up on (buffers too
     // small - noise: thousands of contours - or a start outside the parallel form's list) takes the host tracer below.
     ContourBuffers cb(n, hw);
@@ -132,6 +255,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
       if (hdr[4 * b + 2] == 0) geom::contour_candidates_packed(cpts.data() + p_at[b], clens.data() + c_at[b], hdr[4 * b], cands[b]);
       else geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]);
     });
+    for (int b = 0; b < n; ++b) todo.push_back(b);
   } else {
     launch_binarize_pack(prob_dev, bits_dev, (float)prm.thresh, n, hw, s);  // metrics.rs:41,129
     bits.resize((size_t)n * wpi);
@@ -142,17 +266,19 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
 #endif
     // contour tracing + Douglas-Peucker (metrics.rs:78-98)
     pool.parallel_for(n, [&](int b) { geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]); });
+    for (int b = 0; b < n; ++b) todo.push_back(b);
   }
 #ifdef POSTPROC_TIMING
-  T2 = tnow();
+  if (!dev_chain) T2 = tnow();
 #endif
 
-  // box scores on the GPU (metrics.rs:99 -> :150-184)
+  // ---- the images whose candidates are on the host: box scores on the GPU (metrics.rs:99 -> :150-184), unclip behind them
   std::vector<BoxScoreJob> jobs;
   std::vector<int32_t> pts;
-  std::vector<int> first_job(n + 1, 0);
-  for (int b = 0; b < n; ++b) {
-    first_job[b] = (int)jobs.size();
+  std::vector<int> first_job(todo.size() + 1, 0);
+  for (size_t k = 0; k < todo.size(); ++k) {
+    const int b = todo[k];
+    first_job[k] = (int)jobs.size();
     for (const auto& c : cands[b]) {
       if ((int)c.size() > kBoxScoreMaxPts) fail(OCR_ERR_INVALID, "polygon with %zu vertices exceeds %d", c.size(), kBoxScoreMaxPts);
       int mnx = INT32_MAX, mxx = 0, mny = INT32_MAX, mxy = 0;
@@ -177,11 +303,10 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
       }
     }
   }
-  first_job[n] = (int)jobs.size();
+  first_job[todo.size()] = (int)jobs.size();
   const int nj = (int)jobs.size();
   std::vector<double> sums(nj), counts(nj);
   // unclip on the device behind the box score (unclip.hip): per candidate a status, and for the ones it settles the adjusted polygon
-  const bool dev_unclip = det.device_unclip();
   std::vector<int32_t> ustatus, ulen;
   std::vector<uint32_t> uxy;
   if (nj > 0) {
@@ -206,7 +331,6 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     OCR_HIP(hipMemcpyAsync(counts.data(), scratch + o_cnt, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
     if (dev_unclip) {
       OCR_HIP(hipMemcpyAsync(scratch + o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
-      const UnclipParams up{prm.box_thresh, prm.unclip_ratio, prm.min_size};
       launch_unclip(reinterpret_cast<const BoxScoreJob*>(scratch + o_jobs), reinterpret_cast<const int32_t*>(scratch + o_pts), nullptr, nj, npts,
                     reinterpret_cast<const double*>(scratch + o_sum), reinterpret_cast<const double*>(scratch + o_cnt),
                     reinterpret_cast<const double*>(scratch + o_adj), up, scratch + o_work, reinterpret_cast<uint32_t*>(scratch + o_oxy),
@@ -224,34 +348,19 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   T3 = tnow();
 #endif
 
-  // unclip + filters + coordinate adjustment (metrics.rs:100-123) per image on the pool, then the CSR block in image order
-  struct PerImage {
-    std::vector<uint32_t> xy;
-    std::vector<int32_t> lens;
-    std::vector<double> scores;
-  };
-  std::vector<PerImage> per(n);
-  pool.parallel_for(n, [&](int b) {
+  // what the device did not settle - filters + unclip + coordinate adjustment (metrics.rs:100-123) - per image on the pool
+  pool.parallel_for((int)todo.size(), [&](int k) {
+    const int b = todo[k];
     PerImage& r = per[b];
-    int j = first_job[b];
+    int j = first_job[k];
     for (const auto& c : cands[b]) {
       const double score = sums[j] / counts[j];
-      const int st = dev_unclip ? ustatus[j] : (int)UNCLIP_HOST;
-      if (st == UNCLIP_KEEP) {   // settled on the device
-        const uint32_t* o = uxy.data() + 6 * (size_t)jobs[j].pt_offset;
-        r.xy.insert(r.xy.end(), o, o + 2 * (size_t)ulen[j]);
-        r.lens.push_back(ulen[j]);
-        r.scores.push_back(score);
-      } else if (st == UNCLIP_HOST) {
-        const size_t before = r.xy.size();
-        if (geom::finish_polygon(c, score, adj[2 * b], adj[2 * b + 1], prm, r.xy)) {
-          r.lens.push_back((int32_t)((r.xy.size() - before) / 2));
-          r.scores.push_back(score);
-        }
-      }
+      take(r, dev_unclip ? ustatus[j] : (int)UNCLIP_HOST, dev_unclip ? uxy.data() + 6 * (size_t)jobs[j].pt_offset : nullptr, dev_unclip ? ulen[j] : 0, c,
+           score, b);
       ++j;
     }
   });
+  // the CSR block in image order
   auto res = std::make_unique<PolygonsOwned>();
   res->img_offsets.push_back(0);
   res->poly_offsets.push_back(0);

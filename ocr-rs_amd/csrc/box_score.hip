@@ -30,11 +30,15 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void box_score_kernel(const float* __restrict__ prob, int H, int W,
                                                         const BoxScoreJob* __restrict__ jobs,
                                                         const int32_t* __restrict__ pts_xy,
-                                                        double* __restrict__ sums, double* __restrict__ counts) {
+                                                        double* __restrict__ sums, double* __restrict__ counts, int n_jobs,
+                                                        const int* __restrict__ n_jobs_dev) {
   __shared__ int px[kBoxScoreMaxPts], py[kBoxScoreMaxPts];
   __shared__ unsigned mask[BAND_WORDS];
   __shared__ double red[4];
-  const BoxScoreJob job = jobs[blockIdx.x];
+  // one workgroup per job - or, when the job count only exists on the device (candidates.hip), a fixed grid walking the list
+  if (n_jobs_dev) n_jobs = *n_jobs_dev;
+  for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
+  const BoxScoreJob job = jobs[jb];
   const int tid = threadIdx.x;
   const int np = job.n_pts;
   for (int i = tid; i < np; i += 256) {  // moved_points: relative to the canvas origin
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256) void box_score_kernel(const float* __restrict_
   const double ts = block_sum(sum, red);
   const double tc = block_sum(cnt, red);
   if (tid == 0) {
-    sums[blockIdx.x] = ts;
-    counts[blockIdx.x] = tc;
+    sums[jb] = ts;
+    counts[jb] = tc;
+  }
+  __syncthreads();
   }
 }
 
@@ -137,7 +143,14 @@ void launch_box_scores(const float* prob, int H, int W, const BoxScoreJob* jobs_
                        int n_jobs, double* sums_dev, double* counts_dev, hipStream_t s) {
   if (n_jobs <= 0) return;
   hipLaunchKernelGGL(box_score_kernel, dim3(n_jobs), dim3(256), 0, s, prob, H, W, jobs_dev, pts_xy_dev, sums_dev,
-                     counts_dev);
+                     counts_dev, n_jobs, static_cast<const int*>(nullptr));
+  OCR_HIP(hipGetLastError());
+}
+
+void launch_box_scores_counted(const float* prob, int H, int W, const BoxScoreJob* jobs_dev, const int32_t* pts_xy_dev, const int* n_jobs_dev, int grid,
+                               double* sums_dev, double* counts_dev, hipStream_t s) {
+  if (grid <= 0) return;
+  hipLaunchKernelGGL(box_score_kernel, dim3(grid), dim3(256), 0, s, prob, H, W, jobs_dev, pts_xy_dev, sums_dev, counts_dev, 0, n_jobs_dev);
   OCR_HIP(hipGetLastError());
 }
 

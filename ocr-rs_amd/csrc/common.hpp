@@ -209,6 +209,16 @@ void launch_box_scores(const float* prob, int H, int W, const BoxScoreJob* jobs_
                        const int32_t* pts_xy_dev, int n_jobs, double* sums_dev, double* counts_dev,
                        hipStream_t s);
 
+// the same with the job count on the device (candidates.hip's totals[0]): `grid` workgroups walk the list
+void launch_box_scores_counted(const float* prob, int H, int W, const BoxScoreJob* jobs_dev, const int32_t* pts_xy_dev, const int* n_jobs_dev, int grid,
+                               double* sums_dev, double* counts_dev, hipStream_t s);
+// candidates.hip: device contours (contours.hip's hdr / pts / starts) -> arc length, Douglas-Peucker, >= 4 points -> the batch's
+// box-score jobs and points in image / contour order.  totals = {jobs, points, overflow}; images with a tracer status contribute nothing
+size_t candidates_scratch_bytes(int n, int cap, int maxc);
+void launch_candidates(const int* hdr, const uint32_t* pts, int cap, const int* starts, int maxc, int n, int h, int w, void* scratch, BoxScoreJob* jobs,
+                       int max_jobs, int32_t* pts_xy, int max_pts, int* tot /* [n][2] = {candidates, points} or -1 -1: the host takes the image */,
+                       int* totals, hipStream_t s);
+
 // unclip behind the box score (unclip.hip): score threshold, miter offset, the union's simple-ring case, min-size test, adjustment -
 // one lane per candidate.  status: UNCLIP_DROP (filtered out), UNCLIP_KEEP (out_len[j] adjusted points at out_xy + 6 * pt_offset),
 // UNCLIP_HOST (the host finishes this one with postproc_geom.cpp: non-simple ring, squared-off corner, short side within 3 px of min_size, ...)

@@ -260,6 +260,7 @@ void Detector::parse_options(const char* options) {
       if (device_contours_ < 0 || device_contours_ > 2) fail(OCR_ERR_INVALID, "detector option device_contours: %d (0, 1 or 2)", device_contours_);
     }
     else if (key == "device_unclip") device_unclip_ = num() != 0;
+    else if (key == "device_polygons") device_polygons_ = num() != 0;
     else if (key == "mfma") {
       if (val == "split_bf16") split_bf16_ = true;
       else if (val == "f32") split_bf16_ = false;

@@ -99,6 +99,9 @@ class Detector {
   // unclip (score threshold, miter offset, simple-ring union, min-size test, adjustment) on the device behind the box score
   // (unclip.hip; option device_unclip=0 keeps all of it on the host pool)
   bool device_unclip() const { return device_unclip_; }
+  // with device contours: Douglas-Peucker and the box-score job list on the device too (candidates.hip; option device_polygons=0
+  // brings the contours back and leaves them to the host pool)
+  bool device_polygons() const { return device_polygons_; }
   // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours, slot 3: the same for the batch a pipelined call left pending.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
@@ -237,6 +240,7 @@ class Detector {
   int post_threads_ = 0;   // option post_threads: 0 = automatic
   int device_contours_ = 0;   // option device_contours
   bool device_unclip_ = true; // option device_unclip
+  bool device_polygons_ = true;   // option device_polygons
 };
 
 class Recognizer {

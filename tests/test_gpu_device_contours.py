@@ -107,13 +107,16 @@ def _post(det, maps, adj):
 
 
 def test_postprocess_is_the_same_with_either_tracer():
-    """ocr_det_postprocess with device_contours=1 (parallel form) / 2 (one wave per image) / 0: identical polygon lists and
+    """ocr_det_postprocess with device_contours=1 (parallel form) / 2 (one wave per image) / 0 - with the contours the whole chain
+    (Douglas-Peucker, job list, box scores, unclip: candidates.hip, unclip.hip) stays on the device unless device_polygons=0 -: identical polygon lists and
     scores on text-like and dense maps, on noise whose thousands of contours overflow the device buffers (those images fall back to the
     host tracer inside the call), on a mixed batch, and on a size the device tracer does not take."""
     blob = W.pack_blob(W.make_det_weights(0))
     host = capi.Detector(blob, 0, options="device_contours=0")
     dev = capi.Detector(blob, 0, options="device_contours=1")
     dev2 = capi.Detector(blob, 0, options="device_contours=2;post_threads=2")     # the one-wave-per-image form
+    dev3 = capi.Detector(blob, 0, options="device_contours=1;device_polygons=0")  # contours back to the host: Douglas-Peucker on the pool
+    dev4 = capi.Detector(blob, 0, options="device_contours=1;device_unclip=0")    # (no device unclip -> no device chain either)
     rng = np.random.default_rng(5)
     noise = (rng.random((2, 1, 640, 640)) * 0.9).astype(np.float32)         # ~ 40 k contours per image: overflow -> host fallback
     smooth = rng.random((2, 1, 320, 320)).astype(np.float32)
@@ -125,11 +128,11 @@ def test_postprocess_is_the_same_with_either_tracer():
                        ("mixed", mixed), ("800", W.text_like_maps(1, 800, 9))):
         adj = np.ones((maps.shape[0], 2)) * np.array([1.25, 0.8])
         want = _post(host, maps, adj)
-        for d in (dev, dev2):
+        for d in (dev, dev2, dev3, dev4):
             got = _post(d, maps, adj)
             assert got[0] == want[0], name
             assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got[1], want[1])), name
-    for d in (host, dev, dev2):
+    for d in (host, dev, dev2, dev3, dev4):
         d.close()
     with pytest.raises(capi.OcrError):
         capi.Detector(blob, 0, options="device_contours=3")
@@ -147,8 +150,8 @@ def test_pipelined_calls_with_pretraced_contours_return_the_same_polygons():
     sizes = [3, 5, 2, 8, 8, 1]
     pages = [W.synth_text_pages(300 + i, n, 640, 640, dense=bool(i & 1))[0] for i, n in enumerate(sizes)]
     results = {}
-    for dc in (0, 1, 2):
-        det = capi.Detector(blob, 0, options=f"device_contours={dc};post_threads=2")
+    for dc in (0, 1, 2, 3):
+        det = capi.Detector(blob, 0, options=f"device_contours={dc};post_threads=2" if dc < 3 else "device_contours=1;device_polygons=0;post_threads=2")
         got = []
         # device frames
         dev = [torch.from_numpy(p).cuda() for p in pages]
@@ -176,8 +179,8 @@ def test_pipelined_calls_with_pretraced_contours_return_the_same_polygons():
         got.append(det.detect_pipelined_host(None))
         det.close()
         results[dc] = got
-    assert len(results[0]) == len(results[1]) == len(results[2]) and len(results[0]) >= 10
-    for dc in (1, 2):
+    assert len(results[0]) == len(results[1]) == len(results[2]) == len(results[3]) and len(results[0]) >= 10
+    for dc in (1, 2, 3):
         for k, (a, b) in enumerate(zip(results[0], results[dc])):
             assert a[0] == b[0], (dc, k)
             assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a[1], b[1])), (dc, k)
