@@ -7,7 +7,11 @@
 // (geo's euclidean_length calls libm's hypot, which is NOT sqrt(dx^2 + dy^2) to the last bit: 0.6 % of integer pairs differ).
 // What is not reproducible bit for bit on the device - libm's atan2 / tan / sin / cos - is never decided here: a lane that
 //   * meets a squared-off corner (tan(atan2(..) / 4)),
-//   * gets a ring that is not SIMPLE (the union then has real work: postproc_geom.cpp's exact-rational arrangement),
+//   * gets a ring whose self-intersections are anything but the expected ones - at a concave vertex the offset emits (p + n_k d, p,
+//     p + n_j d): the two neighbouring offset edges cross once, at X, and the loop X .. p .. X has winding 2; the union's outer
+//     boundary takes X (rounded) for the three points.  Exactly these crossings, strictly inside both edges, in order along an edge
+//     that has one at either end, are resolved here with exact integers; any other contact between two edges of the ring is the
+//     business of postproc_geom.cpp's exact-rational arrangement,
 //   * or whose min-area rectangle has a short side within 3 px of min_size (the reference rounds the rectangle's corners outwards
 //     after a rotation by an angle from atan2 / fmod / sin / cos: the integerised side can move by < 2 sqrt 2)
 // returns UNCLIP_HOST and the host finishes exactly that polygon with postproc_geom.cpp.  Everything else is final here.
@@ -55,10 +59,14 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
   status[j] = UNCLIP_HOST;  // until proven final
   const int np = job.n_pts;
   if (np > kUnclipMaxPts) return;
-  // three point arrays of 3 np (+ 1) entries each, private to the job: source / sorted points, raw ring, hull
+  // five arrays of 3 np (+ 1) entries each, private to the job: source points / crossing points / sorted points, raw ring, vertex
+  // kinds / hull, and per ring edge the parameters of the crossings at its two ends
   I2* src = work + 3 * (size_t)job.pt_offset + j;
   I2* raw = src + work_stride;
   I2* hull = raw + work_stride;
+  I2* kind = hull;
+  double* lo = reinterpret_cast<double*>(hull + work_stride);
+  double* hi = lo + work_stride;
   const int32_t* p = pts_xy + 2 * (size_t)job.pt_offset;
 
   // ---- raw_offset_ring: closing duplicate and repeated points out, orientation fixed
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       src[i] = src[n - 1 - i];
       src[n - 1 - i] = t;
     }
-  int m = 0;
+  int m = 0, n_concave = 0;
+  for (int i = 0; i < 3 * n; ++i) kind[i] = {0, 0};
   {
     auto normal = [&](int i, double& nx, double& ny) {
       const I2 a = src[i], b = src[i + 1 == n ? 0 : i + 1];
@@ -115,6 +124,8 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       else if (sin_a < -1.0) sin_a = -1.0;
       if (!done) {
         if (sin_a * delta < 0) {
+          kind[m].x = 1;   // first of a concave vertex's three points
+          ++n_concave;
           raw[m++] = {(int)cround(sx + nkx * delta), (int)cround(sy + nky * delta)};
           raw[m++] = src[jv];
           raw[m++] = {(int)cround(sx + njx * delta), (int)cround(sy + njy * delta)};
@@ -132,15 +143,20 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       nky = njy;
     }
   }
-  // ---- positive_union_outer: repeated points out, then the SIMPLE-ring case (exact integers); anything else is the host's
+  // ---- positive_union_outer: repeated points out; the ring must be simple but for the expected crossing at every concave vertex
   {
     int k = 0;
     for (int i = 0; i < m; ++i)
       if (k == 0 || raw[k - 1].x != raw[i].x || raw[k - 1].y != raw[i].y) raw[k++] = raw[i];
     while (k > 1 && raw[0].x == raw[k - 1].x && raw[0].y == raw[k - 1].y) --k;
+    if (k != m && n_concave) return;   // (a zero-length piece next to a concave vertex: the host's)
     m = k;
   }
   if (m < 3) return;
+  for (int i = 0; i < m; ++i) {
+    lo[i] = -1.0;
+    hi[i] = 2.0;
+  }
   for (int i = 0; i < m; ++i) {
     const I2 a = raw[i], b = raw[i + 1 == m ? 0 : i + 1];
     const long long d1x = b.x - a.x, d1y = b.y - a.y;
@@ -150,14 +166,12 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       long long den = d1x * d2y - d1y * d2x;
       const bool adjacent = q == i + 1 || (i == 0 && q == m - 1);
       if (adjacent) {
-        if (den == 0 || m == 3) {
-          if (den == 0) return;
-        }
+        if (den == 0) return;   // collinear neighbours (a spike or a straight vertex)
         continue;
       }
       const long long wx = c.x - a.x, wy = c.y - a.y;
       if (den == 0) {
-        if (wx * d1y - wy * d1x == 0) return;
+        if (wx * d1y - wy * d1x == 0) return;   // on one line: they may overlap or touch
         continue;
       }
       long long tn = wx * d2y - wy * d2x, un = wx * d1y - wy * d1x;
@@ -166,11 +180,58 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
         tn = -tn;
         un = -un;
       }
-      if (tn >= 0 && tn <= den && un >= 0 && un <= den) return;
+      if (tn < 0 || tn > den || un < 0 || un > den) continue;
+      // the two edges meet.  Expected only as (edge into a concave vertex's first point, edge out of its third point).
+      const int t_fwd = i + 1, t_rev = q + 1 == m ? 0 : q + 1;   // the concave triple would start here
+      const bool fwd = t_fwd < m && kind[t_fwd].x == 1 && q == i + 3;
+      const bool rev = !fwd && kind[t_rev].x == 1 && t_rev + 2 == i;   // (only the triple at the ring's start: edge m - 1 into it, edge 2 out of it)
+      if (!(fwd || rev) || tn == 0 || tn == den || un == 0 || un == den) return;
+      const int t = fwd ? t_fwd : t_rev;
+      if (kind[t].y == 1) return;   // (twice: cannot be)
+      kind[t].y = 1;
+      // X = a + tn / den (b - a), rounded half away from zero like cround((double)((long double)xn / den)): exact for these magnitudes
+      const long long xn = (long long)a.x * den + tn * d1x, yn = (long long)a.y * den + tn * d1y;
+      auto rnd = [](long long num, long long dd) { return num >= 0 ? (2 * num + dd) / (2 * dd) : -((-2 * num + dd) / (2 * dd)); };
+      src[t] = {(int)rnd(xn, den), (int)rnd(yn, den)};
+      if (fwd) {   // edge i ends at the crossing, edge q starts from it
+        hi[i] = (double)tn / (double)den;
+        lo[q] = (double)un / (double)den;
+      } else {
+        hi[q] = (double)un / (double)den;
+        lo[i] = (double)tn / (double)den;
+      }
     }
   }
-  if (shoelace2(raw, m) <= 0) return;   // nothing of positive winding: no polygon (host decides what that means)
-  // (FixupOutPolygon finds nothing to drop in a simple ring: a repeated or collinear vertex fails the adjacency test above)
+  {
+    int k = 0;
+    for (int i = 0; i < m; ++i) {
+      if (!(lo[i] + 1e-9 < hi[i])) return;   // the crossings at an edge's two ends out of order (or too close to call)
+      if (kind[i].x == 1) {
+        if (kind[i].y != 1) return;          // a concave vertex whose neighbours do not cross: not the simple picture
+        raw[k++] = src[i];
+        i += 2;
+      } else {
+        raw[k++] = raw[i];
+      }
+    }
+    m = k;
+  }
+  // FixupOutPolygon: repeated and collinear vertices out (rounded crossings can make them), one at a time from the front, as on the host
+  for (bool changed = true; changed && m >= 3;) {
+    changed = false;
+    for (int i = 0; i < m; ++i) {
+      const I2 pv = raw[i == 0 ? m - 1 : i - 1], c = raw[i], nx = raw[i + 1 == m ? 0 : i + 1];
+      if ((c.x == nx.x && c.y == nx.y) || (c.x == pv.x && c.y == pv.y) ||
+          (long long)(c.y - pv.y) * (nx.x - c.x) == (long long)(c.x - pv.x) * (nx.y - c.y)) {
+        for (int k = i; k + 1 < m; ++k) raw[k] = raw[k + 1];
+        --m;
+        changed = true;
+        break;
+      }
+    }
+  }
+  if (m < 3) return;
+  if (shoelace2(raw, m) <= 0) return;   // nothing of positive winding, or a ring the rounding turned over: the host decides what that means
 
   // ---- min-area rectangle, conservatively: convex hull (monotone chain on the lexicographically sorted points), then per hull edge
   // the extents along and across it.  The reference's short side is that of the integerised rectangle: < 2 sqrt 2 away.
@@ -236,7 +297,7 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
 
 }  // namespace
 
-size_t unclip_work_bytes(size_t total_pts, int n_jobs) { return 3 * (3 * total_pts + (size_t)n_jobs + 1) * sizeof(I2); }
+size_t unclip_work_bytes(size_t total_pts, int n_jobs) { return 5 * (3 * total_pts + (size_t)n_jobs + 1) * sizeof(I2); }
 
 void launch_unclip(const BoxScoreJob* jobs_dev, const int32_t* pts_xy_dev, const int* n_jobs_dev, int n_jobs, size_t total_pts, const double* sums_dev,
                    const double* counts_dev, const double* adj_dev, const UnclipParams& prm, void* work_dev, uint32_t* out_xy_dev,
