@@ -82,12 +82,19 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   post_threads=<n>     (0)    host threads of the post-processing stages (contours, unclip), the calling thread included;
  *                               0 = min(16, CPU share of the process: cgroup quota or online cores).  One process per GPU on a
  *                               shared host should pass its share (cores / ranks)
- *   device_contours=0|1|2 (0)   the contour tracing of ocr_det_postprocess / the pipelined calls on the GPU (contours.hip; maps up to
+ *   device_unclip=0|1    (1)    behind the box scores, per candidate polygon on the GPU (unclip.hip): score threshold, miter offset, the union where
+ *                               the ring is simple or only crosses itself at its concave vertices, min-size test, round(p / adj).  What it does
+ *                               not settle (other self-intersections, squared-off corners, a short side within 3 px of min_size) the host
+ *                               finishes inside the same call; results are bit for bit the host path's (0)
+ *   device_contours=auto|0|1|2 (auto)  the contour tracing of ocr_det_postprocess / the pipelined calls on the GPU (contours.hip; maps up to
  *                               640 x 640 - larger ones, and images the kernel gives up on, take the host tracer inside the same call).
  *                               1: plausible border starts walked in parallel, the raster scan only replays the label tests (0.95-1.5 ms
  *                               per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
- *                               contours either way.  Saves the tracer's share of the host time (15 % on dense pages): worth it
- *                               where one host thread serves a GPU, not otherwise
+ *                               contours either way.  auto: 1 where the host pool has one or two threads (post_threads), else 0 -
+ *                               by measurement
+ *   device_polygons=0|1  (1)    with device contours on square maps: Douglas-Peucker, the >= 4 points filter and the box-score job list on
+ *                               the GPU as well (candidates.hip): with device_unclip the whole chain from the probability map to the adjusted
+ *                               polygons stays on the device and the host only collects.  0: contours back to the host pool
  *   mfma=split_bf16|f32  (split_bf16)  how the f32 precision multiplies in the MFMA-bound convs that have no Winograd kernel
  *                               of their own (stride-2 3x3, in5, FPN phase convs, bin_conv1 over the pyramid, the Winograd GEMMs of
  *                               layer3 / layer4, out4 and out5).  split_bf16: every f32 operand as the exact sum of three bf16 terms, six partial

@@ -256,8 +256,11 @@ void Detector::parse_options(const char* options) {
       if (post_threads_ < 0 || post_threads_ > 256) fail(OCR_ERR_INVALID, "detector option post_threads: %d (0 = automatic, at most 256)", post_threads_);
     }
     else if (key == "device_contours") {
-      device_contours_ = num();
-      if (device_contours_ < 0 || device_contours_ > 2) fail(OCR_ERR_INVALID, "detector option device_contours: %d (0, 1 or 2)", device_contours_);
+      if (val == "auto") device_contours_ = -1;
+      else {
+        device_contours_ = num();
+        if (device_contours_ < 0 || device_contours_ > 2) fail(OCR_ERR_INVALID, "detector option device_contours: %d (auto, 0, 1 or 2)", device_contours_);
+      }
     }
     else if (key == "device_unclip") device_unclip_ = num() != 0;
     else if (key == "device_polygons") device_polygons_ = num() != 0;
@@ -610,6 +613,11 @@ static int host_cpu_share() {
 }
 
 int Detector::post_threads() const { return post_threads_ > 0 ? post_threads_ : std::min(16, host_cpu_share()); }
+
+// auto (the default): the whole polygon chain on the device where the host pool is one or two threads - measured (DESIGN.md section 4:
+// tools/device_contours_sweep.py): with one thread + 37 ... + 130 % pages per second, with two + 0 ... + 40 %; from four threads on the
+// host tracer beside the device unclip is 5 % ahead on f32 pages (the tracer's 32 whole-CU workgroups run beside the next forward)
+int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 ? 1 : 0); }
 
 ThreadPool& Detector::pool() {
   if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread
