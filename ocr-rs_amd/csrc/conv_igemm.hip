@@ -1103,7 +1103,7 @@ static void check(const ConvDesc& d) {
   if (d.src_mode == SRC_PYR4) {
     // rows = cells of the p5 grid (Hin x Win), output [N][8 Hin][8 Win][64], four 64-channel sources in ONE allocation
     if (!phase2 || d.up != 8 || d.ks != 3 || d.stride != 1 || d.pad != 0 || d.Cin != 64 || d.Cout != 64 || d.Ho != d.Hin ||
-        d.Wo != d.Win || d.out2 || d.residual || !d.out || (d.out_bf16 && !d.in_bf16) || d.batch > 1)
+        d.Wo != d.Win || d.out2 || !d.out || (d.out_bf16 && !d.in_bf16) || d.batch > 1)
       fail(OCR_ERR_INVALID, "%s: PYR4 needs the 64->64 bin_conv1 form on the p5 grid with an up-8 PHASE store", d.name);
     // (rows beyond M are dropped through the out-of-range marker 2^31 as their byte offset: the output must end below it)
     if ((long long)d.N * d.Ho * d.Wo * 64 * d.Cout >= (1ll << 29)) fail(OCR_ERR_INVALID, "%s: PYR4 output too large (2^31 bytes)", d.name);

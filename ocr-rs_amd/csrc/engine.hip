@@ -251,6 +251,10 @@ void Detector::parse_options(const char* options) {
       w43_cus_ = num();
       if (w43_cus_ < 0 || w43_cus_ > 4096) fail(OCR_ERR_INVALID, "detector option w43_cus: %d", w43_cus_);
     }
+    else if (key == "w43_side_cus") {
+      w43_side_cus_ = num();
+      if (w43_side_cus_ < 0 || w43_side_cus_ > 4096) fail(OCR_ERR_INVALID, "detector option w43_side_cus: %d", w43_side_cus_);
+    }
     else if (key == "post_threads") {
       post_threads_ = num();
       if (post_threads_ < 0 || post_threads_ > 256) fail(OCR_ERR_INVALID, "detector option post_threads: %d (0 = automatic, at most 256)", post_threads_);
@@ -800,8 +804,10 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   const bool bf = bf16_;
   const size_t es = bf ? 2 : 4;
   hipStream_t cs = stream_;  // stream of the launches below (the side stream while the FPN branch is enqueued)
-  const bool overlap = overlap_ >= 2 && !prof && fpn_composed_ && !bf16_;
-  const bool overlap_small = overlap_ >= 1 && !prof;
+  const bool overlap3 = overlap_ >= 3 && !prof && fpn_composed_ && !bf16_ && bin_pyr_on_ && fused_tail_ && fpn_a_[0].wino43_fused && fpn_a_[1].wino43_fused &&
+                        bin_p2_.wino43_fused && !fpn_a_[0].wino43_x3 && split_bf16_;
+  const bool overlap = overlap3 || (overlap_ == 2 && !prof && fpn_composed_ && !bf16_);   // the FPN branch on the side stream, joined before bin_conv1
+  const bool overlap_small = (overlap_ == 1 || overlap_ == 2) && !prof;   // (3: the side stream is the FPN branch's alone)
   // run `side_work` on the second stream from this point of the main stream on; join() makes the main stream
   // wait for it
   auto fork = [&](auto&& side_work) {
@@ -904,7 +910,8 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       {
         rec.begin();
         launch_winograd43_fused(static_cast<const float*>(src), cw.wino43_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
-                                relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout, w43_cus_ > 0 ? w43_cus_ : num_cus_, cs);
+                                relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout,
+                                cs != stream_ && w43_side_cus_ > 0 ? w43_side_cus_ : w43_cus_ > 0 ? w43_cus_ : num_cus_, cs);
         const double px43 = (double)n * hh * ww;
         rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : cw.cin == 128 ? "winograd43_fused<c128>" : "winograd43_fused<c256>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
                 px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 4);
@@ -1017,7 +1024,39 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
     conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
     cur = x_[l];
-    if (overlap && (l == 1 || l == 2)) {
+    if (overlap3 && l == 1) {
+      // x_[0] and x_[1] are ready: the lateral terms of p2 / p3 (fused Winograd: f32 matrix instructions, latency-bound at two waves per
+      // SIMD), p2's upsampled term on top and bin_conv1's p2 term (into layer1's free temporary) go to the side stream and run beside
+      // layer3 / layer4 / the small FPN convs (split-bf16 GEMMs, transforms): the two families leave each other issue slots and idle
+      // CUs.  Sums are re-associated (lateral + upsampled instead of upsampled + lateral: the same bits;
+      // pyramid + bias + p2 term instead of p2 term + bias + pyramid: one rounding apart)
+      OCR_HIP(hipEventRecord(ev_x2_, stream_));
+      OCR_HIP(hipStreamWaitEvent(side_stream_, ev_x2_, 0));
+      cs = side_stream_;
+      conv3x3("fpn.lateral", fpn_a_[0], x_[0], h4, w4, p_[0], nullptr, false);
+      conv3x3("fpn.lateral", fpn_a_[1], x_[1], h >> 3, w >> 3, p_[1], nullptr, false);
+      {
+        Extra up;
+        up.store = STORE_PHASE;
+        up.residual = p_[0];
+        conv("fpn.upsampled", fpn_b_[0], x_[1], h >> 3, w >> 3, 1, p_[0], false, up);
+      }
+      {
+        ConvW p2 = bin_p2_;
+        p2.bias = nullptr;
+        conv3x3("bin_conv1.p2", p2, p_[0], h4, w4, t_[0], nullptr, false);
+      }
+      cs = stream_;
+    } else if (overlap3 && l == 2) {
+      OCR_HIP(hipEventRecord(ev_x3_, stream_));
+      OCR_HIP(hipStreamWaitEvent(side_stream_, ev_x3_, 0));
+      cs = side_stream_;
+      Extra up;
+      up.store = STORE_PHASE;
+      up.residual = p_[1];
+      conv("fpn.upsampled", fpn_b_[1], x_[2], h >> 4, w >> 4, 1, p_[1], false, up);
+      cs = stream_;
+    } else if (overlap && (l == 1 || l == 2)) {
       // x_{l+1}... is ready: p2 (after layer2) / p3 (after layer3) and their bin_conv1 terms only need the trunk
       // features computed so far, so they go to the side stream and run next to the deeper layers
       hipEvent_t ev = l == 1 ? ev_x2_ : ev_x3_;
@@ -1091,6 +1130,11 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       conv3x3("bin_conv1.p2", p2, p_[0], h4, w4, b1_, b1_, true);
     } else if (bf) {
       // all four sources in the one phase launch (112.8 GF instead of the gathered conv's 241.6), bias + ReLU in its epilogue
+      conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+    } else if (overlap3) {
+      // p2's term was computed on the side stream (into t_[0]): the phase launch over p5, p4, p3 adds it, the bias and the ReLU
+      py.pyr_nsrc = 3;
+      py.residual = t_[0];
       conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
     } else if (bin_p2_.wino43_fused) {
       // the three upsampled sources in the phase launch, p2's 3x3 term on top as a fused Winograd conv (+ bias, ReLU)

@@ -149,7 +149,9 @@ class Detector {
   // overlap=1: the small independent launches side by side (the 1x1 s2 downsample next to its block's
   // 3x3 s2 conv1, out5 next to in4 / out4); =2: also the FPN branch (p2, p3) next to layer3 / layer4.
   // forward_profile always runs one stream (clean per-launch timing).
-  int overlap_ = 0;
+  int overlap_ = 3;        // 3 (default): the FPN's fused-Winograd launches and bin_conv1's p2 term beside layer3 / layer4 (f32 precision, default
+                           // engine; anything else falls back to the one-stream schedule)
+  int w43_side_cus_ = 0;   // ... of the fused Winograd launches that go to the side stream (overlap >= 2): room for the main stream's workgroups beside them
   int w43_cus_ = 0;        // option w43_cus (tuning): size the fused Winograd kernels' persistent grids for this many CUs (0 = the device's)
   hipStream_t side_stream_ = nullptr;
   hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;

@@ -389,6 +389,7 @@ def test_stem_exact_and_inexact_tiles(det, det_w):
     "fpn_unfused=1",                                               # layer-by-layer FPN
     "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
     "overlap=1", "overlap=2",                                      # second-stream schedules
+    "overlap=0", "overlap=3;w43_side_cus=128",                     # one stream (the default is 3: FPN Winograd launches + bin_conv1 p2 term beside layer3 / layer4)
     "mfma=f32",                                                    # every conv on the exact-f32 MFMA (no split-bf16 kernels)
     "mfma=f32;bin_pyr=0",
     "winograd43_x3=1",                                             # the fused F(4x4) convs on the bf16 matrix cores too (winograd43_x3.hip)
