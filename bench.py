@@ -210,8 +210,7 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
 
     done, el = det_rate(cores, 2, 64, budget_s)
     out = {"value": round(done / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
-           "sample": f"{done} frames of {size}x{size} f32 in batches of 2 through oracle/torch_ref.py "
-                     f"(ATen CPU, {cores} threads), {el:.1f} s"}
+           "sample": f"{done} frames {size}x{size}, oracle/torch_ref.py (ATen CPU), {cores} threads, {el:.1f} s"}
     d1, e1 = det_rate(1, 1, 2, 4.0)
     out["one_thread"] = {"value": round(d1 / e1, 3), "unit": "images/s", "cores": 1, "sample": f"{d1} frames, {e1:.1f} s"}
     torch.set_num_threads(cores)
@@ -223,7 +222,7 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
         it += 1
     el = time.perf_counter() - t0
     out["recognition"] = {"value": round(it * 4096 / el, 1), "unit": "crops/s", "cores": cores, "kind": "port",
-                          "sample": f"{it} x 4096 crops of 28x28 through oracle/torch_ref.py (forward + softmax f64 + top-1), {el:.1f} s"}
+                          "sample": f"{it} x 4096 crops 28x28, oracle/torch_ref.py, {el:.1f} s"}
     # post-processing: the compiled CPU path (oracle/postproc_cpu.cpp: binarize, contours, Douglas-Peucker, box scores,
     # unclip - all on host threads; pinned to the reference's known answers by tests/test_oracle_postproc.py), one thread
     # and all cores, on the text-like maps the GPU leg uses
@@ -241,11 +240,7 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
 
     it, el = post_rate(cores, 2.0)
     out["postprocess"] = {"value": round(it * 32 / el, 1), "unit": "images/s", "cores": cores, "kind": "port",
-                          "sample": f"{it} x 32 text-like {size}x{size} maps through oracle/postproc_cpu.cpp (compiled C++: binarize + "
-                                    f"contours + box scores + unclip on {cores} host threads), {el:.1f} s; NOT an independent implementation: its contour / "
-                                    f"polygon / unclip geometry is the product's own host source (ocr-rs_amd/csrc/postproc_geom.cpp compiled into "
-                                    f"oracle/libpostproc_cpu.so), only binarize and the box score are restated - it is the library's host path timed "
-                                    f"without a GPU, pinned to the reference's known answers (tests/test_oracle_postproc.py)"}
+                          "sample": f"{it} x 32 text-like maps, oracle/postproc_cpu.cpp (product's host geometry, DESIGN 6), {el:.1f} s"}
     it1, el1 = post_rate(1, 1.5)
     out["postprocess"]["one_thread"] = {"value": round(it1 * 32 / el1, 1), "unit": "images/s", "cores": 1, "sample": f"{it1} x 32 maps, {el1:.1f} s"}
     return out
@@ -949,6 +944,27 @@ def main():
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         if dist is not None and try_c_abi and gathered is not None:
             line.update(c_abi_exchange(capi, dist, torch, polys, scores, gathered, world, rank, local, line))
+        # the last ~1 500 characters of the line are what a stored record keeps: the numbers a reader needs, once more, at the very end
+        cb = line.get("cpu_baseline") or {}
+        b16 = line.get("bf16") or {}
+        sw = (line.get("post_threads_sweep") or {}).get("2") or {}
+        line["summary"] = {
+            "ms_per_step": line["ms_per_step"], "images_per_s": line["value"], "n_gpus": world, "dtype": a.dtype,
+            "roofline": {"kernel": roof.get("kernel"), "frac": roof.get("frac"), "achieved_tflops": roof.get("achieved"), "peak_tflops": roof.get("peak"),
+                         "avg_launch_ms": roof.get("avg_launch_ms"), "traffic_bytes": roof.get("traffic"), "mfma_busy": roof.get("mfma_busy")},
+            "f32_mfma_only_ms": (line.get("f32_mfma_only") or {}).get("ms_per_step"),
+            "bf16": {k2: b16.get(k2) for k2 in ("ms_per_step", "images_per_s", "e2e_pages_per_s")} if b16 else None,
+            "e2e_pages_per_s": line.get("e2e_pages_per_s"),
+            "detect_postprocess_pipelined_images_per_s": line.get("detect_postprocess_pipelined_images_per_s"),
+            "postprocess_images_per_s": {"text": line.get("postprocess_images_per_s"), "dense": line.get("postprocess_dense_images_per_s")},
+            "post_threads_2": {k2: v2.get("detect_postprocess_pipelined_images_per_s") for k2, v2 in sw.items()} if sw else None,
+            "rec_crops_per_s": {"b256": line.get("rec_crops_per_s_b256"), "b65536": line.get("rec_crops_per_s_b65536")},
+            "cpu_baseline": {"images_per_s": cb.get("value"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                             "one_thread": (cb.get("one_thread") or {}).get("value"),
+                             "rec_crops_per_s": (cb.get("recognition") or {}).get("value"),
+                             "postprocess_images_per_s": (cb.get("postprocess") or {}).get("value")},
+            "exchange_ok": line.get("exchange_ok"),
+        }
         emit(line)
         if line.get("exchange_ok") is False and backend == "nccl":
             exit_code = 4   # the line is out, with the error in it; a failed exchange over RCCL must not read as a clean run
