@@ -42,6 +42,12 @@ __device__ long long shoelace2(const I2* r, int n) {
   return s;
 }
 
+// why a lane hands its polygon back: out_len[j] = -(reason), for tools/unclip_stats.py (the host only looks at the status)
+#define PUNT(r)        \
+  do {                 \
+    out_len[j] = -(r); \
+    return;            \
+  } while (0)
 __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restrict__ jobs, const int32_t* __restrict__ pts_xy, const int* __restrict__ n_jobs_dev,
                                                     int n_jobs, const double* __restrict__ sums, const double* __restrict__ counts,
                                                     const double* __restrict__ adj, UnclipParams prm, I2* __restrict__ work, size_t work_stride,
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
   }
   status[j] = UNCLIP_HOST;  // until proven final
   const int np = job.n_pts;
-  if (np > kUnclipMaxPts) return;
+  if (np > kUnclipMaxPts) PUNT(1);
   // five arrays of 3 np (+ 1) entries each, private to the job: source points / crossing points / sorted points, raw ring, vertex
   // kinds / hull, and per ring edge the parameters of the crossings at its two ends
   I2* src = work + 3 * (size_t)job.pt_offset + j;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
   }
   // (offset_distance works on the polygon as given: repeated points add nothing to the area and exact zeros to the perimeter)
   while (n > 1 && src[0].x == src[n - 1].x && src[0].y == src[n - 1].y) --n;
-  if (n < 3) return;  // no ring -> no polygon: the reference unwraps None (host: OCR_ERR_DEGENERATE or skip)
+  if (n < 3) PUNT(2);  // no ring -> no polygon: the reference unwraps None (host: OCR_ERR_DEGENERATE or skip)
   double per = 0.0;
   long long a2 = 0;
   for (int i = 0; i < np; ++i) {
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
             const double q = delta / r;
             raw[m++] = {(int)cround(sx + (nkx + njx) * q), (int)cround(sy + (nky + njy) * q)};
           } else {
-            return;   // squared-off corner: tan(atan2(..) / 4) is libm's -> host
+            PUNT(3);   // squared-off corner: tan(atan2(..) / 4) is libm's -> host
           }
         }
       }
@@ -149,10 +155,10 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
     for (int i = 0; i < m; ++i)
       if (k == 0 || raw[k - 1].x != raw[i].x || raw[k - 1].y != raw[i].y) raw[k++] = raw[i];
     while (k > 1 && raw[0].x == raw[k - 1].x && raw[0].y == raw[k - 1].y) --k;
-    if (k != m && n_concave) return;   // (a zero-length piece next to a concave vertex: the host's)
+    if (k != m && n_concave) PUNT(4);   // (a zero-length piece next to a concave vertex: the host's)
     m = k;
   }
-  if (m < 3) return;
+  if (m < 3) PUNT(5);
   for (int i = 0; i < m; ++i) {
     lo[i] = -1.0;
     hi[i] = 2.0;
@@ -166,12 +172,18 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       long long den = d1x * d2y - d1y * d2x;
       const bool adjacent = q == i + 1 || (i == 0 && q == m - 1);
       if (adjacent) {
-        if (den == 0) return;   // collinear neighbours (a spike or a straight vertex)
+        if (den == 0) PUNT(6);   // collinear neighbours (a spike or a straight vertex)
         continue;
       }
       const long long wx = c.x - a.x, wy = c.y - a.y;
       if (den == 0) {
-        if (wx * d1y - wy * d1x == 0) return;   // on one line: they may overlap or touch
+        if (wx * d1y - wy * d1x == 0) {
+          // on one line (two stretches of a word's long side with a dent between them): harmless when strictly apart - the
+          // arrangement ignores parallel pairs as well -, the host's when they overlap or touch
+          const long long l2 = d1x * d1x + d1y * d1y;
+          const long long tc = wx * d1x + wy * d1y, td = (long long)(d.x - a.x) * d1x + (long long)(d.y - a.y) * d1y;
+          if (!((tc < 0 && td < 0) || (tc > l2 && td > l2))) PUNT(7);
+        }
         continue;
       }
       long long tn = wx * d2y - wy * d2x, un = wx * d1y - wy * d1x;
@@ -185,9 +197,9 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       const int t_fwd = i + 1, t_rev = q + 1 == m ? 0 : q + 1;   // the concave triple would start here
       const bool fwd = t_fwd < m && kind[t_fwd].x == 1 && q == i + 3;
       const bool rev = !fwd && kind[t_rev].x == 1 && t_rev + 2 == i;   // (only the triple at the ring's start: edge m - 1 into it, edge 2 out of it)
-      if (!(fwd || rev) || tn == 0 || tn == den || un == 0 || un == den) return;
+      if (!(fwd || rev) || tn == 0 || tn == den || un == 0 || un == den) PUNT(8);
       const int t = fwd ? t_fwd : t_rev;
-      if (kind[t].y == 1) return;   // (twice: cannot be)
+      if (kind[t].y == 1) PUNT(9);   // (twice: cannot be)
       kind[t].y = 1;
       // X = a + tn / den (b - a), rounded half away from zero like cround((double)((long double)xn / den)): exact for these magnitudes
       const long long xn = (long long)a.x * den + tn * d1x, yn = (long long)a.y * den + tn * d1y;
@@ -205,9 +217,9 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
   {
     int k = 0;
     for (int i = 0; i < m; ++i) {
-      if (!(lo[i] + 1e-9 < hi[i])) return;   // the crossings at an edge's two ends out of order (or too close to call)
+      if (!(lo[i] + 1e-9 < hi[i])) PUNT(10);   // the crossings at an edge's two ends out of order (or too close to call)
       if (kind[i].x == 1) {
-        if (kind[i].y != 1) return;          // a concave vertex whose neighbours do not cross: not the simple picture
+        if (kind[i].y != 1) PUNT(11);          // a concave vertex whose neighbours do not cross: not the simple picture
         raw[k++] = src[i];
         i += 2;
       } else {
@@ -230,8 +242,8 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       }
     }
   }
-  if (m < 3) return;
-  if (shoelace2(raw, m) <= 0) return;   // nothing of positive winding, or a ring the rounding turned over: the host decides what that means
+  if (m < 3) PUNT(12);
+  if (shoelace2(raw, m) <= 0) PUNT(13);   // nothing of positive winding, or a ring the rounding turned over: the host decides what that means
 
   // ---- min-area rectangle, conservatively: convex hull (monotone chain on the lexicographically sorted points), then per hull edge
   // the extents along and across it.  The reference's short side is that of the integerised rectangle: < 2 sqrt 2 away.
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
     hull[hn++] = src[i];
   }
   --hn;   // the last point repeats the first
-  if (hn < 3) return;
+  if (hn < 3) PUNT(14);
   double best_area = INFINITY;
   for (int pass = 0; pass < 2; ++pass) {
     double short_min = INFINITY;
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(64) void unclip_kernel(const BoxScoreJob* __restric
       if (pass == 0) best_area = fmin(best_area, ar);
       else if (ar <= best_area * (1.0 + 1e-9) + 1e-9) short_min = fmin(short_min, fmin(da, dc) / sqrt(l2));   // every orientation the reference may settle on
     }
-    if (pass == 1 && !(short_min > prm.min_size + 3.0)) return;   // too close to call (or too small): the host decides
+    if (pass == 1 && !(short_min > prm.min_size + 3.0)) PUNT(15);   // too close to call (or too small): the host decides
   }
   // ---- metrics.rs:108-121: BuildResult order (ends at the top-most vertex, ties: right-most), round(p / adj) as u32
   int top = 0;

@@ -78,3 +78,44 @@ def test_32_pages_frames_to_polygons_to_labels_against_the_oracle_chain():
     print(f"e2e {N} pages: {identical_pages} pages with identical polygon lists, {n_poly} oracle polygons, {undecided} near-tie crops")
     assert identical_pages >= N - 2
     assert n_poly > 10 * N
+
+
+def test_maps_that_straddle_the_threshold_differ_only_where_a_pixel_flipped():
+    """The same two chains on SOFT maps: the text-following weights with a flat sigmoid (gain 0.01 instead of 0.06) leave more than 1e-4 of
+    the oracle's pixels within 1e-3 of the 0.6 threshold (/root/reference/src/text_detection/metrics.rs:38,129-131), so float rounding
+    does move pixels across it.  Counted and explained: pages without a flipped pixel have identical polygon lists; on every other page
+    each polygon that one side has and the other has not holds a flipped pixel inside its bounding box."""
+    det_w = W.make_det_weights_text(gain=0.01, tau=84.5)
+    det = capi.Detector(W.pack_blob(det_w), 0)
+    frames, boxes = W.synth_text_pages(2027, N, S, S)
+    prob = det.forward_host(frames)
+    adj = np.ones((N, 2))
+    polys, scores = det.postprocess(prob, N, S, S, adj, capi.MEM_HOST, capi.default_params(skip_degenerate=True))
+    det.close()
+    ref_prob = np.concatenate([T.det_forward(det_w, frames[i:i + 8]) for i in range(0, N, 8)])
+    ref_polys, ref_scores = O.get_boxes_and_box_scores(ref_prob, adj, skip_degenerate=True)
+
+    d = np.abs(prob - ref_prob)
+    near = float((np.abs(ref_prob - np.float32(0.6)) < 1e-3).mean())
+    flips_px = (prob > np.float32(0.6)) != (ref_prob > np.float32(0.6))
+    flips = flips_px.reshape(N, -1).sum(axis=1)
+    assert d.max() < 1e-4
+    assert near >= 1e-4, near                       # the maps do straddle the threshold ...
+    assert sum(len(p) for p in ref_polys) > 10 * N  # ... and still carry the words
+    differing, explained = 0, 0
+    for i in range(N):
+        if flips[i] == 0:
+            assert polys[i] == ref_polys[i], f"page {i}: no pixel flipped, polygon lists differ"
+            assert np.allclose(scores[i], ref_scores[i], rtol=0, atol=1e-6)
+            continue
+        a, b = {tuple(map(tuple, q)) for q in polys[i]}, {tuple(map(tuple, q)) for q in ref_polys[i]}
+        ys, xs = np.nonzero(flips_px[i, 0])
+        for q in a ^ b:
+            differing += 1
+            qa = np.asarray(q)
+            x0, y0, x1, y1 = qa[:, 0].min() - 2, qa[:, 1].min() - 2, qa[:, 0].max() + 2, qa[:, 1].max() + 2
+            inside = ((xs >= x0) & (xs <= x1) & (ys >= y0) & (ys <= y1)).any()
+            assert inside, f"page {i}: polygon {q[:3]}... differs between the chains and no flipped pixel lies in its box"
+            explained += 1
+    print(f"soft maps, {N} pages: {near:.2e} of the oracle's pixels within 1e-3 of the threshold, max|dprob| {d.max():.3e}, {int(flips.sum())} flipped pixels on "
+          f"{int((flips > 0).sum())} pages, {differing} polygons differ, all {explained} with a flipped pixel in their box")

@@ -19,9 +19,15 @@ for kind, dense in (("text", False), ("dense", True)):
     sc = np.full(len(polys), 0.9)
     stats = (C.c_int32 * 4)()
     st = np.zeros(len(polys), np.int32)
+    ln = np.zeros(len(polys), np.int32)
     capi.check(L.ocr_test_unclip_compare(det._h, xy.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), len(polys), sc.ctypes.data_as(C.c_void_p),
-                                         C.c_double(1.0), C.c_double(1.0), C.c_double(0.7), C.c_double(2.0), C.c_double(5.0), stats, st.ctypes.data_as(C.c_void_p), None, None))
+                                         C.c_double(1.0), C.c_double(1.0), C.c_double(0.7), C.c_double(2.0), C.c_double(5.0), stats, st.ctypes.data_as(C.c_void_p),
+                                         ln.ctypes.data_as(C.c_void_p), None))
     print(kind, "candidates", len(polys), "points per candidate", round(float(cnt.mean()), 1), "max", int(cnt.max()), "keep/host/drop/mismatch", list(stats))
+    reasons = {}
+    for k in np.nonzero(st == 2)[0]:
+        reasons[int(-ln[k])] = reasons.get(int(-ln[k]), 0) + 1
+    print("   handed back by reason (unclip.hip PUNT codes):", dict(sorted(reasons.items())))
     # why host?  concave vertices in the candidates
     conc = 0
     for p in polys:
