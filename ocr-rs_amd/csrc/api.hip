@@ -48,6 +48,51 @@ static ContourBuffers enqueue_contours(ocr::Detector& det, int slot, const float
   return cb;
 }
 
+// the polygon chain behind the device tracer (candidates.hip, box_score.hip, unclip.hip): where its pieces live inside one scratch slot
+struct ChainBuffers {
+  char* sc = nullptr;
+  int max_jobs = 0, max_pts = 0;
+  size_t o_jobs = 0, o_pts = 0, o_sum = 0, o_cnt = 0, o_adj = 0, o_st = 0, o_len = 0, o_oxy = 0, o_work = 0, o_tot = 0, o_hd = 0, o_cs = 0, total = 0;
+  explicit ChainBuffers(int n) {
+    max_jobs = n * 1024;   // a dense page: 60 - 130 candidates of 4 - 16 points; a batch that needs more takes the host path
+    max_pts = n * 8192;
+    o_pts = o_jobs + align256((size_t)max_jobs * sizeof(ocr::BoxScoreJob));
+    o_sum = o_pts + align256((size_t)max_pts * 8);
+    o_cnt = o_sum + align256((size_t)max_jobs * 8);
+    o_adj = o_cnt + align256((size_t)max_jobs * 8);
+    o_st = o_adj + align256((size_t)n * 16);
+    o_len = o_st + align256((size_t)max_jobs * 4);
+    o_oxy = o_len + align256((size_t)max_jobs * 4);
+    o_work = o_oxy + align256(3 * (size_t)max_pts * 8);
+    o_tot = o_work + align256(ocr::unclip_work_bytes((size_t)max_pts, max_jobs));
+    o_hd = o_tot + align256((size_t)n * 8);
+    o_cs = o_hd + 256;
+    total = o_cs + ocr::candidates_scratch_bytes(n, ContourBuffers::CAP, ContourBuffers::MAXC);
+  }
+  ocr::BoxScoreJob* jobs() const { return reinterpret_cast<ocr::BoxScoreJob*>(sc + o_jobs); }
+  int32_t* pts() const { return reinterpret_cast<int32_t*>(sc + o_pts); }
+  double* sums() const { return reinterpret_cast<double*>(sc + o_sum); }
+  double* counts() const { return reinterpret_cast<double*>(sc + o_cnt); }
+  int* totals() const { return reinterpret_cast<int*>(sc + o_hd); }
+};
+// Douglas-Peucker + job list, box scores, unclip of a batch whose contours are (or will be, stream order) in `cb`: everything on `s`
+static ChainBuffers enqueue_chain(ocr::Detector& det, int slot, const ContourBuffers& cb, const float* prob_dev, int n, int h, int w, const double* adj,
+                                  const ocr_postproc_params_t& prm, hipStream_t s) {
+  using namespace ocr;
+  ChainBuffers ch(n);
+  ch.sc = static_cast<char*>(det.scratch(slot, ch.total));
+  const UnclipParams up{prm.box_thresh, prm.unclip_ratio, prm.min_size};
+  OCR_HIP(hipMemcpyAsync(ch.sc + ch.o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
+  launch_candidates(reinterpret_cast<const int*>(cb.base + cb.o_hdr), reinterpret_cast<const uint32_t*>(cb.base + cb.o_pts), ContourBuffers::CAP,
+                    reinterpret_cast<const int*>(cb.base + cb.o_st), ContourBuffers::MAXC, n, h, w, ch.sc + ch.o_cs, ch.jobs(), ch.max_jobs, ch.pts(), ch.max_pts,
+                    reinterpret_cast<int*>(ch.sc + ch.o_tot), ch.totals(), s);
+  launch_box_scores_counted(prob_dev, h, w, ch.jobs(), ch.pts(), ch.totals(), std::min(ch.max_jobs, 4096), ch.sums(), ch.counts(), s);
+  launch_unclip(ch.jobs(), ch.pts(), ch.totals(), ch.max_jobs, (size_t)ch.max_pts, ch.sums(), ch.counts(), reinterpret_cast<const double*>(ch.sc + ch.o_adj), up,
+                ch.sc + ch.o_work, reinterpret_cast<uint32_t*>(ch.sc + ch.o_oxy), reinterpret_cast<int32_t*>(ch.sc + ch.o_len),
+                reinterpret_cast<int32_t*>(ch.sc + ch.o_st), s);
+  return ch;
+}
+
 // device_contours in the pipelined calls: the contours of the batch that was just queued are requested right away - behind its
 // forward, on a stream of their own - so that the call which brings its polygons back finds them done instead of waiting
 static void pretrace_pending(ocr::Detector& d) {
@@ -57,7 +102,11 @@ static void pretrace_pending(ocr::Detector& d) {
   if (!contour_trace_fits(p.h, p.w)) return;
   hipStream_t ts = d.trace_stream();   // not the post-processing stream: crops of the batch that just came back must not queue behind this forward
   OCR_HIP(hipStreamWaitEvent(ts, p.event, 0));
-  enqueue_contours(d, 3, p.prob, p.n, p.h, p.w, (float)p.params.thresh, ts);
+  const ContourBuffers cb = enqueue_contours(d, 3, p.prob, p.n, p.h, p.w, (float)p.params.thresh, ts);
+  if (d.device_polygons() && d.device_unclip() && p.h == p.w) {   // ... and the rest of the chain behind them: the call that comes back only collects
+    enqueue_chain(d, 4, cb, p.prob, p.n, p.h, p.w, p.adj.data(), p.params, ts);
+    p.prechained = true;
+  }
   OCR_HIP(hipEventRecord(d.trace_done_event(), ts));
   p.pretraced = true;
 }
@@ -69,7 +118,7 @@ static void pretrace_pending(ocr::Detector& d) {
 // the unclip kernel hands back (UNCLIP_HOST) and takes, from the bit image on, the images the tracer gave up.
 // pretraced: the batch's contours were requested on `s` earlier (enqueue_contours into scratch slot 3): only read them
 void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int mem_kind, const double* adj,
-                 const ocr_postproc_params_t& prm, ocr_polygons_t** out, hipStream_t s, bool pretraced = false) {
+                 const ocr_postproc_params_t& prm, ocr_polygons_t** out, hipStream_t s, bool pretraced = false, bool prechained = false) {
   using namespace ocr;
 #ifdef POSTPROC_TIMING
   auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -82,7 +131,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   const size_t hw = (size_t)h * w, px = (size_t)n * hw;
   const size_t wpi = binarize_pack_words(hw);  // 32-bit words per packed image
   const bool dev_trace = pretraced || (det.device_contours() && contour_trace_fits(h, w));
-  const bool dev_chain = dev_trace && det.device_polygons() && det.device_unclip() && h == w;
+  const bool dev_chain = prechained || (dev_trace && det.device_polygons() && det.device_unclip() && h == w);
   // scratch: [prob copy if host] [packed bitmaps]
   const size_t off_bits = mem_kind == OCR_MEM_HOST ? align256(px * 4) : 0;
   char* scratch = static_cast<char*>(det.scratch(0, off_bits + align256((size_t)n * wpi * 4)));
@@ -131,33 +180,15 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
       cb = enqueue_contours(det, 2, prob_dev, n, h, w, (float)prm.thresh, s);
     }
     bits_dev = cb.bits();
-    const int max_jobs = n * 1024, max_pts = n * 8192;   // a dense page: 60 - 130 candidates of 4 - 12 points; more -> host path
-    const size_t o_jobs = 0;
-    const size_t o_pts = o_jobs + align256((size_t)max_jobs * sizeof(BoxScoreJob));
-    const size_t o_sum = o_pts + align256((size_t)max_pts * 8);
-    const size_t o_cnt = o_sum + align256((size_t)max_jobs * 8);
-    const size_t o_adj = o_cnt + align256((size_t)max_jobs * 8);
-    const size_t o_st = o_adj + align256((size_t)n * 16);
-    const size_t o_len = o_st + align256((size_t)max_jobs * 4);
-    const size_t o_oxy = o_len + align256((size_t)max_jobs * 4);
-    const size_t o_work = o_oxy + align256(3 * (size_t)max_pts * 8);
-    const size_t o_tot = o_work + align256(unclip_work_bytes((size_t)max_pts, max_jobs));
-    const size_t o_hd = o_tot + align256((size_t)n * 8);
-    const size_t o_cs = o_hd + 256;
-    const size_t total = o_cs + candidates_scratch_bytes(n, ContourBuffers::CAP, ContourBuffers::MAXC);
-    char* sc = static_cast<char*>(det.scratch(1, total));
-    auto* d_jobs = reinterpret_cast<BoxScoreJob*>(sc + o_jobs);
-    auto* d_pts = reinterpret_cast<int32_t*>(sc + o_pts);
-    auto* d_sum = reinterpret_cast<double*>(sc + o_sum);
-    auto* d_cnt = reinterpret_cast<double*>(sc + o_cnt);
-    int* d_totals = reinterpret_cast<int*>(sc + o_hd);
-    OCR_HIP(hipMemcpyAsync(sc + o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
-    launch_candidates(reinterpret_cast<const int*>(cb.base + cb.o_hdr), reinterpret_cast<const uint32_t*>(cb.base + cb.o_pts), ContourBuffers::CAP,
-                      reinterpret_cast<const int*>(cb.base + cb.o_st), ContourBuffers::MAXC, n, h, w, sc + o_cs, d_jobs, max_jobs, d_pts, max_pts,
-                      reinterpret_cast<int*>(sc + o_tot), d_totals, s);
-    launch_box_scores_counted(prob_dev, h, w, d_jobs, d_pts, d_totals, std::min(max_jobs, 4096), d_sum, d_cnt, s);
-    launch_unclip(d_jobs, d_pts, d_totals, max_jobs, (size_t)max_pts, d_sum, d_cnt, reinterpret_cast<const double*>(sc + o_adj), up, sc + o_work,
-                  reinterpret_cast<uint32_t*>(sc + o_oxy), reinterpret_cast<int32_t*>(sc + o_len), reinterpret_cast<int32_t*>(sc + o_st), s);
+    ChainBuffers ch(n);
+    if (prechained) ch.sc = static_cast<char*>(det.scratch(4, ch.total));   // queued with the contours (pretrace_pending)
+    else ch = enqueue_chain(det, 1, cb, prob_dev, n, h, w, adj, prm, s);
+    char* sc = ch.sc;
+    const size_t o_tot = ch.o_tot, o_st = ch.o_st, o_len = ch.o_len, o_oxy = ch.o_oxy;
+    BoxScoreJob* d_jobs = ch.jobs();
+    int32_t* d_pts = ch.pts();
+    double *d_sum = ch.sums(), *d_cnt = ch.counts();
+    int* d_totals = ch.totals();
     std::vector<int32_t> tot((size_t)n * 2);
     int32_t totals[4] = {0, 0, 0, 0};
     OCR_HIP(hipMemcpyAsync(tot.data(), sc + o_tot, tot.size() * 4, hipMemcpyDeviceToHost, s));
@@ -682,7 +713,7 @@ int ocr_det_detect_pipelined(ocr_det_t* det, const float* x_dev, int n, int h, i
     if (prev.valid) {
       hipStream_t ps = d.post_stream();
       OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
-      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps, prev.pretraced);
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps, prev.pretraced, prev.prechained);
     }
     pretrace_pending(d);
   });
@@ -702,7 +733,7 @@ int ocr_det_detect_pipelined_host(ocr_det_t* det, const void* x_host, int x_elem
       OCR_HIP(hipStreamWaitEvent(ps, prev.event, 0));   // the forward that produced prev.prob
       if (prev.prob_host)   // the caller asked for the map too: it leaves on the same stream, ahead of the bit image
         OCR_HIP(hipMemcpyAsync(prev.prob_host, prev.prob, (size_t)prev.n * prev.h * prev.w * 4, hipMemcpyDeviceToHost, ps));
-      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps, prev.pretraced);
+      postprocess(d, prev.prob, prev.n, prev.h, prev.w, OCR_MEM_DEVICE, prev.adj.data(), prev.params, prev_out, ps, prev.pretraced, prev.prechained);
     };
     Detector::Pending next;
     if (x_host) {

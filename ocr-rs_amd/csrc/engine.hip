@@ -266,6 +266,7 @@ void Detector::parse_options(const char* options) {
         if (device_contours_ < 0 || device_contours_ > 2) fail(OCR_ERR_INVALID, "detector option device_contours: %d (auto, 0, 1 or 2)", device_contours_);
       }
     }
+    else if (key == "post_priority") post_priority_ = num() != 0;
     else if (key == "device_unclip") device_unclip_ = num() != 0;
     else if (key == "device_polygons") device_polygons_ = num() != 0;
     else if (key == "mfma") {
@@ -618,23 +619,39 @@ static int host_cpu_share() {
 
 int Detector::post_threads() const { return post_threads_ > 0 ? post_threads_ : std::min(16, host_cpu_share()); }
 
-// auto (the default): the whole polygon chain on the device where the host pool is one or two threads - measured (DESIGN.md section 4:
-// tools/device_contours_sweep.py): with one thread + 37 ... + 130 % pages per second, with two + 0 ... + 40 %; from four threads on the
-// host tracer beside the device unclip is 5 % ahead on f32 pages (the tracer's 32 whole-CU workgroups run beside the next forward)
-int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 ? 1 : 0); }
+// auto (the default): the whole polygon chain on the device where the host pool is small - by measurement (DESIGN.md section 4,
+// tools/device_contours_sweep.py): one thread cannot trace and simplify the contours of the f32 detector's dense pages in time (4.7 k
+// pages per second against 5.6 k with the chain), two threads can (5.9 k); the bf16 detector is three times faster: there the chain wins
+// up to two threads (13.9 k / 11.0 k against 11.2 k / 6.8 k).  With more threads the host tracer beside the device unclip is ahead on
+// text pages - the tracer's 32 whole-CU workgroups run beside the next forward and cost it 4 - 8 %
+int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= (bf16_ ? 2 : 1) ? 1 : 0); }
 
 ThreadPool& Detector::pool() {
   if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread
   return *pool_;
 }
 
+// the post-processing and trace streams run short latency-bound kernels (tracer, Douglas-Peucker, box scores, unclip) beside the next
+// forward's long ones: at the highest priority the device offers their workgroups are placed as soon as a CU drains instead of queueing
+// behind the forward's (option post_priority=0: default priority)
+static hipStream_t make_side_stream(bool high_priority) {
+  hipStream_t s = nullptr;
+  int lo = 0, hi = 0;
+  if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+    OCR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    return s;
+  }
+  OCR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+
 hipStream_t Detector::post_stream() {
-  if (!post_stream_) OCR_HIP(hipStreamCreateWithFlags(&post_stream_, hipStreamNonBlocking));
+  if (!post_stream_) post_stream_ = make_side_stream(post_priority_);
   return post_stream_;
 }
 
 hipStream_t Detector::trace_stream() {
-  if (!trace_stream_) OCR_HIP(hipStreamCreateWithFlags(&trace_stream_, hipStreamNonBlocking));
+  if (!trace_stream_) trace_stream_ = make_side_stream(post_priority_);
   return trace_stream_;
 }
 hipEvent_t Detector::trace_done_event() {
@@ -655,7 +672,7 @@ void Detector::synchronize() {
 }
 
 void* Detector::scratch(int slot, size_t bytes) {
-  if (slot < 0 || slot > 3) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
+  if (slot < 0 || slot > 4) fail(OCR_ERR_INTERNAL, "scratch slot %d", slot);
   if (bytes > scratch_bytes_[slot]) {
     // every stream that may read or write a slot drains before a growing slot is freed (slot 2: post_stream_; slot 3: written on
     // trace_stream_, read on post_stream_)

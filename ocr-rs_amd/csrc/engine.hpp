@@ -95,14 +95,14 @@ class Detector {
   int post_threads() const;      // host threads of the post-processing stages (option post_threads, default min(16, CPU share))
   // contours on the device (contours.hip)?  option device_contours=1; off by default: a wave follows a border at about the speed of
   // ONE host core per batch (measured), so it pays only where no host core can be spared
-  int device_contours() const;   // 0 off, 1 parallel form, 2 one wave per image; option auto (default) = 1 when the pool has at most two threads
+  int device_contours() const;   // 0 off, 1 parallel form, 2 one wave per image; option auto (default) = 1 when the pool has one thread (f32) / at most two (bf16)
   // unclip (score threshold, miter offset, simple-ring union, min-size test, adjustment) on the device behind the box score
   // (unclip.hip; option device_unclip=0 keeps all of it on the host pool)
   bool device_unclip() const { return device_unclip_; }
   // with device contours: Douglas-Peucker and the box-score job list on the device too (candidates.hip; option device_polygons=0
   // brings the contours back and leaves them to the host pool)
   bool device_polygons() const { return device_polygons_; }
-  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours, slot 3: the same for the batch a pipelined call left pending.
+  // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours, slot 3: the same for the batch a pipelined call left pending, slot 4: that batch's polygon chain.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
   // host threads of the post-processing stages (created on first use, one image per task)
@@ -119,6 +119,7 @@ class Detector {
     // device_contours: the bit images and contours of this batch were requested on the post-processing stream when the batch was
     // queued (scratch slot 3, layout of api.hip::ContourBuffers): the call that brings the polygons back only reads them
     bool pretraced = false;
+    bool prechained = false;   // ... and so were Douglas-Peucker, box scores and unclip behind them (scratch slot 4, api.hip::ChainBuffers)
   };
   bool has_pending() const { return pending_.valid; }
   Pending& pending() { return pending_; }
@@ -227,8 +228,8 @@ class Detector {
   hipEvent_t trace_done_ = nullptr;
   hipEvent_t pipe_ev_[2] = {nullptr, nullptr};
   int pipe_ev_next_ = 0;
-  void* scratch_[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes_[4] = {0, 0, 0, 0};
+  void* scratch_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes_[5] = {0, 0, 0, 0, 0};
   struct Staging {
     void* in[2] = {nullptr, nullptr};
     float* out[2] = {nullptr, nullptr};
@@ -243,6 +244,7 @@ class Detector {
   int device_contours_ = -1;  // option device_contours (-1 = auto)
   bool device_unclip_ = true; // option device_unclip
   bool device_polygons_ = true;   // option device_polygons
+  bool post_priority_ = true;     // option post_priority: post-processing / trace streams at the device's highest stream priority
 };
 
 class Recognizer {

@@ -16,8 +16,9 @@ pr = [torch.empty_like(dev["text"]), torch.empty_like(dev["text"])]
 blob = W.pack_blob(W.make_det_weights_text())
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 CONFIGS = (("host tracer, host unclip (r4)", "device_contours=0;device_unclip=0"), ("host tracer, device unclip", "device_contours=0"),
+           ("host tracer, device unclip, prio 0", "device_contours=0;post_priority=0"),
            ("device tracer, host DP", "device_contours=1;device_polygons=0"), ("device chain", "device_contours=1"),
-           ("device chain (one wave)", "device_contours=2"))
+           ("device chain, prio 0", "device_contours=1;post_priority=0"))
 for prec in (("f32", "bf16") if which == "both" else (which,)):
     for threads in (1, 2, 4):
         for label, opt in CONFIGS:
