@@ -89,7 +89,7 @@ __device__ long long g_w43_stamps[2 * 4 * 32];
 __device__ long long g_w43_steps[2 * 4 * 26];
 #define W43_STEP(c, k)                                                                                   \
   do {                                                                                                   \
-    if (blockIdx.x == 0 && wave < 2 && lane == 0 && blk_count == 2)                                      \
+    if (blockIdx.x == 0 && wave < 2 && lane == 0 && blk_count == 2 && (c) < 4)                           \
       step_lds[(wave * 4 + (c)) * 26 + (k)] = (long long)__builtin_amdgcn_s_memtime();                   \
   } while (0)
 #else
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
     auto chunk = [&](const int c, auto first) {
       // this wave's share of patch c has landed: it went out at step 0 of the previous chunk and the wait of step 4 there
       // covered it (first block: the wait above)
-      W43_STAMP(1 + 4 * c);
+      if (c < 4) W43_STAMP(1 + 4 * c);   // (the first four chunks: c128 / c256 have more)
       __syncthreads();  // ... every wave's; and nobody still reads the V of the previous chunk
-      W43_STAMP(2 + 4 * c);
+      if (c < 4) W43_STAMP(2 + 4 * c);   // (the first four chunks: c128 / c256 have more)
       // the B stream of a chunk starts here (the transform covers its latency) and drains inside the chunk: a value loaded by
       // inline asm must not be in flight across the loop's back edge, where the compiler may copy registers it believes ready
       issue_b(c * 12 + 0, ring[0]);
@@ -291,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
           }
         }
       }
-      W43_STAMP(3 + 4 * c);
+      if (c < 4) W43_STAMP(3 + 4 * c);   // (the first four chunks: c128 / c256 have more)
       __syncthreads();  // V of chunk c is complete
-      W43_STAMP(4 + 4 * c);
+      if (c < 4) W43_STAMP(4 + 4 * c);   // (the first four chunks: c128 / c256 have more)
       const bool last_chunk = c + 1 == NCH;
       const bool has_patch = !last_chunk || has_next_block;
       f32x4 acur[3], anext[3];

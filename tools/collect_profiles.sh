@@ -9,7 +9,7 @@
 # Back on the build box: tools/rocprof_stats_csv.py <out>/stats and tools/make_pmc_json.py turn the outputs into the CSV / JSON
 # files under profiles/.
 set -o pipefail
-O=$PWD/gpurun_out/${1:-r04/final}
+O=$PWD/gpurun_out/${1:-r05/final}
 mkdir -p $O
 export TMPDIR=/tmp
 python3 -c "import bench; print(bench.csrc_hash())" > $O/csrc_sha.txt   # the kernel sources these passes ran (stamps profiles/pmc.json)
