@@ -78,6 +78,8 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   pyr_p2_direct=0|1    (1)    bf16 precision only: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv on top of the phase
  *                               launch over p5, p4, p3 (0: all four sources in the phase launch)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches
+ *   transform_fuse=0|1   (0)    layer3 / layer4, block 1: conv1's Winograd output transform and conv2's input transform in one launch (the
+ *                               activation between them stays in LDS); bit-identical, and measured to buy nothing
  *   overlap=0|1|2|3      (3)    second stream: 1 small independent launches; 2 the FPN branch as it stands; 3 the FPN's fused-Winograd
  *                               launches (lateral terms of p2 / p3) and bin_conv1's p2 term - f32 matrix instructions - beside layer3 / layer4 /
  *                               the small FPN convs - bf16 matrix instructions and HBM-bound transforms: 1.5 - 2 % of the step (f32 precision with the

@@ -114,6 +114,10 @@ void launch_conv3x3_bf16_c64(const void* x, const void* wfrag, const float* scal
 // of the deep, small-grid layers.  x: [N][H][W][C] f32 -> v: [(m+2)^2][T][C], T = N * ceil(H/m) * ceil(W/m) tiles (zero
 // padding and ragged sizes handled here); mm: [(m+2)^2][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.
 void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, hipStream_t s);
+// F(4x4): output transform of one conv (+ BN, residual, ReLU; y may be null: nothing else reads the activation) and input transform of the next in one launch
+bool winograd43_out_in_fits(int H, int W, int K);
+void launch_winograd43_out_in(const float* mm, const float* scale, const float* bias, const float* residual, int relu, float* y, float* v, int N, int H, int W,
+                              int K, hipStream_t s);
 void launch_winograd_output(const float* mm, const float* scale, const float* bias, const float* residual, int relu,
                             float* y, int N, int H, int W, int K, int m, hipStream_t s);
 // The same conv with both transforms fused into the GEMM kernel, F(4x4,3x3) (winograd43_fused.hip): C = 64, 128 or 256, K a multiple of 64.  ufrag: winograd43_fragments(winograd_weights(.., 4)).

@@ -267,6 +267,7 @@ void Detector::parse_options(const char* options) {
       }
     }
     else if (key == "post_priority") post_priority_ = num() != 0;
+    else if (key == "transform_fuse") transform_fuse_ = num() != 0;
     else if (key == "device_unclip") device_unclip_ = num() != 0;
     else if (key == "device_polygons") device_polygons_ = num() != 0;
     else if (key == "mfma") {
@@ -910,6 +911,79 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   rec.end(!bf && stem_wx3_ ? "stem_x3_conv7x7_bn_relu_maxpool" : "stem_conv7x7_bn_relu_maxpool", 2.0 * n * (h / 2) * (w / 2) * 64 * 49,
           (double)n * h * w * (x_u8 ? 1 : 4) + (double)n * h4 * w4 * 64 * (double)es);
 
+  // the three launches of an unfused Winograd conv (layer3 / layer4, out4, out5), on the main stream: x -> V, V -> M (36 or 16 GEMMs in one
+  // batched launch), M -> y with the epilogue
+  auto wino_dims = [&](const ConvW& cw, int hh, int ww, size_t& wm, size_t& wa, size_t& T) {
+    wm = cw.wino_tile;
+    wa = (wm + 2) * (wm + 2);
+    T = (size_t)n * ((hh + wm - 1) / wm) * ((ww + wm - 1) / wm);
+  };
+  auto wino_in = [&](const ConvW& cw, const void* src, int hh, int ww) {
+    size_t wm, wa, T;
+    wino_dims(cw, hh, ww, wm, wa, T);
+    rec.begin();
+    launch_winograd_input(static_cast<const float*>(src), wino_v_, n, hh, ww, cw.cin, (int)wm, stream_);
+    rec.end(wm == 4 ? "winograd43_input_transform" : "winograd_input_transform", 0.0,
+            (double)n * hh * ww * cw.cin * 4.0 + (double)wa * T * cw.cin * 4.0);
+  };
+  auto wino_gemm = [&](const char* name, const ConvW& cw, int hh, int ww) {
+    size_t wm, wa, T;
+    wino_dims(cw, hh, ww, wm, wa, T);
+    ConvDesc d{};
+    d.src[0] = wino_v_;
+    d.src_mode = SRC_PLAIN;
+    d.src_bytes = wa * T * cw.cin * 4;
+    d.wgt = cw.wino;
+    d.wgt_bytes = cw.wino_bytes;
+    if (split_bf16_ && cw.wino_x3) {
+      d.x3 = 1;
+      d.wgt = cw.wino_x3;
+      d.wgt_bytes = cw.wino_bytes / 4 * 6;
+    }
+    d.batch = (int)wa;
+    d.N = 1;
+    d.Hin = d.Ho = 1;
+    d.Win = d.Wo = (int)T;
+    d.Cin = cw.cin;
+    d.Cout = cw.cout;
+    d.ks = 1;
+    d.stride = 1;
+    d.pad = 0;
+    d.store_mode = STORE_NHWC;
+    d.out = wino_m_;
+    d.name = name;
+    rec.begin();
+    launch_conv_igemm(d, stream_);
+    rec.end(conv_igemm_kernel_name(d), 2.0 * wa * T * cw.cin * cw.cout,
+            (double)wa * 4.0 * ((double)T * cw.cin + (double)T * cw.cout + (double)cw.cin * cw.cout));
+  };
+  auto wino_out = [&](const ConvW& cw, int hh, int ww, void* out, const void* residual, bool relu) {
+    size_t wm, wa, T;
+    wino_dims(cw, hh, ww, wm, wa, T);
+    rec.begin();
+    launch_winograd_output(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(out),
+                           n, hh, ww, cw.cout, (int)wm, stream_);
+    rec.end(wm == 4 ? "winograd43_output_transform" : "winograd_output_transform", 0.0,
+            (double)wa * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
+  };
+  // ... and the output transform of one conv fused with the input transform of the next (winograd.hip: the image of a workgroup's 16
+  // channels stays in LDS); y may be null when only the next conv reads the activation
+  auto wino_out_in = [&](const ConvW& cw, int hh, int ww, void* y, const void* residual, bool relu) {
+    size_t wm, wa, T;
+    wino_dims(cw, hh, ww, wm, wa, T);
+    rec.begin();
+    launch_winograd43_out_in(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(y), wino_v_, n, hh, ww,
+                             cw.cout, stream_);
+    rec.end("winograd43_output+input_transform", 0.0, 2.0 * (double)wa * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * ((residual ? 1.0 : 0.0) + (y ? 1.0 : 0.0)));
+  };
+  // can this conv take the unfused F(4x4) path with fused neighbours?  (the conditions of conv3x3's last branch + the LDS image)
+  auto wino43_unfused = [&](const ConvW& cw, int hh, int ww) {
+    if (bf || !cw.wino || !wino_v_ || cw.wino_tile != 4 || cw.wino43_x3 || cw.wino43_fused || cw.cin != cw.cout) return false;
+    size_t wm, wa, T;
+    wino_dims(cw, hh, ww, wm, wa, T);
+    return wa * T * (size_t)cw.cin * 4 < ((size_t)1 << 31) && winograd43_out_in_fits(hh, ww, cw.cout);
+  };
+
   // 3x3 s1 conv + BN (+ residual) + ReLU of the deep layers as Winograd F(2x2,3x3): input transform, sixteen
   // [tiles x Cin] x [Cin x Cout] GEMMs in one batched launch, output transform with the epilogue (f32 only)
   auto conv3x3 = [&](const char* name, const ConvW& cw, const void* src, int hh, int ww, void* out, const void* residual,
@@ -950,42 +1024,9 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       conv(name, cw, src, hh, ww, 1, out, relu, ex);
       return;
     }
-    rec.begin();
-    launch_winograd_input(static_cast<const float*>(src), wino_v_, n, hh, ww, cw.cin, (int)wm, stream_);
-    rec.end(wm == 4 ? "winograd43_input_transform" : "winograd_input_transform", 0.0,
-            (double)n * hh * ww * cw.cin * 4.0 + (double)wa * T * cw.cin * 4.0);
-    ConvDesc d{};
-    d.src[0] = wino_v_;
-    d.src_mode = SRC_PLAIN;
-    d.src_bytes = wa * T * cw.cin * 4;
-    d.wgt = cw.wino;
-    d.wgt_bytes = cw.wino_bytes;
-    if (split_bf16_ && cw.wino_x3) {
-      d.x3 = 1;
-      d.wgt = cw.wino_x3;
-      d.wgt_bytes = cw.wino_bytes / 4 * 6;
-    }
-    d.batch = (int)wa;
-    d.N = 1;
-    d.Hin = d.Ho = 1;
-    d.Win = d.Wo = (int)T;
-    d.Cin = cw.cin;
-    d.Cout = cw.cout;
-    d.ks = 1;
-    d.stride = 1;
-    d.pad = 0;
-    d.store_mode = STORE_NHWC;
-    d.out = wino_m_;
-    d.name = name;
-    rec.begin();
-    launch_conv_igemm(d, stream_);
-    rec.end(conv_igemm_kernel_name(d), 2.0 * wa * T * cw.cin * cw.cout,
-            (double)wa * 4.0 * ((double)T * cw.cin + (double)T * cw.cout + (double)cw.cin * cw.cout));
-    rec.begin();
-    launch_winograd_output(wino_m_, cw.scale, cw.bias, static_cast<const float*>(residual), relu ? 1 : 0, static_cast<float*>(out),
-                           n, hh, ww, cw.cout, (int)wm, stream_);
-    rec.end(wm == 4 ? "winograd43_output_transform" : "winograd_output_transform", 0.0,
-            (double)wa * T * cw.cout * 4.0 + (double)n * hh * ww * cw.cout * 4.0 * (residual ? 2.0 : 1.0));
+    wino_in(cw, src, hh, ww);
+    wino_gemm(name, cw, hh, ww);
+    wino_out(cw, hh, ww, out, residual, relu);
   };
 
   // composed FPN level lv (0: p2, 1: p3) and its term of bin_conv1: p_k = A_k * x_k + B_k *' x_{k+1} - the
@@ -1037,9 +1078,24 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
         sc.residual = d_[l];
       }
     }
-    conv3x3("layer.conv2", layer_[l][0][1], t_[l], ho, wo, a_[l], sc.residual);
-    conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
-    conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
+    if (transform_fuse_ && wino43_unfused(layer_[l][0][1], ho, wo) && wino43_unfused(layer_[l][1][0], ho, wo) && wino43_unfused(layer_[l][1][1], ho, wo)) {
+      // three unfused F(4x4) convs in a row (layer3 / layer4): conv1's output inside block 1 is read by conv2 only - M -> y -> V in one
+      // launch, the activation never reaches HBM (model.rs:40-55)
+      // (the pair around the block boundary keeps its two launches: there y = a_[l] must be written anyway - the residual of block 1 -
+      // and the fused launch, one workgroup per CU for its LDS image, is slower than the two streaming kernels: 0.107 vs 0.077 ms at H/16)
+      wino_in(layer_[l][0][1], t_[l], ho, wo);
+      wino_gemm("layer.conv2", layer_[l][0][1], ho, wo);
+      wino_out(layer_[l][0][1], ho, wo, a_[l], sc.residual, true);
+      wino_in(layer_[l][1][0], a_[l], ho, wo);
+      wino_gemm("layer.conv1", layer_[l][1][0], ho, wo);
+      wino_out_in(layer_[l][1][0], ho, wo, nullptr, nullptr, true);
+      wino_gemm("layer.conv2", layer_[l][1][1], ho, wo);
+      wino_out(layer_[l][1][1], ho, wo, x_[l], a_[l], true);
+    } else {
+      conv3x3("layer.conv2", layer_[l][0][1], t_[l], ho, wo, a_[l], sc.residual);
+      conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
+      conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
+    }
     cur = x_[l];
     if (overlap3 && l == 1) {
       // x_[0] and x_[1] are ready: the lateral terms of p2 / p3 (fused Winograd: f32 matrix instructions, latency-bound at two waves per

@@ -194,6 +194,8 @@ class Detector {
                                  // slower than the f32-MFMA kernel, DESIGN.md section 3 - kept selectable for A/B)
   bool out4_fused_ = false;      // option out4_fused=1: out4 (256 -> 64 at H/16) on the fused F(4x4,3x3) kernel (0.102 ms) instead of the
                                  // unfused path of layer3 / layer4 (transform + split-bf16 GEMM + transform: 0.084 ms)
+  bool transform_fuse_ = false;  // option transform_fuse=1: inside block 1 of layer3 / layer4 the output transform of conv1 and the input transform of conv2 as one
+                                 // launch (winograd.hip; bit-identical, measured: no gain - DESIGN.md section 9 - so off)
   bool winograd_fused_ = true;   // option winograd_fused=0: direct / unfused-Winograd convs instead of the fused F(4x4,3x3) kernel
   // option mfma=split_bf16 (default) | f32: the MFMA-bound f32 convs without a Winograd kernel of their own (stride-2 3x3,
   // composed FPN phase convs, bin_conv1 over the pyramid, the 36 Winograd GEMMs of layer3 / layer4) run on the bf16 matrix

@@ -266,6 +266,143 @@ __global__ __launch_bounds__(256) void winograd43_output_kernel(const float* __r
   }
 }
 
+
+// ---- output transform of conv k (+ folded BN, residual, ReLU) and input transform of conv k + 1 in ONE launch, for the layers whose
+// image fits a workgroup's LDS (layer3 / layer4 at 640 x 640: 40 x 40 and 20 x 20): the activation between two 3x3 convs of a basic block
+// (/root/reference/src/text_detection/model.rs:40-55) goes M -> y -> V without y's round trip through HBM - and, where nothing else
+// reads it (conv1's output inside a block), without y ever existing.  One workgroup = one image x 16 channels: phase A, per tile and
+// channel pair, A^T M A + epilogue into an LDS image with a zero ring (the next conv's padding); phase B, per tile and pair, the 6 x 6
+// patch out of that image, B^T d B, 36 stores into V.  Same arithmetic, operation for operation, as the two kernels above: bit-identical.
+constexpr int OI_CG = 16;                 // channels per workgroup (64 contiguous bytes per tile and component on the global side)
+constexpr int OI_PS = 20;                 // floats per LDS pixel: 16 + 4 of padding (tile stride 320 B: neighbouring tiles on different banks)
+__global__ __launch_bounds__(256) void winograd43_out_in_kernel(const float* __restrict__ m, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                const float* __restrict__ residual, int relu, float* __restrict__ y, float* __restrict__ v,
+                                                                int H, int W, int K, int th, int tw, long long T, unsigned m_bytes, unsigned y_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float img[];   // [(4 th + 2)][(4 tw + 2)][OI_PS]
+  const int groups = K / OI_CG;
+  const int n = blockIdx.x / groups, k0 = (blockIdx.x - n * groups) * OI_CG;
+  const int tid = threadIdx.x;
+  const int LW = 4 * tw + 2, LH = 4 * th + 2;
+  // zero ring (and nothing else: every interior pixel is written in phase A - pixels beyond the image as zeros)
+  for (int i = tid; i < 2 * (LW + LH) * (OI_CG / 4); i += 256) {
+    const int c4 = (i % (OI_CG / 4)) * 4, q = i / (OI_CG / 4);
+    int yy, xx;
+    if (q < LW) { yy = 0; xx = q; }
+    else if (q < 2 * LW) { yy = LH - 1; xx = q - LW; }
+    else if (q < 2 * LW + LH) { yy = q - 2 * LW; xx = 0; }
+    else { yy = q - 2 * LW - LH; xx = LW - 1; }
+    *reinterpret_cast<f32x4*>(&img[(yy * LW + xx) * OI_PS + c4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m), 0, m_bytes, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(v, 0, m_bytes, 0x00020000);
+  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(y ? y : v, 0, y ? y_bytes : 0u, 0x00020000);
+  const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual : m), 0, residual ? y_bytes : 0u, 0x00020000);
+  const unsigned step = (unsigned)(T * K) * 4u;
+  const int items = th * tw * (OI_CG / 2);
+  // ---- phase A
+  for (int it = tid; it < items; it += 256) {
+    const int kp = it & (OI_CG / 2 - 1), tl = it / (OI_CG / 2);
+    const int ty = tl / tw, tx = tl - ty * tw;
+    const int k = k0 + 2 * kp;
+    const long long t = ((long long)n * th + ty) * tw + tx;
+    const unsigned voff0 = (unsigned)((((n * H + 4 * ty) * W + 4 * tx) * K + k) * 4);
+    unsigned pv[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pv[p][q] = (4 * ty + p < H && 4 * tx + q < W) ? voff0 : WOOB;
+    f32x2 res[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        res[p][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, pv[p][q], (p * W + q) * K * 4, 0));
+    const unsigned voff_m = (unsigned)((t * K + k) * 4);
+    f32x2 u[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x2 a[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) a[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(m_rsrc, voff_m, (6 * i + j) * step, 0));
+      f32x2 col[4];
+      at6(a[0], a[1], a[2], a[3], a[4], a[5], col);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) u[p][j] = col[p];
+    }
+    f32x2 sc = {1.f, 1.f}, bi = {0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x2*>(scale + k);
+    if (bias) bi = *reinterpret_cast<const f32x2*>(bias + k);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x2 o4[4];
+      at6(u[p][0], u[p][1], u[p][2], u[p][3], u[p][4], u[p][5], o4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x2 val = o4[q] * sc + bi + res[p][q];
+        if (relu) {
+          val[0] = fmaxf(val[0], 0.f);
+          val[1] = fmaxf(val[1], 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), y_rsrc, pv[p][q], (p * W + q) * K * 4, 0);   // (no y: an empty descriptor drops it)
+        if (pv[p][q] == WOOB) val = f32x2{0.f, 0.f};   // beyond the image: the next conv's zero padding
+        *reinterpret_cast<f32x2*>(&img[((4 * ty + p + 1) * LW + 4 * tx + q + 1) * OI_PS + 2 * kp]) = val;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase B
+  for (int it = tid; it < items; it += 256) {
+    const int kp = it & (OI_CG / 2 - 1), tl = it / (OI_CG / 2);
+    const int ty = tl / tw, tx = tl - ty * tw;
+    const int k = k0 + 2 * kp;
+    const long long t = ((long long)n * th + ty) * tw + tx;
+    const float* src = &img[((4 * ty) * LW + 4 * tx) * OI_PS + 2 * kp];   // patch origin = pixel (4 ty - 1, 4 tx - 1) of the image
+    f32x2 rt[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x2 d[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x2*>(src + (i * LW + j) * OI_PS);
+      f32x2 tcol[6];
+      bt6(d[0], d[1], d[2], d[3], d[4], d[5], tcol);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rt[i][j] = tcol[i];
+    }
+    const unsigned voff_v = (unsigned)((t * K + k) * 4);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      f32x2 o[6];
+      bt6(rt[i][0], rt[i][1], rt[i][2], rt[i][3], rt[i][4], rt[i][5], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[j]), v_rsrc, voff_v, (6 * i + j) * step, 0);
+    }
+  }
+}
+
+}  // namespace
+
+size_t winograd43_out_in_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) + 2) * (4 * ((W + 3) / 4) + 2) * OI_PS * 4; }
+bool winograd43_out_in_fits(int H, int W, int K) { return K % OI_CG == 0 && winograd43_out_in_lds_bytes(H, W) <= 160 * 1024; }
+
+void launch_winograd43_out_in(const float* m, const float* scale, const float* bias, const float* residual, int relu, float* y, float* v, int N, int H, int W,
+                              int K, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || !winograd43_out_in_fits(H, W, K)) fail(OCR_ERR_INVALID, "winograd out+in: bad shape N=%d H=%d W=%d K=%d", N, H, W, K);
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  const long long T = (long long)N * th * tw;
+  const unsigned long long yb = (unsigned long long)N * H * W * K * 4, mb = 36ull * T * K * 4;
+  if (yb >= (1ull << 31) || mb >= (1ull << 31)) fail(OCR_ERR_INVALID, "winograd out+in: tensors beyond 2 GB");
+  const size_t lds = winograd43_out_in_lds_bytes(H, W);
+  static bool attr_set = false;
+  if (!attr_set) {
+    OCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winograd43_out_in_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(winograd43_out_in_kernel, dim3((unsigned)(N * (K / OI_CG))), dim3(256), lds, s, m, scale, bias, residual, relu, y, v, H, W, K, th, tw, T,
+                     (unsigned)mb, (unsigned)yb);
+  OCR_HIP(hipGetLastError());
+}
+
+namespace {
 }  // namespace
 
 void launch_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, hipStream_t s) {

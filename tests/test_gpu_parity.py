@@ -389,6 +389,7 @@ def test_stem_exact_and_inexact_tiles(det, det_w):
     "fpn_unfused=1",                                               # layer-by-layer FPN
     "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
     "overlap=1", "overlap=2",                                      # second-stream schedules
+    "transform_fuse=1",                                            # layer3 / layer4, block 1: output transform of conv1 + input transform of conv2 in one launch
     "overlap=0", "overlap=3;w43_side_cus=128",                     # one stream (the default is 3: FPN Winograd launches + bin_conv1 p2 term beside layer3 / layer4)
     "mfma=f32",                                                    # every conv on the exact-f32 MFMA (no split-bf16 kernels)
     "mfma=f32;bin_pyr=0",
@@ -410,6 +411,21 @@ def test_engine_modes_agree(det, det_w, options):
         other.close()
     assert np.abs(got - base).max() < 1e-5
     assert np.abs(got - ref).max() < TOL
+
+
+def test_fused_transforms_are_bit_identical(det_w):
+    """winograd43_out_in_kernel (layer3 / layer4: M -> y -> V of two neighbouring 3x3 convs in one launch, the activation in LDS) does the
+    arithmetic of the two separate transform kernels operation for operation: the same map, bit for bit - on a frame size whose deep
+    grids are ragged (H/16 = 6, W/16 = 10: partial 4 x 4 tiles) and on one whose are not, one stream so that nothing else re-associates."""
+    for (n, h, w) in ((3, 96, 160), (2, 128, 192), (1, 64, 64)):
+        x = W.synth_image_batch(41, n, h, w)
+        a = capi.Detector(W.pack_blob(det_w), 0, options="overlap=0;transform_fuse=1")
+        b = capi.Detector(W.pack_blob(det_w), 0, options="overlap=0;transform_fuse=0")
+        try:
+            assert np.array_equal(a.forward_host(x), b.forward_host(x)), (n, h, w)
+        finally:
+            a.close()
+            b.close()
 
 
 def test_engine_options_are_explicit_and_checked(det_w, monkeypatch):
