@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline detector leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--det-options", default="", help="extra engine options of the headline detector, e.g. overlap=0 (profiling aid; the headline is the default engine)")
     ap.add_argument("--no-extras", action="store_true", help="skip recognition / post-processing side numbers")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only, no GPU: the ranks rendezvous on gloo, all-gather fake polygon lists and rank 0 "
@@ -378,7 +379,7 @@ def main():
     det_w = W.make_det_weights(0)
     # host threads of this rank's post-processing pool: its share of the cores when several ranks share the host
     cores_per_rank = int(os.environ.get("OCR_BENCH_CORES_PER_RANK") or max(1, host_cores() // world))
-    det_opts = f"post_threads={min(16, cores_per_rank)}"
+    det_opts = f"post_threads={min(16, cores_per_rank)}" + (";" + a.det_options if a.det_options else "")
     det = capi.Detector(W.pack_blob(det_w), local, options=det_opts)
     if a.dtype == "bf16":
         det.set_precision(capi.PRECISION_BF16)
@@ -469,6 +470,9 @@ def main():
                                 "FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; SQ_INSTS_VALU_MFMA_MOPS_F32/BF16 x 512; "
                                 "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE per XCD)",
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
+                "avg_launch_note": "one stream (ocr_det_forward_profile).  In the timed steps (engine option overlap=3, default) two of this kernel's six launches per step run on the "
+                                   "side stream beside layer3 / layer4 and stretch; rocprofv3's average over ALL launches of the default command is therefore higher "
+                                   "(profiles/README.md); with --det-options overlap=0 it is this number",
                 "avg_launch_gflop_executed": round(mult * fl / cnt / 1e9, 3),
                 "all_kernels": allk}
         if name.startswith("winograd43_fused"):
@@ -935,6 +939,8 @@ def main():
         line.update(e2e)
         line.update(post)
         line.update(extras)
+        if a.det_options:
+            line["det_options"] = a.det_options
         line["post_threads"] = min(16, cores_per_rank)
         line["cores_per_rank"] = cores_per_rank
         if not a.no_cpu_baseline:   # every N: each line of a scaling sweep stands alone (the other ranks wait in the barrier below)

@@ -18,6 +18,9 @@ rocprofv3 --kernel-trace --stats -d $O/stats -o t -- python3 bench.py --steps 20
 # average duration per kernel is the one bench.py's HIP events report (the full command also runs 8-frame pieces for the
 # host-memory rates and other weights, which share kernel names)
 rocprofv3 --kernel-trace --stats -d $O/stats_headline -o t -- python3 bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_headline.json 2> /dev/null || exit 1
+# ... and with the engine's side stream off (overlap=0): every launch of the dominant kernel runs alone, as in bench.py's own per-launch
+# HIP-event passes (ocr_det_forward_profile is always one stream) - the run whose rocprof average the roofline's avg_launch_ms must match
+rocprofv3 --kernel-trace --stats -d $O/stats_headline_overlap0 -o t -- python3 bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline --det-options overlap=0 > $O/bench_line_headline_overlap0.json 2> /dev/null || exit 1
 echo "bench under rocprof done"
 for P in f32 bf16; do
   OPT=""; [ $P = bf16 ] && OPT="precision=bf16"

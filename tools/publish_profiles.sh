@@ -5,6 +5,8 @@ set -e
 O=$1; T=${2:-r04}; P=profiles
 python3 tools/rocprof_stats_csv.py $O/stats > $P/${T}_bench_kernel_stats.csv
 python3 tools/rocprof_stats_csv.py $O/stats_headline > $P/${T}_bench_kernel_stats_headline.csv
+python3 tools/rocprof_stats_csv.py $O/stats_headline_overlap0 > $P/${T}_bench_kernel_stats_headline_overlap0.csv
+grep '^{' $O/bench_line_headline_overlap0.json | tail -1 > $P/${T}_bench_line_headline_overlap0_under_rocprof.json
 grep '^{' $O/bench_line.json | tail -1 > $P/${T}_bench_line_under_rocprof.json
 grep '^{' $O/bench_line_headline.json | tail -1 > $P/${T}_bench_line_headline_under_rocprof.json
 grep '^{' $O/bench_line_bf16.json | tail -1 > $P/${T}_bench_line_bf16.json
