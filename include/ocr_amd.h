@@ -82,8 +82,8 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               activation between them stays in LDS); bit-identical, and measured to buy nothing
  *   overlap=0|1|2|3      (3)    second stream: 1 small independent launches; 2 the FPN branch as it stands; 3 the FPN's fused-Winograd
  *                               launches (lateral terms of p2 / p3) and bin_conv1's p2 term - f32 matrix instructions - beside layer3 / layer4 /
- *                               the small FPN convs - bf16 matrix instructions and HBM-bound transforms: 1.5 - 2 % of the step (f32 precision with the
- *                               default kernels; otherwise, and under ocr_det_forward_profile, one stream).  Sums re-associate by one rounding
+ *                               the small FPN convs - bf16 matrix instructions and HBM-bound transforms: 2 % of the step in both precisions (default kernels;
+ *                               otherwise, and under ocr_det_forward_profile, one stream).  Sums re-associate by one rounding
  *   post_threads=<n>     (0)    host threads of the post-processing stages (contours, unclip), the calling thread included;
  *                               0 = min(16, CPU share of the process: cgroup quota or online cores).  One process per GPU on a
  *                               shared host should pass its share (cores / ranks)

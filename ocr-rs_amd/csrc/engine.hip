@@ -822,8 +822,9 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   const bool bf = bf16_;
   const size_t es = bf ? 2 : 4;
   hipStream_t cs = stream_;  // stream of the launches below (the side stream while the FPN branch is enqueued)
-  const bool overlap3 = overlap_ >= 3 && !prof && fpn_composed_ && !bf16_ && bin_pyr_on_ && fused_tail_ && fpn_a_[0].wino43_fused && fpn_a_[1].wino43_fused &&
-                        bin_p2_.wino43_fused && !fpn_a_[0].wino43_x3 && split_bf16_;
+  const bool overlap3 = overlap_ >= 3 && !prof && fpn_composed_ && bin_pyr_on_ && fused_tail_ &&
+                        (bf16_ ? (fpn_a_[0].w_bf16_c64 && bin_p2_.w_bf16_c64 && pyr_p2_direct_)
+                               : (fpn_a_[0].wino43_fused && fpn_a_[1].wino43_fused && bin_p2_.wino43_fused && !fpn_a_[0].wino43_x3 && split_bf16_));
   const bool overlap = overlap3 || (overlap_ == 2 && !prof && fpn_composed_ && !bf16_);   // the FPN branch on the side stream, joined before bin_conv1
   const bool overlap_small = (overlap_ == 1 || overlap_ == 2) && !prof;   // (3: the side stream is the FPN branch's alone)
   // run `side_work` on the second stream from this point of the main stream on; join() makes the main stream
@@ -1190,7 +1191,12 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     py.pyr4 = true;
     py.store = STORE_PHASE;
     py.f32_out = !bf;  // bf16 precision: the fused head reads bf16
-    if (bf && bin_p2_.w_bf16_c64 && pyr_p2_direct_) {
+    if (overlap3) {
+      // p2's term was computed on the side stream (into t_[0]): the phase launch over p5, p4, p3 adds it, the bias and the ReLU
+      py.pyr_nsrc = 3;
+      py.residual = t_[0];
+      conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+    } else if (bf && bin_p2_.w_bf16_c64 && pyr_p2_direct_) {
       // bf16: the three upsampled sources in the phase launch, p2's 3x3 term on top as the patch-staged 64 -> 64 conv (bias + ReLU
       // there).  p2's nine taps are more than half of the phase launch's gathers (one pixel row per cell, tap and phase - the part
       // of that launch that costs); the direct kernel stages every p2 pixel once.  The partial sum passes through bf16 once more.
@@ -1203,11 +1209,6 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       conv3x3("bin_conv1.p2", p2, p_[0], h4, w4, b1_, b1_, true);
     } else if (bf) {
       // all four sources in the one phase launch (112.8 GF instead of the gathered conv's 241.6), bias + ReLU in its epilogue
-      conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
-    } else if (overlap3) {
-      // p2's term was computed on the side stream (into t_[0]): the phase launch over p5, p4, p3 adds it, the bias and the ReLU
-      py.pyr_nsrc = 3;
-      py.residual = t_[0];
       conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
     } else if (bin_p2_.wino43_fused) {
       // the three upsampled sources in the phase launch, p2's 3x3 term on top as a fused Winograd conv (+ bias, ReLU)

@@ -86,7 +86,7 @@ def test_bf16_bin_conv1_forms_meet_the_same_bars(det_w):
     ref32, ref16 = T.det_forward(det_w, x), T.det_forward_bf16(det_w, x)
     d_ref = np.abs(ref16 - ref32)
     maps = []
-    for opt in ("precision=bf16", "precision=bf16;pyr_p2_direct=0"):
+    for opt in ("precision=bf16", "precision=bf16;pyr_p2_direct=0", "precision=bf16;overlap=0"):   # (the default schedule is overlap=3)
         d = capi.Detector(W.pack_blob(det_w), 0, options=opt)
         try:
             maps.append(d.forward_host(x))
@@ -96,3 +96,5 @@ def test_bf16_bin_conv1_forms_meet_the_same_bars(det_w):
         assert np.abs(maps[-1] - ref32).mean() <= DRIFT_FACTOR * d_ref.mean(), opt
     assert not np.array_equal(maps[0], maps[1])   # two different schedules really ran
     assert np.abs(maps[0] - maps[1]).max() <= DRIFT_FACTOR * d_ref.max()
+    # the side-stream schedule (bin_conv1's p2 term rounded to bf16 BEFORE the pyramid's sum is added instead of after) against the one-stream one
+    assert np.abs(maps[0] - maps[2]).max() <= DRIFT_FACTOR * d_ref.max()
