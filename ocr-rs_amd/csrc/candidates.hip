@@ -234,9 +234,11 @@ __global__ __launch_bounds__(256) void cand_fill_kernel(const int* __restrict__ 
   const int my_c = max(tot[2 * img], 0), my_p = max(tot[2 * img + 1], 0);
   const bool fits = job0 + my_c <= max_jobs && pt0 + my_p <= max_pts;
   if (img == n - 1 && t == 0) {
-    totals[0] = job0 + my_c;
-    totals[1] = pt0 + my_p;
-    totals[2] = fits ? 0 : 1;   // the lists are prefixes: if the last image fits, all do
+    // the lists are prefixes: if the last image fits, all do.  An overflowing batch reports ZERO jobs - the kernels behind this one
+    // (box scores, unclip) walk the list by this count and must not run past what was written - and the host path takes the batch
+    totals[0] = fits ? job0 + my_c : 0;
+    totals[1] = fits ? pt0 + my_p : 0;
+    totals[2] = fits ? 0 : 1;
   }
   if (tot[2 * img] <= 0 || !fits) return;
   const int nc = hdr_all[4 * img];

@@ -392,11 +392,8 @@ void launch_winograd43_out_in(const float* m, const float* scale, const float* b
   const unsigned long long yb = (unsigned long long)N * H * W * K * 4, mb = 36ull * T * K * 4;
   if (yb >= (1ull << 31) || mb >= (1ull << 31)) fail(OCR_ERR_INVALID, "winograd out+in: tensors beyond 2 GB");
   const size_t lds = winograd43_out_in_lds_bytes(H, W);
-  static bool attr_set = false;
-  if (!attr_set) {
-    OCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winograd43_out_in_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  // (per launch: the attribute belongs to the device the calling thread has current, and handles of several devices may share a process)
+  OCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winograd43_out_in_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(winograd43_out_in_kernel, dim3((unsigned)(N * (K / OI_CG))), dim3(256), lds, s, m, scale, bias, residual, relu, y, v, H, W, K, th, tw, T,
                      (unsigned)mb, (unsigned)yb);
   OCR_HIP(hipGetLastError());

@@ -185,3 +185,31 @@ def test_pipelined_calls_with_pretraced_contours_return_the_same_polygons():
             assert a[0] == b[0], (dc, k)
             assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a[1], b[1])), (dc, k)
     assert sum(len(p) for r in results[0] for p in r[0]) > 100   # there was something to compare
+
+
+def test_device_chain_overflow_takes_the_host_path():
+    """More candidates than the device job list holds (1 024 per image of the batch): the chain reports the overflow with ZERO jobs - so that
+    box scores and unclip, which walk the list by that count, touch nothing - and the host path takes the batch: same polygons."""
+    m = np.zeros((1, 1, 640, 640), np.float32)
+    k = 0
+    for gy in range(8, 632, 16):
+        for gx in range(8, 632, 20):
+            if k < 1200:
+                m[0, 0, gy:gy + 7, gx:gx + 9] = 0.9
+                k += 1
+    blob = W.pack_blob(W.make_det_weights(0))
+    host = capi.Detector(blob, 0, options="device_contours=0;device_unclip=0")
+    dev = capi.Detector(blob, 0, options="device_contours=1")
+    adj = np.ones((1, 2))
+    want = _post(host, m, adj)
+    got = _post(dev, m, adj)
+    assert len(want[0][0]) == 1200
+    assert got[0] == want[0] and got[1] == want[1]
+    # ... and a batch of two such maps with room for both (2 048 jobs) stays on the device and agrees as well
+    m2 = np.concatenate([m, m])
+    m2[1, 0, 300:, :] = 0.0
+    want2 = _post(host, m2, np.ones((2, 2)))
+    got2 = _post(dev, m2, np.ones((2, 2)))
+    assert got2[0] == want2[0] and got2[1] == want2[1]
+    host.close()
+    dev.close()
