@@ -220,3 +220,63 @@ def test_reference_known_answer_through_the_device_unclip(golden_dir):
     polys, scores = d.postprocess(pred, 1, 800, 800, np.array([[2.0, 2.0]]))
     assert polys[0] == K.IMG55_POLYS_ADJ2
     d.close()
+
+
+def _random_maps(rng, n, s):
+    """smoothed noise at several scales, rotated boxes, rings with holes, dense text, speckle: tools/fuzz_chain.py's generator"""
+    maps = np.zeros((n, 1, s, s), np.float32)
+    for i in range(n):
+        kind = int(rng.integers(0, 4))
+        m = rng.random((s, s))
+        if kind == 0:
+            for _ in range(int(rng.integers(3, 25))):
+                m = (m + np.roll(m, 1, 0) + np.roll(m, 1, 1) + np.roll(m, -1, 0) + np.roll(m, -1, 1)) / 5
+            m = (m - m.min()) / (m.max() - m.min() + 1e-9)
+            m = np.clip((m - rng.uniform(0.35, 0.6)) * rng.uniform(3, 12) + 0.6, 0, 1)
+        elif kind == 1:
+            yy, xx = np.mgrid[0:s, 0:s]
+            m = 0.1 * m
+            for _ in range(int(rng.integers(3, 60))):
+                cx, cy, w, h, th = rng.uniform(0, s), rng.uniform(0, s), rng.uniform(4, 90), rng.uniform(3, 30), rng.uniform(0, np.pi)
+                u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+                v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+                m = np.where((np.abs(u) < w / 2) & (np.abs(v) < h / 2), rng.uniform(0.62, 1.0), m)
+        elif kind == 2:
+            yy, xx = np.mgrid[0:s, 0:s]
+            m = 0.2 * m
+            for _ in range(int(rng.integers(2, 20))):
+                cx, cy, r0, r1 = rng.uniform(0, s), rng.uniform(0, s), rng.uniform(0, 20), rng.uniform(5, 50)
+                d = np.hypot(xx - cx, yy - cy)
+                m = np.where((d >= r0) & (d <= r0 + r1), rng.uniform(0.65, 0.95), m)
+        elif s >= 128:
+            m = W.dense_text_maps(1, s, int(rng.integers(0, 1 << 30)))[0, 0]
+        if rng.random() < 0.3:
+            m = np.where(rng.random((s, s)) < 0.002, 0.9, m)
+        maps[i, 0] = m
+    return maps
+
+
+def test_random_maps_give_the_same_polygons_wherever_the_chain_runs():
+    """30 random batches (tools/fuzz_chain.py runs 120: 16 131 polygons, no mismatch): host path, device unclip behind the host tracer, the whole
+    chain on the device - identical polygon lists and scores, random adjust values"""
+    blob = W.pack_blob(W.make_det_weights(0))
+    host = capi.Detector(blob, 0, options="device_contours=0;device_unclip=0")
+    chain = capi.Detector(blob, 0, options="device_contours=1")
+    unclip = capi.Detector(blob, 0, options="device_contours=0;device_unclip=1")
+    rng = np.random.default_rng(77)
+    params = capi.default_params(skip_degenerate=True)
+    total = 0
+    for b in range(30):
+        s = int(rng.choice([64, 128, 256, 320, 640]))
+        n = int(rng.integers(1, 4))
+        maps = _random_maps(rng, n, s)
+        adj = np.stack([rng.uniform(0.4, 2.0, n), rng.uniform(0.4, 2.0, n)], 1)
+        want = host.postprocess(maps, n, s, s, adj, capi.MEM_HOST, params)
+        for name, d in (("chain", chain), ("unclip", unclip)):
+            got = d.postprocess(maps, n, s, s, adj, capi.MEM_HOST, params)
+            assert got[0] == want[0], (b, name, s, n)
+            assert all(np.array_equal(np.asarray(a), np.asarray(c)) for a, c in zip(got[1], want[1])), (b, name)
+        total += sum(len(p) for p in want[0])
+    assert total > 1000
+    for d in (host, chain, unclip):
+        d.close()
