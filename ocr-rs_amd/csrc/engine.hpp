@@ -246,6 +246,7 @@ class Detector {
   int device_contours_ = -1;  // option device_contours (-1 = auto)
   bool device_unclip_ = true; // option device_unclip
   bool device_polygons_ = true;   // option device_polygons
+  bool head_cus_yield_ = true;    // option head_cus_yield: layer1's persistent grids leave the previous batch's tracer its CUs (pipelined calls)
   bool post_priority_ = true;     // option post_priority: post-processing / trace streams at the device's highest stream priority
 };
 
