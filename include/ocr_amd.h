@@ -95,8 +95,10 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               640 x 640 - larger ones, and images the kernel gives up on, take the host tracer inside the same call).
  *                               1: plausible border starts walked in parallel, the raster scan only replays the label tests (0.95-1.5 ms
  *                               per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
- *                               contours either way.  auto: 1 where the host pool (post_threads) has one thread - or, in the bf16 precision,
- *                               at most two -, else 0: by measurement
+ *                               contours either way.  auto: 1 where the host pool (post_threads) has at most two threads, else 0: by
+ *                               measurement
+ *   head_cus_yield=0|1   (1)    pipelined calls: while the polygon chain of the previous batch runs (its tracer holds one CU per image), layer1's
+ *                               persistent grids are sized for the CUs that are free
  *   post_priority=0|1    (1)    the post-processing / trace streams at the device's highest stream priority: their short kernels are placed as
  *                               soon as a CU drains instead of queueing behind the next forward's workgroups
  *   device_polygons=0|1  (1)    with device contours on square maps: Douglas-Peucker, the >= 4 points filter and the box-score job list on

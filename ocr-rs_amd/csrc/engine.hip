@@ -621,12 +621,12 @@ static int host_cpu_share() {
 
 int Detector::post_threads() const { return post_threads_ > 0 ? post_threads_ : std::min(16, host_cpu_share()); }
 
-// auto (the default): the whole polygon chain on the device where the host pool is small - by measurement (DESIGN.md section 4,
-// tools/device_contours_sweep.py): one thread cannot trace and simplify the contours of the f32 detector's dense pages in time (4.7 k
-// pages per second against 5.6 k with the chain), two threads can (5.9 k); the bf16 detector is three times faster: there the chain wins
-// up to two threads (13.9 k / 11.0 k against 11.2 k / 6.8 k).  With more threads the host tracer beside the device unclip is ahead on
-// text pages - the tracer's 32 whole-CU workgroups run beside the next forward and cost it 4 - 8 %
-int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= (bf16_ ? 2 : 1) ? 1 : 0); }
+// auto (the default): the whole polygon chain on the device where the host pool has one or two threads - by measurement (DESIGN.md
+// section 4, tools/device_contours_sweep.py, frames per second on text / dense pages): f32, one thread 6.3 k / 6.0 k against 6.2 k / 4.7 k with
+// the host tracer beside the device unclip, two threads 6.2 k / 6.0 k against 6.2 k / 5.9 k; bf16 15.2 k / 11.6 k against 9.8 k / 5.1 k and
+// 15.2 k / 11.5 k against 14.9 k / 8.4 k.  From four threads on the host tracer is ahead on text pages (6.5 k against 6.3 k, 15.5 k against
+// 14.9 k): the device tracer's 32 whole-CU workgroups run beside the next forward and cost it 3 - 5 %
+int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 ? 1 : 0); }
 
 ThreadPool& Detector::pool() {
   if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread
