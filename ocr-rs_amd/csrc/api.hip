@@ -189,11 +189,16 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     int32_t* d_pts = ch.pts();
     double *d_sum = ch.sums(), *d_cnt = ch.counts();
     int* d_totals = ch.totals();
-    std::vector<int32_t> tot((size_t)n * 2);
-    int32_t totals[4] = {0, 0, 0, 0};
-    OCR_HIP(hipMemcpyAsync(tot.data(), sc + o_tot, tot.size() * 4, hipMemcpyDeviceToHost, s));
-    OCR_HIP(hipMemcpyAsync(totals, d_totals, 12, hipMemcpyDeviceToHost, s));
+    // both round trips land in the handle's pinned buffer: the copies are queued back to back and really asynchronous (into pageable
+    // memory each of them is a blocking staged copy)
+    const size_t h_tot = 0, h_totals = align256((size_t)n * 8);
+    char* hb = static_cast<char*>(det.host_scratch(h_totals + 256));
+    OCR_HIP(hipMemcpyAsync(hb + h_tot, sc + o_tot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipMemcpyAsync(hb + h_totals, d_totals, 12, hipMemcpyDeviceToHost, s));
     OCR_HIP(hipStreamSynchronize(s));
+    const std::vector<int32_t> tot(reinterpret_cast<const int32_t*>(hb + h_tot), reinterpret_cast<const int32_t*>(hb + h_tot) + 2 * (size_t)n);
+    int32_t totals[4] = {0, 0, 0, 0};
+    std::memcpy(totals, hb + h_totals, 12);
 #ifdef POSTPROC_TIMING
     T1 = T2 = tnow();
 #endif
@@ -202,18 +207,23 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     } else {
       const int tj = totals[0];
       const size_t tp = (size_t)totals[1];
-      std::vector<BoxScoreJob> jobs(tj);
-      std::vector<double> sums(tj), counts(tj);
-      std::vector<int32_t> ustatus(tj), ulen(tj), pts(tp * 2);
-      std::vector<uint32_t> uxy(3 * tp * 2);
+      const size_t h_jobs = 0, h_sum = h_jobs + align256((size_t)tj * sizeof(BoxScoreJob)), h_cnt = h_sum + align256((size_t)tj * 8),
+                   h_st = h_cnt + align256((size_t)tj * 8), h_len = h_st + align256((size_t)tj * 4), h_pts = h_len + align256((size_t)tj * 4),
+                   h_oxy = h_pts + align256(tp * 8), h_end = h_oxy + align256(3 * tp * 8);
+      hb = static_cast<char*>(det.host_scratch(h_end + 256));
+      const BoxScoreJob* jobs = reinterpret_cast<const BoxScoreJob*>(hb + h_jobs);
+      const double *sums = reinterpret_cast<const double*>(hb + h_sum), *counts = reinterpret_cast<const double*>(hb + h_cnt);
+      const int32_t *ustatus = reinterpret_cast<const int32_t*>(hb + h_st), *ulen = reinterpret_cast<const int32_t*>(hb + h_len),
+                    *pts = reinterpret_cast<const int32_t*>(hb + h_pts);
+      const uint32_t* uxy = reinterpret_cast<const uint32_t*>(hb + h_oxy);
       if (tj > 0) {
-        OCR_HIP(hipMemcpyAsync(jobs.data(), d_jobs, (size_t)tj * sizeof(BoxScoreJob), hipMemcpyDeviceToHost, s));
-        OCR_HIP(hipMemcpyAsync(sums.data(), d_sum, (size_t)tj * 8, hipMemcpyDeviceToHost, s));
-        OCR_HIP(hipMemcpyAsync(counts.data(), d_cnt, (size_t)tj * 8, hipMemcpyDeviceToHost, s));
-        OCR_HIP(hipMemcpyAsync(ustatus.data(), sc + o_st, (size_t)tj * 4, hipMemcpyDeviceToHost, s));
-        OCR_HIP(hipMemcpyAsync(ulen.data(), sc + o_len, (size_t)tj * 4, hipMemcpyDeviceToHost, s));
-        OCR_HIP(hipMemcpyAsync(pts.data(), d_pts, tp * 8, hipMemcpyDeviceToHost, s));
-        OCR_HIP(hipMemcpyAsync(uxy.data(), sc + o_oxy, uxy.size() * 4, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_jobs, d_jobs, (size_t)tj * sizeof(BoxScoreJob), hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_sum, d_sum, (size_t)tj * 8, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_cnt, d_cnt, (size_t)tj * 8, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_st, sc + o_st, (size_t)tj * 4, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_len, sc + o_len, (size_t)tj * 4, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_pts, d_pts, tp * 8, hipMemcpyDeviceToHost, s));
+        OCR_HIP(hipMemcpyAsync(hb + h_oxy, sc + o_oxy, 3 * tp * 8, hipMemcpyDeviceToHost, s));
         OCR_HIP(hipStreamSynchronize(s));
       }
       std::vector<int> first_job(n + 1, 0);
@@ -236,7 +246,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
             c.resize((size_t)jb.n_pts);
             for (int i = 0; i < jb.n_pts; ++i) c[i] = {pts[2 * ((size_t)jb.pt_offset + i)], pts[2 * ((size_t)jb.pt_offset + i) + 1]};
           }
-          take(per[b], ustatus[j], uxy.data() + 6 * (size_t)jb.pt_offset, ulen[j], c, score, b);
+          take(per[b], ustatus[j], uxy + 6 * (size_t)jb.pt_offset, ulen[j], c, score, b);
         }
       });
     }
@@ -336,44 +346,44 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   }
   first_job[todo.size()] = (int)jobs.size();
   const int nj = (int)jobs.size();
-  std::vector<double> sums(nj), counts(nj);
-  // unclip on the device behind the box score (unclip.hip): per candidate a status, and for the ones it settles the adjusted polygon
-  std::vector<int32_t> ustatus, ulen;
-  std::vector<uint32_t> uxy;
+  // unclip on the device behind the box score (unclip.hip): per candidate a status, and for the ones it settles the adjusted polygon.
+  // Job list up and results down through the handle's pinned buffer (asynchronous copies, one wait)
+  const double *sums = nullptr, *counts = nullptr;
+  const int32_t *ustatus = nullptr, *ulen = nullptr;
+  const uint32_t* uxy = nullptr;
   if (nj > 0) {
     const size_t npts = pts.size() / 2;
     const size_t o_jobs = 0;
     const size_t o_pts = o_jobs + align256(jobs.size() * sizeof(BoxScoreJob));
-    const size_t o_sum = o_pts + align256(pts.size() * 4);
+    const size_t o_adj = o_pts + align256(pts.size() * 4);
+    const size_t o_sum = o_adj + align256((size_t)n * 16);            // from here on: results (one block on either side)
     const size_t o_cnt = o_sum + align256((size_t)nj * 8);
-    const size_t o_adj = o_cnt + align256((size_t)nj * 8);
-    const size_t o_st = o_adj + align256((size_t)n * 16);
+    const size_t o_st = o_cnt + align256((size_t)nj * 8);
     const size_t o_len = o_st + align256((size_t)nj * 4);
     const size_t o_oxy = o_len + align256((size_t)nj * 4);
     const size_t o_work = o_oxy + align256(dev_unclip ? 3 * npts * 8 : 0);
     const size_t total = o_work + align256(dev_unclip ? unclip_work_bytes(npts, nj) : 0);
     scratch = static_cast<char*>(det.scratch(1, total));  // slot 0 (map copy) stays valid
-    OCR_HIP(hipMemcpyAsync(scratch + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob), hipMemcpyHostToDevice, s));
-    OCR_HIP(hipMemcpyAsync(scratch + o_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice, s));
+    char* hb = static_cast<char*>(det.host_scratch(o_work));
+    std::memcpy(hb + o_jobs, jobs.data(), jobs.size() * sizeof(BoxScoreJob));
+    std::memcpy(hb + o_pts, pts.data(), pts.size() * 4);
+    std::memcpy(hb + o_adj, adj, (size_t)n * 16);
+    OCR_HIP(hipMemcpyAsync(scratch + o_jobs, hb + o_jobs, o_sum - o_jobs, hipMemcpyHostToDevice, s));   // jobs, points, adjust values: one copy
     launch_box_scores(prob_dev, h, w, reinterpret_cast<const BoxScoreJob*>(scratch + o_jobs),
                       reinterpret_cast<const int32_t*>(scratch + o_pts), nj, reinterpret_cast<double*>(scratch + o_sum),
                       reinterpret_cast<double*>(scratch + o_cnt), s);
-    OCR_HIP(hipMemcpyAsync(sums.data(), scratch + o_sum, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
-    OCR_HIP(hipMemcpyAsync(counts.data(), scratch + o_cnt, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
-    if (dev_unclip) {
-      OCR_HIP(hipMemcpyAsync(scratch + o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    if (dev_unclip)
       launch_unclip(reinterpret_cast<const BoxScoreJob*>(scratch + o_jobs), reinterpret_cast<const int32_t*>(scratch + o_pts), nullptr, nj, npts,
                     reinterpret_cast<const double*>(scratch + o_sum), reinterpret_cast<const double*>(scratch + o_cnt),
                     reinterpret_cast<const double*>(scratch + o_adj), up, scratch + o_work, reinterpret_cast<uint32_t*>(scratch + o_oxy),
                     reinterpret_cast<int32_t*>(scratch + o_len), reinterpret_cast<int32_t*>(scratch + o_st), s);
-      ustatus.resize(nj);
-      ulen.resize(nj);
-      uxy.resize(3 * npts * 2);
-      OCR_HIP(hipMemcpyAsync(ustatus.data(), scratch + o_st, (size_t)nj * 4, hipMemcpyDeviceToHost, s));
-      OCR_HIP(hipMemcpyAsync(ulen.data(), scratch + o_len, (size_t)nj * 4, hipMemcpyDeviceToHost, s));
-      OCR_HIP(hipMemcpyAsync(uxy.data(), scratch + o_oxy, uxy.size() * 4, hipMemcpyDeviceToHost, s));
-    }
+    OCR_HIP(hipMemcpyAsync(hb + o_sum, scratch + o_sum, (dev_unclip ? o_work : o_st) - o_sum, hipMemcpyDeviceToHost, s));   // sums, counts [, status, lengths, polygons]
     OCR_HIP(hipStreamSynchronize(s));
+    sums = reinterpret_cast<const double*>(hb + o_sum);
+    counts = reinterpret_cast<const double*>(hb + o_cnt);
+    ustatus = reinterpret_cast<const int32_t*>(hb + o_st);
+    ulen = reinterpret_cast<const int32_t*>(hb + o_len);
+    uxy = reinterpret_cast<const uint32_t*>(hb + o_oxy);
   }
 #ifdef POSTPROC_TIMING
   T3 = tnow();
@@ -386,7 +396,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     int j = first_job[k];
     for (const auto& c : cands[b]) {
       const double score = sums[j] / counts[j];
-      take(r, dev_unclip ? ustatus[j] : (int)UNCLIP_HOST, dev_unclip ? uxy.data() + 6 * (size_t)jobs[j].pt_offset : nullptr, dev_unclip ? ulen[j] : 0, c,
+      take(r, dev_unclip ? ustatus[j] : (int)UNCLIP_HOST, dev_unclip ? uxy + 6 * (size_t)jobs[j].pt_offset : nullptr, dev_unclip ? ulen[j] : 0, c,
            score, b);
       ++j;
     }

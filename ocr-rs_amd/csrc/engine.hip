@@ -566,6 +566,7 @@ Detector::~Detector() {
   for (hipEvent_t ev : pipe_ev_)
     if (ev) (void)hipEventDestroy(ev);
   free_workspace();
+  if (host_scratch_) (void)hipHostFree(host_scratch_);
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
   for (Staging& st : stage_)
@@ -619,7 +620,11 @@ static int host_cpu_share() {
   return (int)n;
 }
 
-int Detector::post_threads() const { return post_threads_ > 0 ? post_threads_ : std::min(16, host_cpu_share()); }
+int Detector::post_threads() const {
+  if (post_threads_ > 0) return post_threads_;
+  if (auto_threads_ == 0) auto_threads_ = std::min(16, host_cpu_share());   // (three sysfs reads: once per handle, not per call)
+  return auto_threads_;
+}
 
 // auto (the default): the whole polygon chain on the device where the host pool has one or two threads - by measurement (DESIGN.md
 // section 4, tools/device_contours_sweep.py, frames per second on text / dense pages): f32, one thread 6.3 k / 6.0 k against 6.2 k / 4.7 k with
@@ -671,6 +676,18 @@ hipEvent_t Detector::pipeline_event() {
 void Detector::synchronize() {
   OCR_HIP(hipSetDevice(device_));
   OCR_HIP(hipStreamSynchronize(stream_));
+}
+
+void* Detector::host_scratch(size_t bytes) {
+  if (bytes > host_scratch_bytes_) {
+    if (host_scratch_) OCR_HIP(hipHostFree(host_scratch_));
+    host_scratch_ = nullptr;
+    host_scratch_bytes_ = 0;
+    const size_t want = bytes + bytes / 2;
+    OCR_HIP(hipHostMalloc(&host_scratch_, want, hipHostMallocDefault));
+    host_scratch_bytes_ = want;
+  }
+  return host_scratch_;
 }
 
 void* Detector::scratch(int slot, size_t bytes) {

@@ -105,6 +105,8 @@ class Detector {
   // growable device scratch for post-processing; slot 0: map copy + bitmap, slot 1: jobs / results, slot 2: device contours, slot 3: the same for the batch a pipelined call left pending, slot 4: that batch's polygon chain.
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
+  // growable PINNED host memory where the polygon chain's results land (one buffer per handle: a call collects before it returns)
+  void* host_scratch(size_t bytes);
   // host threads of the post-processing stages (created on first use, one image per task)
   ThreadPool& pool();
   // ocr_det_detect_pipelined: the batch whose forward is in flight and whose post-processing is still owed
@@ -230,6 +232,9 @@ class Detector {
   hipEvent_t trace_done_ = nullptr;
   hipEvent_t pipe_ev_[2] = {nullptr, nullptr};
   int pipe_ev_next_ = 0;
+  void* host_scratch_ = nullptr;
+  size_t host_scratch_bytes_ = 0;
+  mutable int auto_threads_ = 0;   // min(16, CPU share), read once
   void* scratch_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes_[5] = {0, 0, 0, 0, 0};
   struct Staging {
