@@ -87,7 +87,8 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   post_threads=<n>     (0)    host threads of the post-processing stages (contours, unclip), the calling thread included;
  *                               0 = min(16, CPU share of the process: cgroup quota or online cores).  One process per GPU on a
  *                               shared host should pass its share (cores / ranks)
- *   device_unclip=0|1    (1)    behind the box scores, per candidate polygon on the GPU (unclip.hip): score threshold, miter offset, the union where
+ *   device_unclip=0|1|2  (1)    behind the box scores, per candidate polygon on the GPU (unclip.hip; 1: where a call has more than 40 candidates per pool
+ *                               thread - the kernel is lane-serial, 0.2 ms however few it gets -, 2: always): score threshold, miter offset, the union where
  *                               the ring is simple or only crosses itself at its concave vertices, min-size test, round(p / adj).  What it does
  *                               not settle (other self-intersections, squared-off corners, a short side within 3 px of min_size) the host
  *                               finishes inside the same call; results are bit for bit the host path's (0)

@@ -152,7 +152,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   std::vector<std::vector<std::vector<geom::Pt>>> cands(n);
   std::vector<int> todo;            // images whose candidates the host has (or must make): box scores + unclip in the second part
   std::vector<uint32_t> bits;
-  const bool dev_unclip = det.device_unclip();
+  bool dev_unclip = det.device_unclip();   // (the host-built job list below decides per call: a handful of polygons per pool thread is faster on the host)
   const UnclipParams up{prm.box_thresh, prm.unclip_ratio, prm.min_size};
   // a device-settled or host-finished candidate into its image's lists
   auto take = [&](PerImage& r, int st, const uint32_t* o, int olen, const std::vector<geom::Pt>& c, double score, int b) {
@@ -346,6 +346,9 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   }
   first_job[todo.size()] = (int)jobs.size();
   const int nj = (int)jobs.size();
+  // The unclip kernel is lane-serial: about 0.2 ms however few polygons it gets, against 6 us per polygon and pool thread on the host -
+  // it takes the list when there are more than 40 polygons per thread (32 text maps of three polygons with 16 threads: host; with one: device)
+  if (dev_unclip && !det.device_unclip_always() && nj <= 40 * det.post_threads()) dev_unclip = false;
   // unclip on the device behind the box score (unclip.hip): per candidate a status, and for the ones it settles the adjusted polygon.
   // Job list up and results down through the handle's pinned buffer (asynchronous copies, one wait)
   const double *sums = nullptr, *counts = nullptr;

@@ -269,7 +269,10 @@ void Detector::parse_options(const char* options) {
     else if (key == "post_priority") post_priority_ = num() != 0;
     else if (key == "head_cus_yield") head_cus_yield_ = num() != 0;
     else if (key == "transform_fuse") transform_fuse_ = num() != 0;
-    else if (key == "device_unclip") device_unclip_ = num() != 0;
+    else if (key == "device_unclip") {
+      device_unclip_ = num();
+      if (device_unclip_ < 0 || device_unclip_ > 2) fail(OCR_ERR_INVALID, "detector option device_unclip: %d (0, 1 or 2)", device_unclip_);
+    }
     else if (key == "device_polygons") device_polygons_ = num() != 0;
     else if (key == "mfma") {
       if (val == "split_bf16") split_bf16_ = true;
@@ -644,10 +647,10 @@ ThreadPool& Detector::pool() {
 static hipStream_t make_side_stream(bool high_priority) {
   hipStream_t s = nullptr;
   int lo = 0, hi = 0;
-  if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
-    OCR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+  if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess)
     return s;
-  }
+  (void)hipGetLastError();   // (no priorities on this device / runtime: an ordinary stream)
   OCR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   return s;
 }

@@ -98,7 +98,8 @@ class Detector {
   int device_contours() const;   // 0 off, 1 parallel form, 2 one wave per image; option auto (default) = 1 when the pool has at most two threads
   // unclip (score threshold, miter offset, simple-ring union, min-size test, adjustment) on the device behind the box score
   // (unclip.hip; option device_unclip=0 keeps all of it on the host pool)
-  bool device_unclip() const { return device_unclip_; }
+  bool device_unclip() const { return device_unclip_ != 0; }
+  bool device_unclip_always() const { return device_unclip_ == 2; }   // option device_unclip=2: also for a handful of polygons (tests)
   // with device contours: Douglas-Peucker and the box-score job list on the device too (candidates.hip; option device_polygons=0
   // brings the contours back and leaves them to the host pool)
   bool device_polygons() const { return device_polygons_; }
@@ -249,7 +250,7 @@ class Detector {
   hipEvent_t ev_before_fwd_ = nullptr;
   int post_threads_ = 0;   // option post_threads: 0 = automatic
   int device_contours_ = -1;  // option device_contours (-1 = auto)
-  bool device_unclip_ = true; // option device_unclip
+  int device_unclip_ = 1;     // option device_unclip: 0 host, 1 device where it pays (default), 2 device always
   bool device_polygons_ = true;   // option device_polygons
   bool head_cus_yield_ = true;    // option head_cus_yield: layer1's persistent grids leave the previous batch's tracer its CUs (pipelined calls)
   bool post_priority_ = true;     // option post_priority: post-processing / trace streams at the device's highest stream priority

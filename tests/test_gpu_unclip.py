@@ -182,7 +182,7 @@ def _post(det, maps, adj, **kw):
 
 def test_postprocess_is_the_same_with_and_without_the_device_unclip():
     blob = W.pack_blob(W.make_det_weights(0))
-    dev = capi.Detector(blob, 0, options="device_unclip=1")
+    dev = capi.Detector(blob, 0, options="device_unclip=2")
     host = capi.Detector(blob, 0, options="device_unclip=0")
     rng = np.random.default_rng(5)
     noise = (rng.random((2, 1, 320, 320)) * 0.95).astype(np.float32)
@@ -214,7 +214,7 @@ def test_reference_known_answer_through_the_device_unclip(golden_dir):
     import os
     img = np.array(Image.open(os.path.join(golden_dir, "gt_shrinked_img55.png")).convert("L"))
     pred = (img.astype(np.float64) / 255.0).astype(np.float32).reshape(1, 1, 800, 800)
-    d = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0, options="device_unclip=1")
+    d = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0, options="device_unclip=2")
     polys, scores = d.postprocess(pred, 1, 800, 800, np.array([[1.0, 1.0]]))
     assert polys[0] == K.IMG55_POLYS_ADJ1 and scores[0] == K.IMG55_SCORES
     polys, scores = d.postprocess(pred, 1, 800, 800, np.array([[2.0, 2.0]]))
@@ -262,7 +262,7 @@ def test_random_maps_give_the_same_polygons_wherever_the_chain_runs():
     blob = W.pack_blob(W.make_det_weights(0))
     host = capi.Detector(blob, 0, options="device_contours=0;device_unclip=0")
     chain = capi.Detector(blob, 0, options="device_contours=1")
-    unclip = capi.Detector(blob, 0, options="device_contours=0;device_unclip=1")
+    unclip = capi.Detector(blob, 0, options="device_contours=0;device_unclip=2")
     rng = np.random.default_rng(77)
     params = capi.default_params(skip_degenerate=True)
     total = 0

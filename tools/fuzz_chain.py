@@ -10,7 +10,7 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 blob = W.pack_blob(W.make_det_weights(0))
 host = capi.Detector(blob, 0, options="device_contours=0;device_unclip=0;post_threads=8")
 dev = capi.Detector(blob, 0, options="device_contours=1;post_threads=2")
-dev2 = capi.Detector(blob, 0, options="device_contours=0;device_unclip=1;post_threads=2")
+dev2 = capi.Detector(blob, 0, options="device_contours=0;device_unclip=2;post_threads=2")
 rng = np.random.default_rng(2026)
 params = capi.default_params(skip_degenerate=True)
 tot = bad = 0
