@@ -267,6 +267,7 @@ void Detector::parse_options(const char* options) {
       }
     }
     else if (key == "post_priority") post_priority_ = num() != 0;
+    else if (key == "side_priority") side_priority_ = num();
     else if (key == "head_cus_yield") head_cus_yield_ = num() != 0;
     else if (key == "transform_fuse") transform_fuse_ = num() != 0;
     else if (key == "device_unclip") {
@@ -298,7 +299,15 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     OCR_HIP(hipGetDeviceProperties(&prop, device));
     num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (overlap_) {
-      OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+      {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent (numerically largest), hi = most urgent
+        const int pr = side_priority_ < 0 ? lo : side_priority_ > 0 ? hi : 0;
+        if (side_priority_ == 0 || hipStreamCreateWithPriority(&side_stream_, hipStreamNonBlocking, pr) != hipSuccess) {
+          (void)hipGetLastError();
+          OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+        }
+      }
       OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x3_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));

@@ -253,6 +253,8 @@ class Detector {
   int device_unclip_ = 1;     // option device_unclip: 0 host, 1 device where it pays (default), 2 device always
   bool device_polygons_ = true;   // option device_polygons
   bool head_cus_yield_ = true;    // option head_cus_yield: layer1's persistent grids leave the previous batch's tracer its CUs (pipelined calls)
+  int side_priority_ = -1;        // option side_priority: the side stream of overlap=1..3 at the device's least urgent priority (-1, default: the main stream's
+                                  // launches are the critical path and get the CUs first, the side work fills in: -0.7 % of the f32 step), 0 default, 1 most urgent
   bool post_priority_ = true;     // option post_priority: post-processing / trace streams at the device's highest stream priority
 };
 
