@@ -308,6 +308,7 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
           OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
         }
       }
+      OCR_HIP(hipEventCreateWithFlags(&ev_x1_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x3_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
@@ -563,6 +564,7 @@ Detector::~Detector() {
   if (side_stream_) {
     (void)hipStreamSynchronize(side_stream_);
     (void)hipStreamDestroy(side_stream_);
+    (void)hipEventDestroy(ev_x1_);
     (void)hipEventDestroy(ev_x2_);
     (void)hipEventDestroy(ev_x3_);
     (void)hipEventDestroy(ev_side_);
@@ -1135,17 +1137,22 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     }
     cur = x_[l];
     if (l == 0) grid_cus = num_cus_;   // (the tracer of the previous batch is done by now: 1.1 ms against stem + layer1 = 1.1 ms f32)
-    if (overlap3 && l == 1) {
-      // x_[0] and x_[1] are ready: the lateral terms of p2 / p3 (fused Winograd: f32 matrix instructions, latency-bound at two waves per
-      // SIMD), p2's upsampled term on top and bin_conv1's p2 term (into layer1's free temporary) go to the side stream and run beside
-      // layer3 / layer4 / the small FPN convs (split-bf16 GEMMs, transforms): the two families leave each other issue slots and idle
-      // CUs.  Sums are re-associated (lateral + upsampled instead of upsampled + lateral: the same bits;
-      // pyramid + bias + p2 term instead of p2 term + bias + pyramid: one rounding apart)
+    if (overlap3 && l == 0) {
+      // Side stream (least urgent priority), from here to bin_conv1: the FPN's fused-Winograd launches and bin_conv1's p2 term - f32 matrix
+      // instructions, latency-bound at two waves per SIMD - beside layer2 / layer3 / layer4 / the small FPN convs (split-bf16 GEMMs, HBM-bound
+      // transforms): the two families leave each other issue slots and idle CUs.  p2's lateral term only needs
+      // layer1's output; its upsampled term, bin_conv1's p2 term (into layer1's free temporary) and p3's lateral term follow layer2, p3's
+      // upsampled term layer3.  Sums are re-associated (lateral + upsampled instead of upsampled + lateral: the same bits; pyramid + bias + p2
+      // term instead of p2 term + bias + pyramid: one rounding apart)
+      OCR_HIP(hipEventRecord(ev_x1_, stream_));
+      OCR_HIP(hipStreamWaitEvent(side_stream_, ev_x1_, 0));
+      cs = side_stream_;
+      conv3x3("fpn.lateral", fpn_a_[0], x_[0], h4, w4, p_[0], nullptr, false);
+      cs = stream_;
+    } else if (overlap3 && l == 1) {
       OCR_HIP(hipEventRecord(ev_x2_, stream_));
       OCR_HIP(hipStreamWaitEvent(side_stream_, ev_x2_, 0));
       cs = side_stream_;
-      conv3x3("fpn.lateral", fpn_a_[0], x_[0], h4, w4, p_[0], nullptr, false);
-      conv3x3("fpn.lateral", fpn_a_[1], x_[1], h >> 3, w >> 3, p_[1], nullptr, false);
       {
         Extra up;
         up.store = STORE_PHASE;
@@ -1157,6 +1164,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
         p2.bias = nullptr;
         conv3x3("bin_conv1.p2", p2, p_[0], h4, w4, t_[0], nullptr, false);
       }
+      conv3x3("fpn.lateral", fpn_a_[1], x_[1], h >> 3, w >> 3, p_[1], nullptr, false);
       cs = stream_;
     } else if (overlap3 && l == 2) {
       OCR_HIP(hipEventRecord(ev_x3_, stream_));

@@ -158,7 +158,7 @@ class Detector {
   int w43_side_cus_ = 0;   // ... of the fused Winograd launches that go to the side stream (overlap >= 2): room for the main stream's workgroups beside them
   int w43_cus_ = 0;        // option w43_cus (tuning): size the fused Winograd kernels' persistent grids for this many CUs (0 = the device's)
   hipStream_t side_stream_ = nullptr;
-  hipEvent_t ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_x1_ = nullptr, ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena arena_;
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
   std::vector<float> stem_w_host_;  // conv1 [64][49], kept for the bf16 fragments
