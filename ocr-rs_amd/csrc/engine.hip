@@ -7,6 +7,10 @@
 
 #include "engine.hpp"
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include <thread>
 
 #include "thread_pool.hpp"
@@ -214,6 +218,44 @@ ConvW Detector::compose_upsampled(const ConvW& out, const ConvW& in_up) {
 
 // "key=value;key=value" -> engine options (include/ocr_amd.h, ocr_det_create_with_options).  The environment is
 // never consulted: which schedule runs is the caller's explicit choice.
+
+// ---- process-wide stream cache.  The runtime maps streams onto a few hardware queues per priority and RECYCLES the queues of destroyed
+// streams: a handle created after others had been destroyed could get, for its "default priority" side stream, a hardware queue that
+// still carried another priority - its side work then ran ahead of the main stream's critical path and the step took 5.8 ms instead of
+// 4.6 (rocprofv3 kernel trace, tools/pipe_options.py).  So a handle's streams are never destroyed: they are parked by (device, role,
+// priority) and the next handle of the process takes exactly the same ones - every handle sees the queue layout of the first.
+namespace {
+std::mutex g_stream_mu;
+std::map<std::tuple<int, int, int>, std::vector<hipStream_t>> g_parked_streams;
+enum StreamRole { ROLE_OWN = 0, ROLE_SIDE, ROLE_POST, ROLE_TRACE, ROLE_COPY, ROLE_OUT, ROLE_REC };
+
+hipStream_t acquire_stream(int device, int role, int prio) {   // prio: -1 least urgent, 0 default, 1 most urgent
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto& v = g_parked_streams[std::make_tuple(device, role, prio)];
+    if (!v.empty()) {
+      hipStream_t s = v.back();
+      v.pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  int lo = 0, hi = 0;
+  if (prio != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio < 0 ? lo : hi) == hipSuccess)
+    return s;
+  (void)hipGetLastError();   // (no priorities on this device / runtime: an ordinary stream)
+  OCR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+void park_stream(int device, int role, int prio, hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  g_parked_streams[std::make_tuple(device, role, prio)].push_back(s);
+}
+}  // namespace
+
 void Detector::parse_options(const char* options) {
   if (!options) return;
   std::string s(options);
@@ -292,22 +334,14 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   check_device(device);
   parse_options(options);
   WeightBlob wb(blob, bytes);
-  OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  own_stream_ = acquire_stream(device, ROLE_OWN, 0);
   stream_ = own_stream_;
   {
     hipDeviceProp_t prop;
     OCR_HIP(hipGetDeviceProperties(&prop, device));
     num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (overlap_) {
-      {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent (numerically largest), hi = most urgent
-        const int pr = side_priority_ < 0 ? lo : side_priority_ > 0 ? hi : 0;
-        if (side_priority_ == 0 || hipStreamCreateWithPriority(&side_stream_, hipStreamNonBlocking, pr) != hipSuccess) {
-          (void)hipGetLastError();
-          OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-        }
-      }
+      side_stream_ = acquire_stream(device, ROLE_SIDE, side_priority_ < 0 ? -1 : side_priority_ > 0 ? 1 : 0);
       OCR_HIP(hipEventCreateWithFlags(&ev_x1_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x3_, hipEventDisableTiming));
@@ -562,8 +596,7 @@ Detector::~Detector() {
     (void)hipStreamSynchronize(out_stream_);
   }
   if (side_stream_) {
-    (void)hipStreamSynchronize(side_stream_);
-    (void)hipStreamDestroy(side_stream_);
+    park_stream(device_, ROLE_SIDE, side_priority_ < 0 ? -1 : side_priority_ > 0 ? 1 : 0, side_stream_);
     (void)hipEventDestroy(ev_x1_);
     (void)hipEventDestroy(ev_x2_);
     (void)hipEventDestroy(ev_x3_);
@@ -572,10 +605,9 @@ Detector::~Detector() {
     (void)hipEventDestroy(ev_join_);
   }
   if (post_stream_) {
-    (void)hipStreamSynchronize(post_stream_);
-    (void)hipStreamDestroy(post_stream_);
+    park_stream(device_, ROLE_POST, post_priority_ ? 1 : 0, post_stream_);
   }
-  if (trace_stream_) (void)hipStreamDestroy(trace_stream_);
+  park_stream(device_, ROLE_TRACE, post_priority_ ? 1 : 0, trace_stream_);
   if (trace_done_) (void)hipEventDestroy(trace_done_);
   for (hipEvent_t ev : pipe_ev_)
     if (ev) (void)hipEventDestroy(ev);
@@ -593,12 +625,10 @@ Detector::~Detector() {
     }
   if (ev_before_fwd_) (void)hipEventDestroy(ev_before_fwd_);
   if (copy_stream_) {
-    (void)hipStreamSynchronize(copy_stream_);
-    (void)hipStreamDestroy(copy_stream_);
-    (void)hipStreamSynchronize(out_stream_);
-    (void)hipStreamDestroy(out_stream_);
+    park_stream(device_, ROLE_COPY, 0, copy_stream_);
+    park_stream(device_, ROLE_OUT, 0, out_stream_);
   }
-  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+  park_stream(device_, ROLE_OWN, 0, own_stream_);
 }
 
 // CPU share of this process: its affinity mask (a rank pinned by taskset / numactl), capped by the cgroup quota where there
@@ -655,24 +685,13 @@ ThreadPool& Detector::pool() {
 // the post-processing and trace streams run short latency-bound kernels (tracer, Douglas-Peucker, box scores, unclip) beside the next
 // forward's long ones: at the highest priority the device offers their workgroups are placed as soon as a CU drains instead of queueing
 // behind the forward's (option post_priority=0: default priority)
-static hipStream_t make_side_stream(bool high_priority) {
-  hipStream_t s = nullptr;
-  int lo = 0, hi = 0;
-  if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
-      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess)
-    return s;
-  (void)hipGetLastError();   // (no priorities on this device / runtime: an ordinary stream)
-  OCR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  return s;
-}
-
 hipStream_t Detector::post_stream() {
-  if (!post_stream_) post_stream_ = make_side_stream(post_priority_);
+  if (!post_stream_) post_stream_ = acquire_stream(device_, ROLE_POST, post_priority_ ? 1 : 0);
   return post_stream_;
 }
 
 hipStream_t Detector::trace_stream() {
-  if (!trace_stream_) trace_stream_ = make_side_stream(post_priority_);
+  if (!trace_stream_) trace_stream_ = acquire_stream(device_, ROLE_TRACE, post_priority_ ? 1 : 0);
   return trace_stream_;
 }
 hipEvent_t Detector::trace_done_event() {
@@ -817,6 +836,42 @@ struct Recorder {
 };
 }  // namespace
 
+namespace {
+__global__ void side_probe_spin_kernel(long long ticks) {   // about `ticks` / 100 MHz of one wave; every wave reaches the exit
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void side_probe_noop_kernel() {}
+}  // namespace
+
+// Do the handle's stream and its side stream really run side by side?  The runtime maps streams onto a few hardware queues; two streams
+// that share one execute in submission order, and the overlap schedule then SERIALISES behind cross-stream waits (measured: 5.73 ms per
+// step against 4.77 on one stream and 4.60 side by side).  Which queue a new stream gets depends on every stream the process created
+// before, so it is measured, once per (handle, stream): a 0.2 ms spin on the main stream, an empty launch on the side stream - if the empty
+// launch finishes while the spin still runs, the queues are distinct.  If not, the forward keeps to one stream (overlap=0's schedule).
+bool Detector::side_stream_concurrent() {
+  if (!side_stream_) return false;
+  if (side_checked_for_ == stream_) return side_ok_;
+  side_checked_for_ = stream_;
+  side_ok_ = false;
+  hipEvent_t e1 = nullptr, e2 = nullptr;
+  OCR_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  OCR_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+  {
+    hipLaunchKernelGGL(side_probe_spin_kernel, dim3(1), dim3(64), 0, stream_, 20000ll);
+    OCR_HIP(hipEventRecord(e1, stream_));
+    hipLaunchKernelGGL(side_probe_noop_kernel, dim3(1), dim3(64), 0, side_stream_);
+    OCR_HIP(hipEventRecord(e2, side_stream_));
+    OCR_HIP(hipEventSynchronize(e2));
+    side_ok_ = hipEventQuery(e1) == hipErrorNotReady;
+    (void)hipGetLastError();
+    OCR_HIP(hipStreamSynchronize(stream_));
+  }
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  return side_ok_;
+}
+
 void Detector::forward(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                        std::vector<ProfileEntry>* prof, int x_u8, hipEvent_t wait_for) {
   if (!x || !prob) fail(OCR_ERR_INVALID, "det_forward: null tensor");
@@ -860,11 +915,12 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   // starts), layer1's launches are sized for the CUs that are free: + 14 % on four launches instead of + 100 %
   const int busy_cus = head_cus_yield_ && pending_.valid && pending_.prechained ? std::min(pending_.n, num_cus_ / 4) : 0;
   int grid_cus = num_cus_ - busy_cus;
-  const bool overlap3 = overlap_ >= 3 && !prof && fpn_composed_ && bin_pyr_on_ && fused_tail_ &&
+  const bool side_ok = overlap_ >= 1 && !prof && side_stream_concurrent();
+  const bool overlap3 = overlap_ >= 3 && side_ok && fpn_composed_ && bin_pyr_on_ && fused_tail_ &&
                         (bf16_ ? (fpn_a_[0].w_bf16_c64 && bin_p2_.w_bf16_c64 && pyr_p2_direct_)
                                : (fpn_a_[0].wino43_fused && fpn_a_[1].wino43_fused && bin_p2_.wino43_fused && !fpn_a_[0].wino43_x3 && split_bf16_));
-  const bool overlap = overlap3 || (overlap_ == 2 && !prof && fpn_composed_ && !bf16_);   // the FPN branch on the side stream, joined before bin_conv1
-  const bool overlap_small = (overlap_ == 1 || overlap_ == 2) && !prof;   // (3: the side stream is the FPN branch's alone)
+  const bool overlap = overlap3 || (overlap_ == 2 && side_ok && fpn_composed_ && !bf16_);   // the FPN branch on the side stream, joined before bin_conv1
+  const bool overlap_small = (overlap_ == 1 || overlap_ == 2) && side_ok;   // (3: the side stream is the FPN branch's alone)
   // run `side_work` on the second stream from this point of the main stream on; join() makes the main stream
   // wait for it
   auto fork = [&](auto&& side_work) {
@@ -1332,8 +1388,8 @@ void Detector::ensure_staging(int set, size_t in_bytes, size_t prob_elems) {
   if (set < 0 || set > 1) fail(OCR_ERR_INTERNAL, "staging set %d", set);
   Staging& st = stage_[set];
   if (!copy_stream_) {
-    OCR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-    OCR_HIP(hipStreamCreateWithFlags(&out_stream_, hipStreamNonBlocking));
+    copy_stream_ = acquire_stream(device_, ROLE_COPY, 0);
+    out_stream_ = acquire_stream(device_, ROLE_OUT, 0);
   }
   if (!st.ev_in[0])
     for (int i = 0; i < 2; ++i) {
@@ -1412,7 +1468,7 @@ void Detector::forward_host(const void* x, int x_u8, int n, int h, int w, float*
 Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(device) {
   check_device(device);
   WeightBlob wb(blob, bytes);
-  OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  own_stream_ = acquire_stream(device, ROLE_REC, 0);
   stream_ = own_stream_;
   arena_.reserve((size_t)8 << 20);
   auto vec = [&](const char* name, std::initializer_list<int> shape) {
@@ -1441,7 +1497,7 @@ Recognizer::~Recognizer() {
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   if (stage_) (void)hipFree(stage_);
   if (feat_) (void)hipFree(feat_);
-  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+  park_stream(device_, ROLE_REC, 0, own_stream_);
 }
 
 void Recognizer::synchronize() {

@@ -158,6 +158,10 @@ class Detector {
   int w43_side_cus_ = 0;   // ... of the fused Winograd launches that go to the side stream (overlap >= 2): room for the main stream's workgroups beside them
   int w43_cus_ = 0;        // option w43_cus (tuning): size the fused Winograd kernels' persistent grids for this many CUs (0 = the device's)
   hipStream_t side_stream_ = nullptr;
+  // measured once per (handle, stream): do stream_ and side_stream_ sit on different hardware queues? (engine.hip::side_stream_concurrent)
+  bool side_stream_concurrent();
+  hipStream_t side_checked_for_ = nullptr;
+  bool side_ok_ = false;
   hipEvent_t ev_x1_ = nullptr, ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena arena_;
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
