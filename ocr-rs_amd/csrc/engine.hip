@@ -336,6 +336,11 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   WeightBlob wb(blob, bytes);
   own_stream_ = acquire_stream(device, ROLE_OWN, 0);
   stream_ = own_stream_;
+  // The priority streams are made NOW, with the handle: a priority stream created after the process already holds a few ordinary ones
+  // gets a hardware queue it shares with one of them (measured: the tracer then runs IN the next forward's queue and the pipelined rate
+  // drops from 6.3 k to 4.8 k frames/s).  They are cached process-wide (acquire_stream), so this costs once.
+  post_stream_ = acquire_stream(device, ROLE_POST, post_priority_ ? 1 : 0);
+  trace_stream_ = acquire_stream(device, ROLE_TRACE, post_priority_ ? 1 : 0);
   {
     hipDeviceProp_t prop;
     OCR_HIP(hipGetDeviceProperties(&prop, device));
@@ -675,7 +680,7 @@ int Detector::post_threads() const {
 // the host tracer beside the device unclip, two threads 6.2 k / 6.0 k against 6.2 k / 5.9 k; bf16 15.2 k / 11.6 k against 9.8 k / 5.1 k and
 // 15.2 k / 11.5 k against 14.9 k / 8.4 k.  From four threads on the host tracer is ahead on text pages (6.5 k against 6.3 k, 15.5 k against
 // 14.9 k): the device tracer's 32 whole-CU workgroups run beside the next forward and cost it 3 - 5 %
-int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 ? 1 : 0); }
+int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 && trace_stream_concurrent() ? 1 : 0); }
 
 ThreadPool& Detector::pool() {
   if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread
@@ -849,27 +854,38 @@ __global__ void side_probe_noop_kernel() {}
 // step against 4.77 on one stream and 4.60 side by side).  Which queue a new stream gets depends on every stream the process created
 // before, so it is measured, once per (handle, stream): a 0.2 ms spin on the main stream, an empty launch on the side stream - if the empty
 // launch finishes while the spin still runs, the queues are distinct.  If not, the forward keeps to one stream (overlap=0's schedule).
+static bool streams_concurrent(hipStream_t main, hipStream_t other) {
+  hipEvent_t e1 = nullptr, e2 = nullptr;
+  OCR_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  OCR_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+  hipLaunchKernelGGL(side_probe_spin_kernel, dim3(1), dim3(64), 0, main, 20000ll);
+  OCR_HIP(hipEventRecord(e1, main));
+  hipLaunchKernelGGL(side_probe_noop_kernel, dim3(1), dim3(64), 0, other);
+  OCR_HIP(hipEventRecord(e2, other));
+  OCR_HIP(hipEventSynchronize(e2));
+  const bool ok = hipEventQuery(e1) == hipErrorNotReady;
+  (void)hipGetLastError();
+  OCR_HIP(hipStreamSynchronize(main));
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  return ok;
+}
+
 bool Detector::side_stream_concurrent() {
   if (!side_stream_) return false;
   if (side_checked_for_ == stream_) return side_ok_;
   side_checked_for_ = stream_;
-  side_ok_ = false;
-  hipEvent_t e1 = nullptr, e2 = nullptr;
-  OCR_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-  OCR_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-  {
-    hipLaunchKernelGGL(side_probe_spin_kernel, dim3(1), dim3(64), 0, stream_, 20000ll);
-    OCR_HIP(hipEventRecord(e1, stream_));
-    hipLaunchKernelGGL(side_probe_noop_kernel, dim3(1), dim3(64), 0, side_stream_);
-    OCR_HIP(hipEventRecord(e2, side_stream_));
-    OCR_HIP(hipEventSynchronize(e2));
-    side_ok_ = hipEventQuery(e1) == hipErrorNotReady;
-    (void)hipGetLastError();
-    OCR_HIP(hipStreamSynchronize(stream_));
-  }
-  (void)hipEventDestroy(e1);
-  (void)hipEventDestroy(e2);
+  side_ok_ = streams_concurrent(stream_, side_stream_);
   return side_ok_;
+}
+
+// ... and the stream the polygon chain is queued on: if it shares the forward's queue, the tracer of batch k runs IN FRONT of the forward of
+// batch k + 2 instead of beside it (4.8 k instead of 6.3 k frames/s): device_contours=auto then keeps to the host tracer
+bool Detector::trace_stream_concurrent() const {
+  if (trace_checked_for_ == stream_) return trace_ok_;
+  trace_checked_for_ = stream_;
+  trace_ok_ = trace_stream_ && streams_concurrent(stream_, trace_stream_);
+  return trace_ok_;
 }
 
 void Detector::forward(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,

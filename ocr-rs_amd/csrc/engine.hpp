@@ -160,6 +160,9 @@ class Detector {
   hipStream_t side_stream_ = nullptr;
   // measured once per (handle, stream): do stream_ and side_stream_ sit on different hardware queues? (engine.hip::side_stream_concurrent)
   bool side_stream_concurrent();
+  bool trace_stream_concurrent() const;
+  mutable hipStream_t trace_checked_for_ = nullptr;
+  mutable bool trace_ok_ = false;
   hipStream_t side_checked_for_ = nullptr;
   bool side_ok_ = false;
   hipEvent_t ev_x1_ = nullptr, ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
