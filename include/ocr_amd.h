@@ -98,7 +98,6 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
  *                               contours either way.  auto: 1 where the host pool (post_threads) has at most two threads, else 0: by
  *                               measurement
- *   side_priority=-1|0|1 (-1)   stream priority of the overlap side stream: least urgent (the main stream's launches are the critical path), default, most urgent
  *   head_cus_yield=0|1   (1)    pipelined calls: while the polygon chain of the previous batch runs (its tracer holds one CU per image), layer1's
  *                               persistent grids are sized for the CUs that are free
  *   post_priority=0|1    (1)    the post-processing / trace streams at the device's highest stream priority: their short kernels are placed as

@@ -7,10 +7,6 @@
 
 #include "engine.hpp"
 
-#include <map>
-#include <mutex>
-#include <tuple>
-
 #include <thread>
 
 #include "thread_pool.hpp"
@@ -218,44 +214,6 @@ ConvW Detector::compose_upsampled(const ConvW& out, const ConvW& in_up) {
 
 // "key=value;key=value" -> engine options (include/ocr_amd.h, ocr_det_create_with_options).  The environment is
 // never consulted: which schedule runs is the caller's explicit choice.
-
-// ---- process-wide stream cache.  The runtime maps streams onto a few hardware queues per priority and RECYCLES the queues of destroyed
-// streams: a handle created after others had been destroyed could get, for its "default priority" side stream, a hardware queue that
-// still carried another priority - its side work then ran ahead of the main stream's critical path and the step took 5.8 ms instead of
-// 4.6 (rocprofv3 kernel trace, tools/pipe_options.py).  So a handle's streams are never destroyed: they are parked by (device, role,
-// priority) and the next handle of the process takes exactly the same ones - every handle sees the queue layout of the first.
-namespace {
-std::mutex g_stream_mu;
-std::map<std::tuple<int, int, int>, std::vector<hipStream_t>> g_parked_streams;
-enum StreamRole { ROLE_OWN = 0, ROLE_SIDE, ROLE_POST, ROLE_TRACE, ROLE_COPY, ROLE_OUT, ROLE_REC };
-
-hipStream_t acquire_stream(int device, int role, int prio) {   // prio: -1 least urgent, 0 default, 1 most urgent
-  {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    auto& v = g_parked_streams[std::make_tuple(device, role, prio)];
-    if (!v.empty()) {
-      hipStream_t s = v.back();
-      v.pop_back();
-      return s;
-    }
-  }
-  hipStream_t s = nullptr;
-  int lo = 0, hi = 0;
-  if (prio != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
-      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio < 0 ? lo : hi) == hipSuccess)
-    return s;
-  (void)hipGetLastError();   // (no priorities on this device / runtime: an ordinary stream)
-  OCR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  return s;
-}
-void park_stream(int device, int role, int prio, hipStream_t s) {
-  if (!s) return;
-  (void)hipStreamSynchronize(s);
-  std::lock_guard<std::mutex> lk(g_stream_mu);
-  g_parked_streams[std::make_tuple(device, role, prio)].push_back(s);
-}
-}  // namespace
-
 void Detector::parse_options(const char* options) {
   if (!options) return;
   std::string s(options);
@@ -309,7 +267,6 @@ void Detector::parse_options(const char* options) {
       }
     }
     else if (key == "post_priority") post_priority_ = num() != 0;
-    else if (key == "side_priority") side_priority_ = num();
     else if (key == "head_cus_yield") head_cus_yield_ = num() != 0;
     else if (key == "transform_fuse") transform_fuse_ = num() != 0;
     else if (key == "device_unclip") {
@@ -334,19 +291,14 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
   check_device(device);
   parse_options(options);
   WeightBlob wb(blob, bytes);
-  own_stream_ = acquire_stream(device, ROLE_OWN, 0);
+  OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-  // The priority streams are made NOW, with the handle: a priority stream created after the process already holds a few ordinary ones
-  // gets a hardware queue it shares with one of them (measured: the tracer then runs IN the next forward's queue and the pipelined rate
-  // drops from 6.3 k to 4.8 k frames/s).  They are cached process-wide (acquire_stream), so this costs once.
-  post_stream_ = acquire_stream(device, ROLE_POST, post_priority_ ? 1 : 0);
-  trace_stream_ = acquire_stream(device, ROLE_TRACE, post_priority_ ? 1 : 0);
   {
     hipDeviceProp_t prop;
     OCR_HIP(hipGetDeviceProperties(&prop, device));
     num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (overlap_) {
-      side_stream_ = acquire_stream(device, ROLE_SIDE, side_priority_ < 0 ? -1 : side_priority_ > 0 ? 1 : 0);
+      OCR_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
       OCR_HIP(hipEventCreateWithFlags(&ev_x1_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x2_, hipEventDisableTiming));
       OCR_HIP(hipEventCreateWithFlags(&ev_x3_, hipEventDisableTiming));
@@ -601,7 +553,8 @@ Detector::~Detector() {
     (void)hipStreamSynchronize(out_stream_);
   }
   if (side_stream_) {
-    park_stream(device_, ROLE_SIDE, side_priority_ < 0 ? -1 : side_priority_ > 0 ? 1 : 0, side_stream_);
+    (void)hipStreamSynchronize(side_stream_);
+    (void)hipStreamDestroy(side_stream_);
     (void)hipEventDestroy(ev_x1_);
     (void)hipEventDestroy(ev_x2_);
     (void)hipEventDestroy(ev_x3_);
@@ -610,9 +563,10 @@ Detector::~Detector() {
     (void)hipEventDestroy(ev_join_);
   }
   if (post_stream_) {
-    park_stream(device_, ROLE_POST, post_priority_ ? 1 : 0, post_stream_);
+    (void)hipStreamSynchronize(post_stream_);
+    (void)hipStreamDestroy(post_stream_);
   }
-  park_stream(device_, ROLE_TRACE, post_priority_ ? 1 : 0, trace_stream_);
+  if (trace_stream_) (void)hipStreamDestroy(trace_stream_);
   if (trace_done_) (void)hipEventDestroy(trace_done_);
   for (hipEvent_t ev : pipe_ev_)
     if (ev) (void)hipEventDestroy(ev);
@@ -630,10 +584,12 @@ Detector::~Detector() {
     }
   if (ev_before_fwd_) (void)hipEventDestroy(ev_before_fwd_);
   if (copy_stream_) {
-    park_stream(device_, ROLE_COPY, 0, copy_stream_);
-    park_stream(device_, ROLE_OUT, 0, out_stream_);
+    (void)hipStreamSynchronize(copy_stream_);
+    (void)hipStreamDestroy(copy_stream_);
+    (void)hipStreamSynchronize(out_stream_);
+    (void)hipStreamDestroy(out_stream_);
   }
-  park_stream(device_, ROLE_OWN, 0, own_stream_);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
 // CPU share of this process: its affinity mask (a rank pinned by taskset / numactl), capped by the cgroup quota where there
@@ -680,7 +636,7 @@ int Detector::post_threads() const {
 // the host tracer beside the device unclip, two threads 6.2 k / 6.0 k against 6.2 k / 5.9 k; bf16 15.2 k / 11.6 k against 9.8 k / 5.1 k and
 // 15.2 k / 11.5 k against 14.9 k / 8.4 k.  From four threads on the host tracer is ahead on text pages (6.5 k against 6.3 k, 15.5 k against
 // 14.9 k): the device tracer's 32 whole-CU workgroups run beside the next forward and cost it 3 - 5 %
-int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 && trace_stream_concurrent() ? 1 : 0); }
+int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 ? 1 : 0); }
 
 ThreadPool& Detector::pool() {
   if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread
@@ -690,13 +646,24 @@ ThreadPool& Detector::pool() {
 // the post-processing and trace streams run short latency-bound kernels (tracer, Douglas-Peucker, box scores, unclip) beside the next
 // forward's long ones: at the highest priority the device offers their workgroups are placed as soon as a CU drains instead of queueing
 // behind the forward's (option post_priority=0: default priority)
+static hipStream_t make_side_stream(bool high_priority) {
+  hipStream_t s = nullptr;
+  int lo = 0, hi = 0;
+  if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess)
+    return s;
+  (void)hipGetLastError();   // (no priorities on this device / runtime: an ordinary stream)
+  OCR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+
 hipStream_t Detector::post_stream() {
-  if (!post_stream_) post_stream_ = acquire_stream(device_, ROLE_POST, post_priority_ ? 1 : 0);
+  if (!post_stream_) post_stream_ = make_side_stream(post_priority_);
   return post_stream_;
 }
 
 hipStream_t Detector::trace_stream() {
-  if (!trace_stream_) trace_stream_ = acquire_stream(device_, ROLE_TRACE, post_priority_ ? 1 : 0);
+  if (!trace_stream_) trace_stream_ = make_side_stream(post_priority_);
   return trace_stream_;
 }
 hipEvent_t Detector::trace_done_event() {
@@ -841,53 +808,6 @@ struct Recorder {
 };
 }  // namespace
 
-namespace {
-__global__ void side_probe_spin_kernel(long long ticks) {   // about `ticks` / 100 MHz of one wave; every wave reaches the exit
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-__global__ void side_probe_noop_kernel() {}
-}  // namespace
-
-// Do the handle's stream and its side stream really run side by side?  The runtime maps streams onto a few hardware queues; two streams
-// that share one execute in submission order, and the overlap schedule then SERIALISES behind cross-stream waits (measured: 5.73 ms per
-// step against 4.77 on one stream and 4.60 side by side).  Which queue a new stream gets depends on every stream the process created
-// before, so it is measured, once per (handle, stream): a 0.2 ms spin on the main stream, an empty launch on the side stream - if the empty
-// launch finishes while the spin still runs, the queues are distinct.  If not, the forward keeps to one stream (overlap=0's schedule).
-static bool streams_concurrent(hipStream_t main, hipStream_t other) {
-  hipEvent_t e1 = nullptr, e2 = nullptr;
-  OCR_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-  OCR_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-  hipLaunchKernelGGL(side_probe_spin_kernel, dim3(1), dim3(64), 0, main, 20000ll);
-  OCR_HIP(hipEventRecord(e1, main));
-  hipLaunchKernelGGL(side_probe_noop_kernel, dim3(1), dim3(64), 0, other);
-  OCR_HIP(hipEventRecord(e2, other));
-  OCR_HIP(hipEventSynchronize(e2));
-  const bool ok = hipEventQuery(e1) == hipErrorNotReady;
-  (void)hipGetLastError();
-  OCR_HIP(hipStreamSynchronize(main));
-  (void)hipEventDestroy(e1);
-  (void)hipEventDestroy(e2);
-  return ok;
-}
-
-bool Detector::side_stream_concurrent() {
-  if (!side_stream_) return false;
-  if (side_checked_for_ == stream_) return side_ok_;
-  side_checked_for_ = stream_;
-  side_ok_ = streams_concurrent(stream_, side_stream_);
-  return side_ok_;
-}
-
-// ... and the stream the polygon chain is queued on: if it shares the forward's queue, the tracer of batch k runs IN FRONT of the forward of
-// batch k + 2 instead of beside it (4.8 k instead of 6.3 k frames/s): device_contours=auto then keeps to the host tracer
-bool Detector::trace_stream_concurrent() const {
-  if (trace_checked_for_ == stream_) return trace_ok_;
-  trace_checked_for_ = stream_;
-  trace_ok_ = trace_stream_ && streams_concurrent(stream_, trace_stream_);
-  return trace_ok_;
-}
-
 void Detector::forward(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                        std::vector<ProfileEntry>* prof, int x_u8, hipEvent_t wait_for) {
   if (!x || !prob) fail(OCR_ERR_INVALID, "det_forward: null tensor");
@@ -931,12 +851,11 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   // starts), layer1's launches are sized for the CUs that are free: + 14 % on four launches instead of + 100 %
   const int busy_cus = head_cus_yield_ && pending_.valid && pending_.prechained ? std::min(pending_.n, num_cus_ / 4) : 0;
   int grid_cus = num_cus_ - busy_cus;
-  const bool side_ok = overlap_ >= 1 && !prof && side_stream_concurrent();
-  const bool overlap3 = overlap_ >= 3 && side_ok && fpn_composed_ && bin_pyr_on_ && fused_tail_ &&
+  const bool overlap3 = overlap_ >= 3 && !prof && fpn_composed_ && bin_pyr_on_ && fused_tail_ &&
                         (bf16_ ? (fpn_a_[0].w_bf16_c64 && bin_p2_.w_bf16_c64 && pyr_p2_direct_)
                                : (fpn_a_[0].wino43_fused && fpn_a_[1].wino43_fused && bin_p2_.wino43_fused && !fpn_a_[0].wino43_x3 && split_bf16_));
-  const bool overlap = overlap3 || (overlap_ == 2 && side_ok && fpn_composed_ && !bf16_);   // the FPN branch on the side stream, joined before bin_conv1
-  const bool overlap_small = (overlap_ == 1 || overlap_ == 2) && side_ok;   // (3: the side stream is the FPN branch's alone)
+  const bool overlap = overlap3 || (overlap_ == 2 && !prof && fpn_composed_ && !bf16_);   // the FPN branch on the side stream, joined before bin_conv1
+  const bool overlap_small = (overlap_ == 1 || overlap_ == 2) && !prof;   // (3: the side stream is the FPN branch's alone)
   // run `side_work` on the second stream from this point of the main stream on; join() makes the main stream
   // wait for it
   auto fork = [&](auto&& side_work) {
@@ -1210,12 +1129,12 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     cur = x_[l];
     if (l == 0) grid_cus = num_cus_;   // (the tracer of the previous batch is done by now: 1.1 ms against stem + layer1 = 1.1 ms f32)
     if (overlap3 && l == 0) {
-      // Side stream (least urgent priority), from here to bin_conv1: the FPN's fused-Winograd launches and bin_conv1's p2 term - f32 matrix
-      // instructions, latency-bound at two waves per SIMD - beside layer2 / layer3 / layer4 / the small FPN convs (split-bf16 GEMMs, HBM-bound
-      // transforms): the two families leave each other issue slots and idle CUs.  p2's lateral term only needs
-      // layer1's output; its upsampled term, bin_conv1's p2 term (into layer1's free temporary) and p3's lateral term follow layer2, p3's
-      // upsampled term layer3.  Sums are re-associated (lateral + upsampled instead of upsampled + lateral: the same bits; pyramid + bias + p2
-      // term instead of p2 term + bias + pyramid: one rounding apart)
+      // Side stream, from here to bin_conv1: the FPN's fused-Winograd launches and bin_conv1's p2 term - f32 matrix instructions,
+      // latency-bound at two waves per SIMD - beside layer2 / layer3 / layer4 / the small FPN convs (split-bf16 GEMMs, HBM-bound transforms):
+      // the two families leave each other issue slots and idle CUs.  p2's lateral term only needs layer1's output;
+      // its upsampled term, bin_conv1's p2 term (into layer1's free temporary) and p3's lateral term follow layer2, p3's upsampled term
+      // layer3.  Sums are re-associated (lateral + upsampled instead of upsampled + lateral: the same bits; pyramid + bias + p2 term instead
+      // of p2 term + bias + pyramid: one rounding apart)
       OCR_HIP(hipEventRecord(ev_x1_, stream_));
       OCR_HIP(hipStreamWaitEvent(side_stream_, ev_x1_, 0));
       cs = side_stream_;
@@ -1404,8 +1323,8 @@ void Detector::ensure_staging(int set, size_t in_bytes, size_t prob_elems) {
   if (set < 0 || set > 1) fail(OCR_ERR_INTERNAL, "staging set %d", set);
   Staging& st = stage_[set];
   if (!copy_stream_) {
-    copy_stream_ = acquire_stream(device_, ROLE_COPY, 0);
-    out_stream_ = acquire_stream(device_, ROLE_OUT, 0);
+    OCR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    OCR_HIP(hipStreamCreateWithFlags(&out_stream_, hipStreamNonBlocking));
   }
   if (!st.ev_in[0])
     for (int i = 0; i < 2; ++i) {
@@ -1484,7 +1403,7 @@ void Detector::forward_host(const void* x, int x_u8, int n, int h, int w, float*
 Recognizer::Recognizer(const void* blob, size_t bytes, int device) : device_(device) {
   check_device(device);
   WeightBlob wb(blob, bytes);
-  own_stream_ = acquire_stream(device, ROLE_REC, 0);
+  OCR_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
   arena_.reserve((size_t)8 << 20);
   auto vec = [&](const char* name, std::initializer_list<int> shape) {
@@ -1513,7 +1432,7 @@ Recognizer::~Recognizer() {
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   if (stage_) (void)hipFree(stage_);
   if (feat_) (void)hipFree(feat_);
-  park_stream(device_, ROLE_REC, 0, own_stream_);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
 void Recognizer::synchronize() {

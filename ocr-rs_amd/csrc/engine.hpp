@@ -158,13 +158,6 @@ class Detector {
   int w43_side_cus_ = 0;   // ... of the fused Winograd launches that go to the side stream (overlap >= 2): room for the main stream's workgroups beside them
   int w43_cus_ = 0;        // option w43_cus (tuning): size the fused Winograd kernels' persistent grids for this many CUs (0 = the device's)
   hipStream_t side_stream_ = nullptr;
-  // measured once per (handle, stream): do stream_ and side_stream_ sit on different hardware queues? (engine.hip::side_stream_concurrent)
-  bool side_stream_concurrent();
-  bool trace_stream_concurrent() const;
-  mutable hipStream_t trace_checked_for_ = nullptr;
-  mutable bool trace_ok_ = false;
-  hipStream_t side_checked_for_ = nullptr;
-  bool side_ok_ = false;
   hipEvent_t ev_x1_ = nullptr, ev_x2_ = nullptr, ev_x3_ = nullptr, ev_side_ = nullptr, ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena arena_;
   float *stem_w_ = nullptr, *stem_scale_ = nullptr, *stem_bias_ = nullptr;
@@ -260,8 +253,6 @@ class Detector {
   int device_unclip_ = 1;     // option device_unclip: 0 host, 1 device where it pays (default), 2 device always
   bool device_polygons_ = true;   // option device_polygons
   bool head_cus_yield_ = true;    // option head_cus_yield: layer1's persistent grids leave the previous batch's tracer its CUs (pipelined calls)
-  int side_priority_ = -1;        // option side_priority: the side stream of overlap=1..3 at the device's least urgent priority (-1, default: the main stream's
-                                  // launches are the critical path and get the CUs first, the side work fills in: -0.7 % of the f32 step), 0 default, 1 most urgent
   bool post_priority_ = true;     // option post_priority: post-processing / trace streams at the device's highest stream priority
 };
 
