@@ -212,3 +212,15 @@ def test_run_based_border_following_matches_the_oracle_on_noise(h, w, density, s
         if len(pts) >= 4:
             want.append([(int(p[0]), int(p[1])) for p in pts])
     assert got == want
+
+
+def test_device_hypot_restatement_is_libm_hypot():
+    """unclip.hip sums a polygon's perimeter with glibc's hypot restated for the device (csrc/hypot_glibc.hpp): geo's euclidean_length calls
+    libm's hypot (/root/reference/src/polygon.rs:27), which differs from sqrt(dx^2 + dy^2) by an ulp on 0.6 % of integer pairs.  Host code
+    only: every integer pair up to 3 000 through both, no mismatch - and sqrt(dx^2 + dy^2) would not pass this."""
+    import ctypes as C
+    L = capi.test_lib()
+    L.ocr_test_hypot_port_mismatches.restype = C.c_longlong
+    assert L.ocr_test_hypot_port_mismatches(3000) == 0
+    import math
+    assert any(math.hypot(a, b) != math.sqrt(a * a + b * b) for a in range(1, 200) for b in range(1, a))
