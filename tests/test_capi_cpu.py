@@ -223,4 +223,7 @@ def test_device_hypot_restatement_is_libm_hypot():
     L.ocr_test_hypot_port_mismatches.restype = C.c_longlong
     assert L.ocr_test_hypot_port_mismatches(3000) == 0
     import math
-    assert any(math.hypot(a, b) != math.sqrt(a * a + b * b) for a in range(1, 200) for b in range(1, a))
+    libm = C.CDLL("libm.so.6")
+    libm.hypot.restype = C.c_double
+    libm.hypot.argtypes = [C.c_double, C.c_double]
+    assert any(libm.hypot(float(a), float(b)) != math.sqrt(a * a + b * b) for a in range(1, 300) for b in range(1, a))
