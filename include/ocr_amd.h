@@ -94,9 +94,9 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               finishes inside the same call; results are bit for bit the host path's (0)
  *   device_contours=auto|0|1|2 (auto)  the contour tracing of ocr_det_postprocess / the pipelined calls on the GPU (contours.hip; maps up to
  *                               640 x 640 - larger ones, and images the kernel gives up on, take the host tracer inside the same call).
- *                               1: plausible border starts walked in parallel, the raster scan only replays the label tests (0.95-1.5 ms
- *                               per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
- *                               contours either way.  auto: 1 where the host pool (post_threads) has at most two threads, else 0: by
+ *                               1: plausible border starts walked in parallel, the raster scan only replays the label tests, a row at a time as
+ *                               word-wide bit arithmetic (0.35-0.5 ms per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
+ *                               contours either way.  auto: 1 where the host pool (post_threads) has at most four threads, else 0: by
  *                               measurement
  *   head_cus_yield=0|1   (1)    pipelined calls: while the polygon chain of the previous batch runs (its tracer holds one CU per image), layer1's
  *                               persistent grids are sized for the CUs that are free

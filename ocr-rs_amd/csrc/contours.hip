@@ -397,53 +397,69 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
   uint32_t* pts = pts_all + (size_t)img * cap;
   int* starts = starts_all + (size_t)img * (maxc + 1);
   int ncont = 0, npts = 0, ka = 0;
-  auto fg = [&](unsigned i) -> unsigned { return (bits[i >> 5] >> (i & 31)) & 1u; };
   const int wr = w >> 5;
   for (int y = 0; y < h && !status; ++y) {
-    uint32_t cand = 0;
+    // A pixel can start a border only at the first pixel of a run (outer border: label still clear, W neighbour zero) or at its last
+    // (hole border: not negative, E neighbour zero).  Both tests are word-wide bit arithmetic on the row's foreground, `seen` and `neg`
+    // words, one word per lane: the scan only stops at pixels that DO start a border (a few dozen per image) instead of stepping through
+    // every run boundary (a few thousand, five dependent LDS reads each: that walk was most of the kernel).  A border traced in this row
+    // changes the labels of pixels further right, so the masks are rebuilt after every trace, for x beyond it.
+    uint32_t rs = 0, re = 0;
+    const size_t rw = (size_t)y * wr + lane;
     if (lane < wr) {
       const uint32_t* row = bits + (size_t)y * wr;
       const uint32_t cur = row[lane];
       const uint32_t lbit = lane > 0 ? row[lane - 1] >> 31 : 0u;
       const uint32_t rbit = lane + 1 < wr ? row[lane + 1] & 1u : 0u;
-      cand = (cur & ~((cur << 1) | lbit)) | (cur & ~((cur >> 1) | (rbit << 31)));
+      rs = cur & ~((cur << 1) | lbit);            // first pixels of runs
+      re = cur & ~((cur >> 1) | (rbit << 31));    // last pixels of runs
+      if (lane == 0) rs &= ~1u;                   // x > 0
+      if (lane == wr - 1) re &= ~(1u << 31);      // x + 1 < w
     }
-    unsigned long long words = __ballot(cand != 0);
-    while (words && !status) {
-      const int wi = uni(__builtin_ctzll(words));
-      words &= words - 1;
-      uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, wi);
-      while (c && !status) {
-        const int x = wi * 32 + uni(__builtin_ctz(c));
-        c &= c - 1;
-        const unsigned i = (unsigned)y * w + x;
-        const unsigned sb = uni((int)((seen[i >> 5] >> (i & 31)) & 1u)), nb = uni((int)((neg[i >> 5] >> (i & 31)) & 1u));
-        int type = -1;
-        if (!sb && x > 0 && !uni((int)fg(i - 1))) type = 0;
-        else if (!nb && x + 1 < w && !uni((int)fg(i + 1))) type = 1;
-        if (type < 0) continue;
-        const int key = 2 * (int)i + type;
-        while (ka < K && uni(keys[ka]) < key) ++ka;
-        if (ka >= K || uni(keys[ka]) != key) {   // a start the list does not hold: this image goes to the host tracer
-          status = 3;
-          break;
-        }
-        const int len = uni(rlen[ka]), off = uni(roff[ka]);
-        if (ncont >= maxc || npts + len > cap) {
-          status = 1;
-          break;
-        }
-        if (lane == 0) starts[ncont] = npts;
-        ++ncont;
-        for (int q = lane; q < len; q += 64) {
-          const uint32_t p = pool[off + q];
-          const unsigned pi = ((p >> 16) & 0x7fffu) * (unsigned)w + (p & 0xffffu);
-          atomicOr(const_cast<uint32_t*>(seen) + (pi >> 5), 1u << (pi & 31));
-          if (p >> 31) atomicOr(const_cast<uint32_t*>(neg) + (pi >> 5), 1u << (pi & 31));
-          pts[npts + q] = p & 0x7fffffffu;
-        }
-        npts += len;
+    if (!__ballot((rs | re) != 0)) continue;
+    int xmin = 0;
+    while (!status) {
+      uint32_t t0 = 0, t1 = 0;
+      if (lane < wr) {
+        const uint32_t sw = seen[rw], ng = neg[rw];
+        t0 = rs & ~sw;                            // value == 1 and the W neighbour is zero: outer border start
+        t1 = re & ~ng & ~t0;                      // else value > 0 and the E neighbour is zero: hole border start
+        const int lo = xmin - 32 * lane;          // only pixels at or beyond xmin
+        const uint32_t keep = lo <= 0 ? ~0u : lo >= 32 ? 0u : ~0u << lo;
+        t0 &= keep;
+        t1 &= keep;
       }
+      const unsigned long long words = __ballot((t0 | t1) != 0);
+      if (!words) break;
+      const int wi = uni(__builtin_ctzll(words));
+      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, wi), c1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, wi);
+      const int bit = uni(__builtin_ctz(c0 | c1));
+      const int x = wi * 32 + bit;
+      const int type = (c0 >> bit) & 1u ? 0 : 1;
+      xmin = x + 1;
+      const unsigned i = (unsigned)y * w + x;
+      const int key = 2 * (int)i + type;
+      while (ka < K && uni(keys[ka]) < key) ++ka;
+      if (ka >= K || uni(keys[ka]) != key) {   // a start the list does not hold: this image goes to the host tracer
+        status = 3;
+        break;
+      }
+      const int len = uni(rlen[ka]), off = uni(roff[ka]);
+      if (ncont >= maxc || npts + len > cap) {
+        status = 1;
+        break;
+      }
+      if (lane == 0) starts[ncont] = npts;
+      ++ncont;
+      for (int q = lane; q < len; q += 64) {
+        const uint32_t p = pool[off + q];
+        const unsigned pi = ((p >> 16) & 0x7fffu) * (unsigned)w + (p & 0xffffu);
+        atomicOr(const_cast<uint32_t*>(seen) + (pi >> 5), 1u << (pi & 31));
+        if (p >> 31) atomicOr(const_cast<uint32_t*>(neg) + (pi >> 5), 1u << (pi & 31));
+        pts[npts + q] = p & 0x7fffffffu;
+      }
+      npts += len;
+      __builtin_amdgcn_wave_barrier();   // the label ORs of every lane are issued before the masks are read again (LDS serves a wave in order)
     }
   }
   if (lane == 0) {

@@ -631,12 +631,12 @@ int Detector::post_threads() const {
   return auto_threads_;
 }
 
-// auto (the default): the whole polygon chain on the device where the host pool has one or two threads - by measurement (DESIGN.md
-// section 4, tools/device_contours_sweep.py, frames per second on text / dense pages): f32, one thread 6.3 k / 6.0 k against 6.2 k / 4.7 k with
-// the host tracer beside the device unclip, two threads 6.2 k / 6.0 k against 6.2 k / 5.9 k; bf16 15.2 k / 11.6 k against 9.8 k / 5.1 k and
-// 15.2 k / 11.5 k against 14.9 k / 8.4 k.  From four threads on the host tracer is ahead on text pages (6.5 k against 6.3 k, 15.5 k against
-// 14.9 k): the device tracer's 32 whole-CU workgroups run beside the next forward and cost it 3 - 5 %
-int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 2 ? 1 : 0); }
+// auto (the default): the whole polygon chain on the device where the host pool has at most four threads - by measurement (DESIGN.md
+// section 4, tools/device_contours_sweep.py, frames per second on text / dense pages, chain against host tracer + device unclip): f32, one
+// thread 6.2 k / 6.1 k against 6.1 k / 5.0 k, two 6.2 k / 6.1 k against 6.2 k / 6.0 k, four 6.2 k / 6.1 k against 6.3 k / 6.1 k; bf16 15.7 k /
+// 15.0 k against 10.5 k / 5.3 k, 15.6 k / 14.9 k against 15.0 k / 8.2 k, 15.7 k / 15.1 k against 15.7 k / 13.0 k.  With a large pool the host
+// tracer is a few per cent ahead on sparse pages (nothing of the chain then competes with the next forward for CUs)
+int Detector::device_contours() const { return device_contours_ >= 0 ? device_contours_ : (post_threads() <= 4 ? 1 : 0); }
 
 ThreadPool& Detector::pool() {
   if (!pool_) pool_ = std::make_unique<ThreadPool>(post_threads() - 1);  // + the calling thread

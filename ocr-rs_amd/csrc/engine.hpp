@@ -95,7 +95,7 @@ class Detector {
   int post_threads() const;      // host threads of the post-processing stages (option post_threads, default min(16, CPU share))
   // contours on the device (contours.hip)?  option device_contours=1; off by default: a wave follows a border at about the speed of
   // ONE host core per batch (measured), so it pays only where no host core can be spared
-  int device_contours() const;   // 0 off, 1 parallel form, 2 one wave per image; option auto (default) = 1 when the pool has at most two threads
+  int device_contours() const;   // 0 off, 1 parallel form, 2 one wave per image; option auto (default) = 1 when the pool has at most four threads
   // unclip (score threshold, miter offset, simple-ring union, min-size test, adjustment) on the device behind the box score
   // (unclip.hip; option device_unclip=0 keeps all of it on the host pool)
   bool device_unclip() const { return device_unclip_ != 0; }
