@@ -75,6 +75,10 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               F(2x2,3x3) (16 per 4); 0 = F(2x2) everywhere
  *   fpn_unfused=0|1      (0)    1 = layer-by-layer FPN (laterals, top-down sums, out_k, gathered bin_conv1) as model.rs writes it
  *   bin_pyr=0|1          (1)    bin_conv1 over the upsampled concat as one phase-conv launch (0: four launches)
+ *   pyr_grouped=0|1      (1)    bin_conv1's phase launch over p5, p4, p3 (split-bf16 and bf16 kernels): the output phases y mod 8 in {1,2}, {3,4},
+ *                               {5,6} (same along x) read the same source rows - such a block of phases is one 128-column tile that fetches
+ *                               and splits the operand once; the four corner phases are a second, small launch.  0 = one 64-column tile per
+ *                               phase.  Bit-identical
  *   pyr_p2_direct=0|1    (1)    bf16 precision only: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv on top of the phase
  *                               launch over p5, p4, p3 (0: all four sources in the phase launch)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches

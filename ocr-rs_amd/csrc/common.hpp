@@ -70,6 +70,8 @@ struct ConvDesc {
   // src_bytes / wgt_bytes cover all of them.  0 or 1 = a single problem.
   int batch;
   int pyr_nsrc;           // SRC_PYR4: 0 / 4 = all four sources, 3 = p5, p4, p3 only (p2's term is computed elsewhere)
+  int pyr_group;          // SRC_PYR4 with x3: 0 = all 64 phases, one 64-column tile each; 1 = the 60 phases that share their operand rows with a
+                          // neighbour, as 128-column tiles of 2 x 2 / 1 x 2 / 2 x 1 phase blocks; 2 = the four corner phases (0 | 7, 0 | 7)
   const void* wgt;
   const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32
   const float* bias;

@@ -132,6 +132,7 @@ struct ConvArgs {
   int batch;    // batched GEMM: number of problems (grid slices along M); 1 otherwise
   int pyr_chunked;  // PYR4 tile order (see the kernel)
   int pyr_nsrc;     // PYR4: 4 = p5, p4, p3, p2; 3 = without p2
+  int pyr_group;    // PYR4, split-bf16: 0 = one tile per phase; 1 = phase blocks as column groups (128-wide tiles); 2 = the four corner phases
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
   int debug;    // builds with -DIGEMM_DEBUG only (ocr_test_set_conv_debug): X3 ablations - 1 no A DMA, 2 no B DMA, 4 no split, 8 no MFMA
 };
@@ -211,9 +212,62 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // (same for columns) - with that phase's pre-summed weights; the up*up phases are consecutive slices of
   // the grid.
   int ph = 0, pa = 0, pb = 0;
-  if constexpr (SRC == SRC_PYR4) {
+  // PYRG (SRC_PYR4, split-bf16, 128 columns): the phases y mod 8 in {1,2}, {3,4}, {5,6} read the SAME source rows of p5, p4 and p3 (their
+  // 3x3 windows cover the same low-res pixels; only the pre-summed weights differ), likewise along x.  Such a block of 2 x 2 (or
+  // 1 x 2, 2 x 1) phases is ONE GEMM with 64 columns per phase: the A operand is fetched and split once for 128 columns instead
+  // of once per 64, and 21 + 4 tiles gather a cell block's sources instead of 64.  Row groups ga = 0..4 <-> y mod 8 = {0}, {1,2},
+  // {3,4}, {5,6}, {7}; a virtual tile is (ga, gb, 128-column half); the four corner phases (64 columns) run as launch kind 2.
+  constexpr bool PYRG = SRC == SRC_PYR4 && BN == 128;   // (the split-bf16 kernel and the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase)
+  [[maybe_unused]] int g_nb = 1, g_half = 0;
+  if constexpr (PYRG) {
+    constexpr int CHS = 2, CH = 1 << CHS;
+    const int nm = p.nblk_m;
+    // tiles of row group ga: [0, 3 nm), [3 nm, 11 nm), [11 nm, 19 nm), [19 nm, 27 nm), [27 nm, 30 nm)
+    int ga = 0, idx = tile_m, cnt = 3;
+    if (tile_m >= 27 * nm) {
+      ga = 4;
+      idx = tile_m - 27 * nm;
+    } else if (tile_m >= 3 * nm) {
+      const int u = (tile_m - 3 * nm) / (8 * nm);
+      ga = 1 + u;
+      idx = tile_m - 3 * nm - u * 8 * nm;
+      cnt = 8;
+    }
+    int v;
+    if ((nm & (CH - 1)) == 0 && p.pyr_chunked) {
+      // order (row group | chunk of CH cell blocks | virtual tile | block in chunk): the tiles of a chunk gather the same source
+      // lines back to back inside one XCD's run
+      const int per = cnt * CH, chunk = idx / per, rem = idx - chunk * per;
+      v = rem >> CHS;
+      tile_m = chunk * CH + (rem & (CH - 1));
+    } else {
+      v = idx / nm;
+      tile_m = idx - v * nm;
+    }
+    int gb;
+    if (cnt == 3) {          // one phase row: the corner columns belong to launch kind 2
+      gb = 1 + v;
+    } else if (v == 0 || v == 7) {
+      gb = v == 0 ? 0 : 4;
+    } else {
+      gb = 1 + ((v - 1) >> 1);
+      g_half = (v - 1) & 1;
+    }
+    pa = ga == 0 ? 0 : 2 * ga - 1;
+    pb = gb == 0 ? 0 : 2 * gb - 1;
+    g_nb = (gb == 0 || gb == 4) ? 1 : 2;
+    g_nb = __builtin_amdgcn_readfirstlane(g_nb);
+    g_half = __builtin_amdgcn_readfirstlane(g_half);
+    ph = pa * 8 + pb;
+  } else if constexpr (SRC == SRC_PYR4) {
     constexpr int CHS = BM == 128 ? 2 : 3, CH = 1 << CHS;   // cell blocks per chunk: 512 cells of the p5 grid
-    if ((p.nblk_m & (CH - 1)) == 0 && p.pyr_chunked) {
+    if (p.pyr_group == 2) {   // the corner phases (0 | 7, 0 | 7), plain order
+      const int c4 = tile_m / p.nblk_m;
+      tile_m -= c4 * p.nblk_m;
+      pa = (c4 >> 1) * 7;
+      pb = (c4 & 1) * 7;
+      ph = pa * 8 + pb;
+    } else if ((p.nblk_m & (CH - 1)) == 0 && p.pyr_chunked) {
       // order (phase row a | chunk of CH cell blocks | phase column b | block in chunk): an XCD's contiguous run of
       // tiles is one phase row; the 8 x CH tiles of a chunk share the source lines they gather (3 MB, L2-sized)
       // and each weight set is used by CH consecutive tiles.  Phase-major order fetched 3.5 GB for 280 MB of sources.
@@ -273,7 +327,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     nt = pyr_taps(0, pa) * nw;
   }
   const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
+  const int n0 = PYRG ? g_half * BN : tile_n * BN;
+  // PYRG: 64-column group q of the block -> its phase (pa + dpa, pb + dpb)
+  [[maybe_unused]] auto group_dpa = [&](int q) { return g_nb == 2 ? q >> 1 : q; };
+  [[maybe_unused]] auto group_dpb = [&](int q) { return g_nb == 2 ? q & 1 : 0; };
 
   // descriptor inputs through readfirstlane: provably wave-uniform, so the descriptors stay in SGPRs however the
   // allocator treats the other kernel arguments (the inline-asm DMA needs them there)
@@ -320,11 +377,24 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     // a DMA instruction fills 16 rows x 64 B of one plane: lane l -> row l >> 2, slot l & 3 holding global chunk
     // slot ^ f(row), f(row) = (row >> 2) & 3 (= (l >> 4) & 3: the wave's rows start at a multiple of 16)
 #pragma unroll
-    for (int i = 0; i < BSUB; ++i)
-      bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + 64 * i + 16 * wave + (lane >> 2)) * wrow * EBW + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    for (int i = 0; i < BSUB; ++i) {
+      int brow = (ph + bz) * p.Cout + n0 + 64 * i;
+      if constexpr (PYRG) {   // weight rows [phase][64]: column group 2 g_half + i is its own phase
+        const int q = 2 * g_half + i;
+        brow = ((pa + group_dpa(q)) * 8 + pb + group_dpb(q)) * 64;
+      }
+      bvoff[i] = (unsigned)((brow + 16 * wave + (lane >> 2)) * wrow * EBW + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    }
   } else {
 #pragma unroll
-    for (int i = 0; i < BI; ++i) bvoff[i] = (unsigned)(((ph + bz) * p.Cout + n0 + r + 32 * i) * wrow * EB + gq * 16);
+    for (int i = 0; i < BI; ++i) {
+      int brow = (ph + bz) * p.Cout + n0 + 32 * i;
+      if constexpr (PYRG) {   // weight rows [phase][64]: column group 2 g_half + (i >> 1) is its own phase
+        const int q = 2 * g_half + (i >> 1);
+        brow = ((pa + group_dpa(q)) * 8 + pb + group_dpb(q)) * 64 + 32 * (i & 1);
+      }
+      bvoff[i] = (unsigned)((brow + r) * wrow * EB + gq * 16);
+    }
   }
   const unsigned plane_bytes = p.wgt_bytes / 3;  // X3: byte distance between the hi / mid / lo planes
 
@@ -528,18 +598,31 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     // PYR4 (three upsampled sources, at most 2 x 2 taps each at a phase): the tap tables of all sources up front, slot
     // 4 s + t = the weight row's tap slot - no table is rebuilt inside the K loop and no source index is dynamic
     constexpr bool PYRX = SRC == SRC_PYR4;
-    unsigned avx[PYRX ? 12 : 1][AI];
+    // per source and row the offset of the window's first pixel (taken modulo 2^32: it may lie before the tensor) and one validity
+    // bit per tap slot; a step's offsets are base + a scalar tap distance, or the out-of-range marker - 16 registers where the
+    // twelve full tap tables took 48 (the 128-column form has to fit two workgroups per CU)
+    unsigned axb[PYRX ? 3 : 1][AI], axv[AI];
     int nts[3] = {0, 0, 0};
     if constexpr (PYRX) {
 #pragma unroll
+      for (int i = 0; i < AI; ++i) axv[i] = 0u;
+#pragma unroll
       for (int s = 0; s < 3; ++s) {
-        nts[s] = pyr_taps(s, pa) * pyr_taps(s, pb);
+        const int ush = 3 - s, u = 1 << ush;
+        const int snw = pyr_taps(s, pb), snh = pyr_taps(s, pa);
+        nts[s] = snh * snw;
+        const int Hs = p.Hin << s, Ws = p.Win << s;
+        const int dy = (pa >> ush) - ((pa & (u - 1)) == 0 ? 1 : 0), dx = (pb >> ush) - ((pb & (u - 1)) == 0 ? 1 : 0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (t < nts[s]) {   // wave-uniform
+        for (int i = 0; i < AI; ++i) {
+          const int ys = (ih0[i] << s) + dy, xs = (iw0[i] << s) + dx;
+          axb[s][i] = (unsigned)((p.src_off[s] + ((abase[i] * Hs + ys) * Ws + xs) * 64) * EB + gq * 16);
 #pragma unroll
-            for (int i = 0; i < AI; ++i) avx[4 * s + t][i] = tap_offset(s, t, i);
+          for (int t = 0; t < 4; ++t) {
+            const int kh = snw == 2 ? t >> 1 : t, kw = t - kh * snw;
+            if (t < nts[s] && (unsigned)(ys + kh) < (unsigned)Hs && (unsigned)(xs + kw) < (unsigned)Ws) axv[i] |= 1u << (4 * s + t);
           }
+        }
       }
     }
     // the step the iterator points at: its A offsets (one static row of the tap table, picked by a wave-uniform switch)
@@ -549,12 +632,14 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     auto select_next = [&] {
       if constexpr (PYRX) {
         const int flat = 4 * it_s + it_t;
+        const int snw = pyr_taps(it_s, pb);
+        const int kh = snw == 2 ? it_t >> 1 : it_t, kw = it_t - kh * snw;
+        const unsigned dist = (unsigned)((kh * (p.Win << it_s) + kw) * 64 * EB);   // scalar
 #pragma unroll
-        for (int t = 0; t < 12; ++t)
-          if (flat == t) {
-#pragma unroll
-            for (int i = 0; i < AI; ++i) cur_av[i] = avx[t][i];
-          }
+        for (int i = 0; i < AI; ++i) {
+          const unsigned b = it_s == 0 ? axb[0][i] : it_s == 1 ? axb[1][i] : axb[2][i];   // wave-uniform selects
+          cur_av[i] = (axv[i] >> flat) & 1u ? b + dist : OOB;
+        }
         cur_soff_a = it_c * ROWB;
         cur_soff_b = (flat * p.Cin) * EBW + it_c * 64;
         const int ntc = it_s == 0 ? nts[0] : it_s == 1 ? nts[1] : nts[2];
@@ -897,6 +982,62 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     return;
   }
 
+  // ---- epilogue of the split-bf16 phase convs: as epilogue B below (tile through LDS, row-major float4 traffic), but every residual
+  // row of the thread is requested BEFORE the tile goes through LDS - all loads in flight under the transpose instead of rounds of
+  // load, wait, store behind it (the 128 x 128 phase-block tile's epilogue was a third of its launch: two workgroups per CU, and
+  // the one in its epilogue multiplies nothing).  Row offsets by magic division per thread: no row table, one barrier less.
+  if constexpr (X3 && STORE == STORE_PHASE) {
+    constexpr int CPR = BN / 4, RPP = 256 / CPR, PASSES = BM / RPP;
+    float* tile = reinterpret_cast<float*>(lds);
+    const int c4 = (tid % CPR) * 4, rr0 = tid / CPR;
+    const int col = n0 + c4;
+    int ch = col;
+    unsigned colb = (unsigned)col * 4u;
+    if constexpr (PYRG) {   // this thread's column group is the phase (pa + dpa, pb + dpb) of the same 64 channels: dpa output rows down, dpb pixels right
+      const int q = col >> 6;
+      ch = col & 63;
+      colb = (unsigned)((group_dpa(q) * (p.Wo << 3) + group_dpb(q)) * 64 + ch) * 4u;
+    }
+    const int ush = p.up_shift;
+    const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)((((unsigned)p.M << (2 * ush)) * (unsigned)p.Cout) * 4u));
+    const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.out), 0, out_bytes, 0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.residual ? p.residual : p.out), 0, p.residual ? out_bytes : 0u, 0x00020000);
+    unsigned ro[PASSES];
+    f32x4 res[PASSES];
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int m = m0 + rr0 + k * RPP;
+      const int n = fast_div(m, p.mg_howo, p.sh_howo);
+      const int rem = m - n * HoWo;
+      const int oh = fast_div(rem, p.mg_wo, p.sh_wo);
+      const int ow = rem - oh * p.Wo;
+      // rows beyond M get an out-of-range offset: loads return zeros, stores are dropped by the hardware
+      ro[k] = m < p.M ? (unsigned)(((((n * p.Ho + oh) << ush) + pa) * (p.Wo << ush) + (ow << ush) + pb) * p.Cout) * 4u + colb : OOB;
+      res[k] = Elem<float>::bload4(r_rsrc, ro[k]);   // (no residual: an empty descriptor, zeros)
+    }
+    __syncthreads();              // every wave is done reading the last operand stage
+    {
+      const int colq = lane & 31, rowq = (lane >> 5) * 4;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[(wm * WM + (e & 3) + 8 * (e >> 2) + rowq) * BN + j * 32 + colq] = acc[0][j][e];
+    }
+    __syncthreads();
+    const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 bi = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&tile[(rr0 + k * RPP) * BN + c4]) * sc + bi + res[k];
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      Elem<float>::bstore4(o_rsrc, ro[k], v);
+    }
+    return;
+  }
+
   // ---- epilogue B (HBM-bound launches: lateral + top-down sum, transposed conv; every bf16 output).  The accumulator
   // tile goes through LDS (the operand stages are free now) so that global traffic is row-major
   // float4: a wave touches 512 contiguous bytes of one pixel row per instruction.  Per-row index
@@ -945,8 +1086,9 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   }
   __syncthreads();
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = zero4;
-  if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-  if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + col);
+  const int ch = PYRG ? col & 63 : col;   // PYRG: the block's column groups are phases of the same 64 channels
+  if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ch);
+  if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + ch);
   if constexpr (STORE == STORE_PHASE || STORE == STORE_NHWC) {
     if (!p.out2) {
       // plain and phase stores (f32 or bf16): buffer loads / stores at (row offset + column) - rows beyond M lie outside the
@@ -957,7 +1099,12 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(out_elems * ES));
       const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.out), 0, out_bytes, 0x00020000);
       const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.residual ? p.residual : p.out), 0, p.residual ? out_bytes : 0u, 0x00020000);
-      const unsigned colb = (unsigned)col * ES, rowb = (unsigned)p.Cout * ES;
+      unsigned colb = (unsigned)col * ES;
+      [[maybe_unused]] const unsigned rowb = (unsigned)p.Cout * ES;
+      if constexpr (PYRG) {   // this thread's column group is the phase (pa + dpa, pb + dpb): dpa output rows down, dpb pixels right
+        const int q = col >> 6;
+        colb = (unsigned)((group_dpa(q) * (p.Wo << 3) + group_dpb(q)) * 64 + ch) * ES;
+      }
       auto rows = [&](auto relu_c) {
         constexpr int G = PASSES < 4 ? PASSES : 4;
 #pragma unroll
@@ -1076,8 +1223,13 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.batch = d.batch > 1 ? d.batch : 1;
   a.pyr_chunked = 1;
   a.pyr_nsrc = d.pyr_nsrc == 3 ? 3 : 4;
+  a.pyr_group = d.pyr_group;
   a.debug = g_conv_debug;
   a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
+  if (SRC == SRC_PYR4 && d.pyr_group) {   // 30 virtual tiles of 128 columns per cell block (60 phases), or the four corner phases
+    a.nblk_n = 1;
+    a.nblk = a.nblk_m * (d.pyr_group == 1 ? 30 : 4);
+  }
   make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
   make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
   hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE, X3>), dim3(a.nblk), dim3(256), 0, s, a);
@@ -1094,6 +1246,8 @@ static void check(const ConvDesc& d) {
   const int bk = 128 / eb;
   // x3: f32 activations, weights as three bf16 planes (hi, mid, lo) of the f32 layout -> 6 bytes per weight
   const int ebw = d.x3 ? 6 : eb;
+  if (d.pyr_group && (d.pyr_group < 0 || d.pyr_group > 2 || !(d.x3 || d.in_bf16) || d.src_mode != SRC_PYR4 || d.pyr_nsrc != 3))
+    fail(OCR_ERR_INVALID, "%s: phase blocks (pyr_group %d) exist for the split-bf16 and bf16 PYR4 forms over p5, p4, p3", d.name, d.pyr_group);
   if (d.x3 && d.src_mode == SRC_PYR4 && d.pyr_nsrc != 3) fail(OCR_ERR_INVALID, "%s: the split-bf16 PYR4 form takes the three upsampled sources only", d.name);
   if (d.x3 && (d.in_bf16 || d.out_bf16 || d.src_mode == SRC_CAT4 || d.store_mode == STORE_SHUFFLE2))
     fail(OCR_ERR_INVALID, "%s: the split-bf16 form exists for f32 PLAIN / PYR4 convs with NHWC or PHASE stores", d.name);
@@ -1183,7 +1337,8 @@ static Tile pick_tile(const ConvDesc& d) {
     (void)reps;
     // 128 x 128 wherever Cout allows it, however few tiles that leaves (measured on every launch shape of the detector,
     // tools/profile_layers.py with the tile override: operand DMA per MFMA is what the wide tile saves)
-    if (g_tile_override == 2 || d.Cout % 128 || d.src_mode == SRC_PYR4) return T128x64;
+    if (d.src_mode == SRC_PYR4) return d.pyr_group == 1 ? T128x128 : T128x64;
+    if (g_tile_override == 2 || d.Cout % 128) return T128x64;
     return T128x128;
   }
   if (g_tile_override == 1 && d.Cout % 128 == 0) return T128x128;
@@ -1192,7 +1347,7 @@ static Tile pick_tile(const ConvDesc& d) {
   const long long M = (long long)d.N * d.Ho * d.Wo;
   const int reps = d.store_mode == STORE_PHASE ? d.up * d.up : (d.batch > 1 ? d.batch : 1);
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (d.Cout / bn) * reps; };
-  if (d.src_mode == SRC_PYR4) return T64x64;  // bf16 too: 0.254 vs 0.265 ms with 128x64
+  if (d.src_mode == SRC_PYR4) return d.pyr_group == 1 ? T128x128 : T64x64;  // bf16 too: 0.254 vs 0.265 ms with 128x64
   // bf16 3x3: the wide tile from 256 input channels on, and for every stride-2 conv (0.070 -> 0.064, 0.052 -> 0.046 ms at layer2 / layer3)
   if (d.in_bf16 && d.ks > 1) return (d.Cout % 128 == 0 && (d.Cin >= 256 || d.stride == 2)) ? T128x128 : T128x64;
   if ((d.ks > 1 || d.batch > 1) && d.src_mode == SRC_PLAIN) return T64x64;
@@ -1266,6 +1421,7 @@ static void launch_x3(const ConvDesc& d, hipStream_t s) {
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
   if (d.x3) {
+    if (d.src_mode == SRC_PYR4 && d.pyr_group == 1) return launch_inst<float, float, 128, 128, 3, 1, SRC_PYR4, STORE_PHASE, true>(d, s);
     if (d.src_mode == SRC_PYR4) return launch_inst<float, float, 128, 64, 3, 1, SRC_PYR4, STORE_PHASE, true>(d, s);
     if (d.store_mode == STORE_PHASE) return launch_x3<2, 1, SRC_PLAIN, STORE_PHASE>(d, s);
     if (d.ks == 3 && d.stride == 1) return launch_x3<3, 1, SRC_PLAIN, STORE_NHWC>(d, s);
@@ -1275,6 +1431,8 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
     fail(OCR_ERR_INVALID, "%s: no split-bf16 conv_igemm variant for ks=%d stride=%d", d.name, d.ks, d.stride);
   }
   if (d.in_bf16) {
+    if (d.src_mode == SRC_PYR4 && d.pyr_group == 1 && !d.out_bf16) return launch_inst<__bf16, float, 128, 128, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
+    if (d.src_mode == SRC_PYR4 && d.pyr_group == 1) return launch_inst<__bf16, __bf16, 128, 128, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
     if (d.src_mode == SRC_PYR4 && !d.out_bf16) return launch_inst<__bf16, float, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
     if (d.src_mode == SRC_PYR4) return launch_inst<__bf16, __bf16, 64, 64, 3, 1, SRC_PYR4, STORE_PHASE>(d, s);
     if (d.store_mode == STORE_PHASE && !d.out_bf16) return launch_tiles<__bf16, float, 2, 1, SRC_PLAIN, STORE_PHASE>(d, s);

@@ -245,6 +245,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "fpn_unfused") fpn_composed_ = num() == 0;
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
     else if (key == "pyr_p2_direct") pyr_p2_direct_ = num() != 0;
+    else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") overlap_ = num();
     else if (key == "w43_cus") {
@@ -839,6 +840,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     bool cat4 = false;
     bool pyr4 = false;      // SRC_PYR4: the four pyramid levels as sources of one phase-conv launch
     int pyr_nsrc = 4;       // ... or only the three upsampled ones (3)
+    int pyr_group = 0;      // split-bf16 form: 1 = the phase blocks that share their operand rows as 128-column tiles, 2 = the corner phases
     bool f32_out = false;   // bf16 precision: keep this conv's result (and residual) in f32
     int store = STORE_NHWC;
   };
@@ -876,6 +878,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     // bin_conv1 (the gathered CAT4 conv) feeds the fused head in its own element type: bf16 in the bf16 precision
     d.out_bf16 = (in_bf && !(ex.cat4 && !fused_tail_) && !ex.f32_out) ? 1 : 0;
     d.pyr_nsrc = ex.pyr_nsrc;
+    d.pyr_group = ex.pyr_group;
     d.up = cw.up;
     const size_t ies = in_bf ? 2 : 4;
     d.src[0] = src;
@@ -922,13 +925,15 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     const double reps = ex.store == STORE_PHASE ? (double)(cw.up * cw.up) : 1.0;  // phase convs per low-res pixel
     // taps executed per low-res pixel over all phases: (up + 2)^2 (edge phases 2, inner phases 1 per direction)
     // PYR4 per cell: (8+2)^2 + 4 (4+2)^2 + 16 (2+2)^2 tap-phases of the upsampled levels + 64 * 9 of p2
-    const double K = ex.pyr4 ? 64.0 * (100 + 144 + 256 + (ex.pyr_nsrc == 4 ? 576 : 0))
+    // (phase blocks: the corner phases' 4 x 12 tap-phases are their own launch)
+    const double K = ex.pyr4 ? 64.0 * ((ex.pyr_group == 1 ? 452 : ex.pyr_group == 2 ? 48 : 500) + (ex.pyr_nsrc == 4 ? 576 : 0))
                              : ex.store == STORE_PHASE ? (double)cw.cin * (cw.up + 2) * (cw.up + 2) : (double)cw.ks * cw.ks * cw.cin;
     double in_bytes = (double)n * hin * win * cw.cin * (double)ies;
     if (ex.cat4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 0.25 + 1.0 / 16 + 1.0 / 64);
-    if (ex.pyr4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 4.0 + 16.0 + 64.0);
+    if (ex.pyr4) in_bytes = (double)n * hin * win * 64 * (double)ies * (1.0 + 4.0 + 16.0 + (ex.pyr_nsrc == 4 ? 64.0 : 0.0));
     const double oes = d.out_bf16 ? 2.0 : 4.0;
-    double out_bytes = M * reps * cw.cout * oes * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
+    const double phases = ex.pyr_group == 1 ? 60.0 : ex.pyr_group == 2 ? 4.0 : reps;   // output pixels written per low-res pixel
+    double out_bytes = M * phases * cw.cout * oes * ((out ? 1.0 : 0.0) + (ex.out2 ? 1.0 : 0.0) + (ex.residual ? 1.0 : 0.0) +
                                             (ex.up_residual ? 0.25 : 0.0));
     rec.end(conv_igemm_kernel_name(d), 2.0 * M * cw.cout * K, in_bytes + out_bytes + K * cw.cout * (double)ies);
   };
@@ -1227,11 +1232,26 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     py.pyr4 = true;
     py.store = STORE_PHASE;
     py.f32_out = !bf;  // bf16 precision: the fused head reads bf16
+    // split-bf16 and bf16 forms over p5, p4, p3: the phases that share their operand rows with a neighbour as 128-column tiles of phase
+    // blocks, the four corner phases as a second, small launch (conv_igemm.hip, PYRG)
+    auto pyramid3 = [&](const ConvW& cw, bool relu) {
+      if (((!bf && split_bf16_ && cw.w_x3) || bf) && pyr_grouped_) {
+        // (the two write disjoint phases of b1.  The corner launch - 4 x 100 tiles at 32 x 640 x 640, less than one round of the chip - on
+        // the side stream beside the block launch: the same step, 4.557 / 4.547 against 4.551 / 4.555 ms on one box; not kept)
+        py.pyr_group = 1;
+        conv("bin_conv1.pyramid", cw, p_[3], h >> 5, w >> 5, 1, b1_, relu, py);
+        py.pyr_group = 2;
+        conv("bin_conv1.pyramid.corners", cw, p_[3], h >> 5, w >> 5, 1, b1_, relu, py);
+        py.pyr_group = 0;
+      } else {
+        conv("bin_conv1.pyramid", cw, p_[3], h >> 5, w >> 5, 1, b1_, relu, py);
+      }
+    };
     if (overlap3) {
       // p2's term was computed on the side stream (into t_[0]): the phase launch over p5, p4, p3 adds it, the bias and the ReLU
       py.pyr_nsrc = 3;
       py.residual = t_[0];
-      conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);
+      pyramid3(bin_pyr_, true);
     } else if (bf && bin_p2_.w_bf16_c64 && pyr_p2_direct_) {
       // bf16: the three upsampled sources in the phase launch, p2's 3x3 term on top as the patch-staged 64 -> 64 conv (bias + ReLU
       // there).  p2's nine taps are more than half of the phase launch's gathers (one pixel row per cell, tap and phase - the part
@@ -1239,7 +1259,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       py.pyr_nsrc = 3;
       ConvW up3 = bin_pyr_;
       up3.bias = nullptr;
-      conv("bin_conv1.pyramid", up3, p_[3], h >> 5, w >> 5, 1, b1_, false, py);
+      pyramid3(up3, false);
       ConvW p2 = bin_p2_;
       p2.bias = bin1_.bias;
       conv3x3("bin_conv1.p2", p2, p_[0], h4, w4, b1_, b1_, true);
@@ -1251,7 +1271,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       py.pyr_nsrc = 3;
       ConvW up3 = bin_pyr_;
       up3.bias = nullptr;
-      conv("bin_conv1.pyramid", up3, p_[3], h >> 5, w >> 5, 1, b1_, false, py);
+      pyramid3(up3, false);
       conv3x3("bin_conv1.p2", bin_p2_, p_[0], h4, w4, b1_, b1_, true);
     } else {
       conv("bin_conv1.pyramid", bin_pyr_, p_[3], h >> 5, w >> 5, 1, b1_, true, py);

@@ -386,6 +386,7 @@ def test_stem_exact_and_inexact_tiles(det, det_w):
     "winograd_fused=0",                                            # direct convs on the large grids, unfused Winograd layer3/4
     "winograd=0;winograd_fused=0",                                 # no Winograd at all
     "bin_pyr=0",                                                   # bin_conv1 as four launches
+    "pyr_grouped=0",                                               # bin_conv1 over p5..p3 as one 64-column tile per phase (default: phase blocks)
     "fpn_unfused=1",                                               # layer-by-layer FPN
     "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
     "overlap=1", "overlap=2",                                      # second-stream schedules
@@ -426,6 +427,24 @@ def test_fused_transforms_are_bit_identical(det_w):
         finally:
             a.close()
             b.close()
+
+
+def test_phase_blocks_are_bit_identical(det_w):
+    """bin_conv1 over p5, p4, p3 (conv_igemm.hip, PYRG): phases that read the same source rows are column groups of one 128-wide tile
+    (+ a launch for the four corner phases).  Per output element the same products in the same order as the one-tile-per-phase form:
+    the same map bit for bit - with one cell block (plain tile order), with a partial last cell block in chunked order (400 cells),
+    and on a ragged p5 grid; one stream and the default schedule; the split-bf16
+    kernel and the bf16 kernel."""
+    for (n, h, w) in ((2, 96, 160), (4, 320, 320), (3, 224, 352)):
+        x = W.synth_image_batch(43, n, h, w)
+        for sched in ("overlap=0", "overlap=3", "precision=bf16;overlap=0", "precision=bf16;overlap=3"):
+            a = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";pyr_grouped=1")
+            b = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";pyr_grouped=0")
+            try:
+                assert np.array_equal(a.forward_host(x), b.forward_host(x)), (n, h, w, sched)
+            finally:
+                a.close()
+                b.close()
 
 
 def test_engine_options_are_explicit_and_checked(det_w, monkeypatch):
