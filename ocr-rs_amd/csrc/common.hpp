@@ -54,7 +54,7 @@ struct ConvDesc {
   // f32 conv on the bf16 matrix cores: every f32 operand is the exact sum of three bf16 terms (hi + mid + lo, 3 x 8
   // significant bits); six of the nine partial products (all but mid.lo, lo.mid, lo.lo: <= 2^-23 of the product) are
   // accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Activations stay f32 in HBM and are split in registers; wgt holds
-  // split3_weights() of the f32 layout (three bf16 planes, wgt_bytes = 6 per weight).  f32 PLAIN / PYR4 convs only.
+  // split3_weights_tiled() of the f32 layout (three bf16 planes, wgt_bytes = 6 per weight).  f32 PLAIN / PYR4 convs only.
   int x3;
   const void* src[4];     // PLAIN: src[0]; CAT4: p5,p4,p3,p2 (all inside ONE allocation starting at src_base)
   const void* src_base;   // CAT4: start of the allocation holding the four sources (else unused)
@@ -90,6 +90,10 @@ void launch_conv_igemm(const ConvDesc& d, hipStream_t s);
 // hi / mid / lo bf16 planes of an f32 weight array whose rows are multiples of 16 long ([3][count] bf16; inside every
 // aligned group of 16 the k order is the one the split-bf16 kernel's A fragments have: 0-3, 8-11, 4-7, 12-15)
 std::vector<uint16_t> split3_weights(const float* w, size_t count);
+// ... and the form conv_igemm's split-bf16 kernels read: the same planes cut into blocks of 16 rows x one K-step (32 k, 64 bytes per
+// row), each block stored as the 1 KB LDS image one DMA instruction writes (row r, 16-byte slot s = chunk s ^ ((r >> 2) & 3)), blocks
+// ordered [row / 16][K-step][plane]: `wrow` = weights per row (taps x Cin), rows a multiple of 16
+std::vector<uint16_t> split3_weights_tiled(const float* w, size_t count, int wrow);
 const char* conv_igemm_kernel_name(const ConvDesc& d);
 void set_conv_tile_override(int t);  // tuning aid: 0 = automatic
 void set_conv_debug(int d);          // ablation bits, effective in -DIGEMM_DEBUG builds only

@@ -376,6 +376,11 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   if constexpr (X3) {
     // a DMA instruction fills 16 rows x 64 B of one plane: lane l -> row l >> 2, slot l & 3 holding global chunk
     // slot ^ f(row), f(row) = (row >> 2) & 3 (= (l >> 4) & 3: the wave's rows start at a multiple of 16)
+    // The planes are TILED on the host (split3_weights_tiled): block (16 rows, K-step, plane) = 1 KB in the order of its LDS image
+    // (row r, slot s holding chunk s ^ f(r)), blocks ordered [row / 16][K-step][plane].  A DMA instruction reads 1 KB of
+    // consecutive bytes - eight full cache lines - where the row-major planes gave it sixteen half lines 2 wrow bytes apart (the
+    // other half of each line was fetched again a tap later): the weight stream was a quarter of these kernels' time.
+    const int nK = wrow >> 5;   // K-steps per weight row
 #pragma unroll
     for (int i = 0; i < BSUB; ++i) {
       int brow = (ph + bz) * p.Cout + n0 + 64 * i;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         const int q = 2 * g_half + i;
         brow = ((pa + group_dpa(q)) * 8 + pb + group_dpb(q)) * 64;
       }
-      bvoff[i] = (unsigned)((brow + 16 * wave + (lane >> 2)) * wrow * EBW + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+      bvoff[i] = (unsigned)(((brow >> 4) + wave) * nK * 3072 + lane * 16);
     }
   } else {
 #pragma unroll
@@ -396,7 +401,6 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       bvoff[i] = (unsigned)((brow + r) * wrow * EB + gq * 16);
     }
   }
-  const unsigned plane_bytes = p.wgt_bytes / 3;  // X3: byte distance between the hi / mid / lo planes
 
   // K order.  PLAIN: channel chunk outer, tap inner - the KS*KS taps of one 32-channel chunk
   // touch the same few cache lines of neighbouring pixels back to back (L2 hits), instead of
@@ -459,15 +463,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < AI; ++i)
       if (!IGEMM_DBG(p, 1)) dma16(a_rsrc, st + 32 * i * ROWB, av[i], c * ROWB);
-    if constexpr (X3) {
-      if (IGEMM_DBG(p, 2)) return;
-      const unsigned sb = __builtin_amdgcn_readfirstlane(lds_base - (unsigned)(8 * wave * ROWB) + (unsigned)(stage * STAGE + A_BYTES + 16 * wave * 64));
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int i = 0; i < BSUB; ++i)
-          dma16(b_rsrc, sb + (unsigned)(pl * BN * 64 + i * 64 * 64), bvoff[i], (int)(pl * plane_bytes) + (tap * p.Cin + kbase) * EBW + c * 64);
-    } else {
+    if constexpr (!X3) {   // (the split-bf16 loop has its own DMA schedule)
 #pragma unroll
       for (int i = 0; i < BI; ++i) dma16(b_rsrc, st + (A_ROWS + 32 * i) * ROWB, bvoff[i], (tap * p.Cin + kbase) * EB + c * ROWB);
     }
@@ -641,7 +637,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
           cur_av[i] = (axv[i] >> flat) & 1u ? b + dist : OOB;
         }
         cur_soff_a = it_c * ROWB;
-        cur_soff_b = (flat * p.Cin) * EBW + it_c * 64;
+        cur_soff_b = (flat * pass_chunks + it_c) * 3072;   // K-step (tap slot, chunk) of the tiled planes: 3 x 1 KB
         const int ntc = it_s == 0 ? nts[0] : it_s == 1 ? nts[1] : nts[2];
         if (++it_t == ntc) {
           it_t = 0;
@@ -659,7 +655,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
           for (int i = 0; i < AI; ++i) cur_av[i] = avoff[t][i];
         }
       cur_soff_a = it_c * ROWB;
-      cur_soff_b = (it_t * p.Cin) * EBW + it_c * 64;
+      cur_soff_b = (it_t * csteps + it_c) * 3072;   // K-step (tap, chunk) of the tiled planes: 3 x 1 KB
       if (++it_t == nt) {
         it_t = 0;
         ++it_c;
@@ -675,7 +671,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
         constexpr int pl = (P - AI) / BSUB, i = (P - AI) % BSUB;
         if (!IGEMM_DBG(p, 2))
           dma16(b_rsrc, __builtin_amdgcn_readfirstlane(lds_base - (unsigned)(8 * wave * ROWB) + (unsigned)(stage * STAGE + A_BYTES + 16 * wave * 64 + pl * BN * 64 + i * 64 * 64)),
-                bvoff[i], (int)(pl * plane_bytes) + cur_soff_b);
+                bvoff[i], cur_soff_b + pl * 1024);
       }
     };
     auto dma_all = [&](int stage) {
@@ -1409,6 +1405,24 @@ std::vector<uint16_t> split3_weights(const float* w, size_t count) {
       out[count + g + pos] = m;
       out[2 * count + g + pos] = bf16_rne(r2);
     }
+  return out;
+}
+
+std::vector<uint16_t> split3_weights_tiled(const float* w, size_t count, int wrow) {
+  if (wrow <= 0 || wrow % 32 || count % ((size_t)wrow * 16)) fail(OCR_ERR_INTERNAL, "split3_weights_tiled: %zu weights in rows of %d are not whole blocks of 16 rows x 32", count, wrow);
+  const std::vector<uint16_t> planes = split3_weights(w, count);
+  std::vector<uint16_t> out(3 * count);
+  const size_t rows = count / wrow, nK = wrow / 32;
+  for (size_t r16 = 0; r16 < rows / 16; ++r16)
+    for (size_t ks = 0; ks < nK; ++ks)
+      for (int pl = 0; pl < 3; ++pl) {
+        uint16_t* blk = &out[((r16 * nK + ks) * 3 + pl) * 512];
+        for (int r = 0; r < 16; ++r)
+          for (int sl = 0; sl < 4; ++sl) {
+            const uint16_t* src = &planes[(size_t)pl * count + (r16 * 16 + r) * wrow + ks * 32 + (size_t)((sl ^ ((r >> 2) & 3)) * 8)];
+            for (int e = 0; e < 8; ++e) blk[r * 32 + sl * 8 + e] = src[e];
+          }
+      }
   return out;
 }
 

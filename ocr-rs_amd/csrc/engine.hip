@@ -154,7 +154,7 @@ void Detector::add_winograd_weights(ConvW& cw) {
   const std::vector<float> u = winograd_weights(cw.host.data(), cw.cout, cw.cin, cw.wino_tile);
   cw.wino = arena_.upload(u);
   cw.wino_bytes = u.size() * sizeof(float);
-  if (split_bf16_ && cw.cin % 32 == 0) cw.wino_x3 = arena_.upload_u16(split3_weights(u.data(), u.size()));
+  if (split_bf16_ && cw.cin % 32 == 0) cw.wino_x3 = arena_.upload_u16(split3_weights_tiled(u.data(), u.size(), cw.cin));   // [component][Cout][Cin]
 }
 
 void Detector::add_winograd_fused_weights(ConvW& cw) {
@@ -165,8 +165,9 @@ void Detector::add_winograd_fused_weights(ConvW& cw) {
 }
 
 // hi / mid / lo bf16 planes of a conv's f32 weights (and of its Winograd form): what conv_igemm's split-bf16 kernels read
-void Detector::add_split_weights(ConvW& cw) {
-  if (!cw.host.empty() && !cw.w_x3 && cw.cin % 32 == 0) cw.w_x3 = arena_.upload_u16(split3_weights(cw.host.data(), cw.host.size()));
+void Detector::add_split_weights(ConvW& cw, int wrow) {
+  if (wrow == 0) wrow = cw.ks * cw.ks * cw.cin;   // weights per output channel (phase convs: 2 x 2 taps; bin_conv1 over the pyramid: 21 tap slots)
+  if (!cw.host.empty() && !cw.w_x3 && cw.cin % 32 == 0) cw.w_x3 = arena_.upload_u16(split3_weights_tiled(cw.host.data(), cw.host.size(), wrow));
 }
 
 // A_k = out_k o in_k
@@ -488,9 +489,9 @@ Detector::Detector(const void* blob, size_t bytes, int device, const char* optio
     add_split_weights(in_[2]);    // in4 (1x1, 256 -> 256 at H/16, with the top-down sum as its second output)
     for (int l = 1; l < 4; ++l) add_split_weights(down_[l]);   // the 1x1 stride-2 downsample convs
     if (fpn_composed_) {
-      for (int l = 0; l < 2; ++l) add_split_weights(fpn_b_[l]);       // phase convs of p2 / p3
-      for (int l = 0; l < 3; ++l) add_split_weights(bin_up_[l]);
-      if (bin_pyr_on_) add_split_weights(bin_pyr_);
+      for (int l = 0; l < 2; ++l) add_split_weights(fpn_b_[l], 4 * fpn_b_[l].cin);       // phase convs of p2 / p3: [phase][Cout][2 x 2][Cin]
+      for (int l = 0; l < 3; ++l) add_split_weights(bin_up_[l], 4 * bin_up_[l].cin);
+      if (bin_pyr_on_) add_split_weights(bin_pyr_, 21 * 64);
     }
   }
   if (opt_bf16_) set_precision(1);

@@ -37,7 +37,7 @@ struct ConvW {
   float* w = nullptr;      // [Cout][ks*ks][Cin]
   size_t w_bytes = 0;
   void* w_bf16 = nullptr;  // same layout in bf16 (filled by Detector::set_precision)
-  void* w_x3 = nullptr;    // same layout as three bf16 planes hi / mid / lo (split3_weights): the f32 conv on the bf16 matrix cores
+  void* w_x3 = nullptr;    // the same weights as three bf16 planes hi / mid / lo, tiled for the DMA (split3_weights_tiled): the f32 conv on the bf16 matrix cores
   void* wino_x3 = nullptr; // ... of the Winograd weights `wino`
   void* w_bf16_c64 = nullptr;  // 3x3 64 -> 64 convs: bf16 MFMA fragments for conv3x3_bf16_c64.hip
   std::vector<float> host; // the f32 layout, kept for the bf16 conversion
@@ -206,7 +206,7 @@ class Detector {
   // cores from operands split into three bf16 terms, six partial products, f32 accumulate (conv_igemm.hip, X3): f32-level
   // accuracy (profiles/r03_bf16x3_accuracy.txt) at up to 2.67x the f32 MFMA rate.  f32 keeps every conv on v_mfma_f32_32x32x2_f32.
   bool split_bf16_ = true;
-  void add_split_weights(ConvW& cw);
+  void add_split_weights(ConvW& cw, int wrow = 0);
   ConvW out_[4];          // out2..out5
   ConvW bin1_, tr1_;
   float* tr2_w_ = nullptr;

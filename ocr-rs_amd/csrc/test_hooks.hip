@@ -272,7 +272,7 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
     }
     if (variant == 2) {  // the split-bf16 form of the f32 conv: weights as three bf16 planes
       if (in_bf16 || out_bf16 || cat4) fail(OCR_ERR_INVALID, "variant 2 (split bf16) takes f32 tensors");
-      const std::vector<uint16_t> planes = split3_weights(wgt, w_e);
+      const std::vector<uint16_t> planes = split3_weights_tiled(wgt, w_e, ks * ks * cin);
       void* d_pl = nullptr;
       OCR_HIP(hipMalloc(&d_pl, planes.size() * 2));
       allocs.push_back(d_pl);
@@ -414,7 +414,7 @@ int ocr_test_dual_stream_bench(ocr_det_t* det, int n, int which_b, int w43_cus, 
     d.src_bytes = in_e * 4;
     std::vector<float> hw(w_e);
     for (auto& v : hw) v = 0.05f * rnd();
-    const std::vector<uint16_t> planes = split3_weights(hw.data(), w_e);
+    const std::vector<uint16_t> planes = split3_weights_tiled(hw.data(), w_e, d.ks * d.ks * d.Cin);
     d.wgt = dev_bytes(planes.data(), planes.size() * 2);
     d.wgt_bytes = w_e * 6;
     d.out = dev_bytes(nullptr, out_e * 4);
@@ -576,7 +576,7 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
       std::vector<float> hw(w_e);
       uint32_t st = 777u;
       for (size_t i = 0; i < w_e; ++i) { st = st * 1664525u + 1013904223u; hw[i] = 0.05f * (((st >> 8) & 0xffff) / 32768.0f - 1.0f); }
-      const std::vector<uint16_t> planes = split3_weights(hw.data(), w_e);
+      const std::vector<uint16_t> planes = split3_weights_tiled(hw.data(), w_e, ks * ks * cin);
       OCR_HIP(hipMemcpy(wt, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
     }
     ConvDesc d{};
