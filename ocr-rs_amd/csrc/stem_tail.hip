@@ -156,8 +156,22 @@ __global__ __launch_bounds__(NT) void stem_kernel(const TX* __restrict__ x, cons
 // phases and by HBM, not by the matrix cores.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int IRB = IR + 1;      // one more row: window row 7 of the last conv row (zero weight, must be finite)
-constexpr int PWB = 36;          // bf16 per image row (72 bytes): 32 used
+// Tile shapes of the bf16 / split-bf16 stem: TPH x TPW pooled pixels per workgroup step <- (2 TPH + 1) x (2 TPW + 1) conv pixels as
+// MTILES MFMA row tiles of 32 (MTILES / 4 per wave) <- IR x ICP input pixels kept as bf16 images of PWB pixels per row (+ one row:
+// window row 7 of the last conv row - zero weight, must be finite).
+//   4 x 6 (round 2): 117 of 128 MFMA rows used, 24 pooled pixels per pair of barriers
+//   8 x 7 (round 5): 255 of 256 rows, 56 pooled pixels per pair of barriers, 1.91 x the staging for 2.33 x the output; 74 KB of LDS,
+//                    still two workgroups per CU
+template <int TPH_, int TPW_, int PWB_>
+struct StemTile {
+  static constexpr int TPH = TPH_, TPW = TPW_;
+  static constexpr int CR = 2 * TPH + 1, CC = 2 * TPW + 1, NPIX = CR * CC, MTILES = (NPIX + 31) / 32;
+  static constexpr int IR = 2 * (CR - 1) + 7, ICP = 2 * (CC - 1) + 7 + 1, IRB = IR + 1, PWB = PWB_;
+  static_assert(MTILES % 4 == 0, "whole row tiles per wave");
+  static_assert(ICP % 2 == 0 && PWB % 2 == 0 && PWB >= ICP && PWB / 2 >= CC - 1 + 4, "a window's four words lie inside the image row");
+};
+using StemTileS = StemTile<4, 6, 36>;
+using StemTileL = StemTile<8, 7, 40>;
 // X3: the f32 stem on the bf16 matrix cores - the input tile as three bf16 images (pixel = hi + mid + lo exactly), the
 // weights as three fragment sets, six partial products per window (mid.lo, lo.mid, lo.lo are below 2^-23 of a product),
 // f32 accumulate, f32 output: 48 MFMAs of 32 cycles per wave and tile where the exact-f32 kernel above issues 56 of 64.
@@ -167,17 +181,19 @@ constexpr int PWB = 36;          // bf16 per image row (72 bytes): 32 used
 __device__ long long g_stem_stamps[2 * 4 * 8];
 #define STEM_STAMP(k)                                                                                                  \
   do {                                                                                                                 \
-    if (blockIdx.x == 3 && blockIdx.y == 20 && blockIdx.z == 5 && (wv == 0 || wv == 3) && lane == 0)                   \
+    if (blockIdx.x == 3 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 5 && (wv == 0 || wv == 3) && lane == 0)                   \
       g_stem_stamps[((wv ? 1 : 0) * 4 + tl) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime();                      \
   } while (0)
 #else
 #define STEM_STAMP(k) do {} while (0)
 #endif
-template <bool X3, typename TX, typename TO>
+template <bool X3, typename TX, typename TO, typename TC>
 __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x, const u32x4* __restrict__ wfrag,
                                                        const float* __restrict__ scale, const float* __restrict__ bias,
                                                        TO* __restrict__ out, int H, int W) {
   static_assert(std::is_same<TO, std::conditional_t<X3, float, __bf16>>::value, "X3 writes f32, the bf16 precision bf16");
+  constexpr int TPH = TC::TPH, TPW = TC::TPW, CR = TC::CR, CC = TC::CC, NPIX = TC::NPIX, MTILES = TC::MTILES;
+  constexpr int IR = TC::IR, ICP = TC::ICP, IRB = TC::IRB, PWB = TC::PWB;
   constexpr int NPL = X3 ? 3 : 1;                       // bf16 images of the input tile / weight fragment sets
   constexpr int IMG = IRB * PWB / 2;                    // words per image (two bf16 per word)
   __shared__ __attribute__((aligned(16))) unsigned in_s[NPL * IMG];
@@ -261,8 +277,9 @@ __global__ __launch_bounds__(NT) void stem_bf16_kernel(const TX* __restrict__ x,
     if constexpr (!(X3 && sizeof(TX) == 4)) __syncthreads();
     inexact = false;
     STEM_STAMP(2);
-    {
-      const int mt = wv;
+#pragma unroll 1   // (unrolled, the two tiles' accumulators and fragments take the split-bf16 form past 256 registers: one workgroup per CU)
+    for (int u = 0; u < MTILES / 4; ++u) {   // this wave's row tiles
+      const int mt = wv + 4 * u;
       const int pix = min(32 * mt + l31, NPIX - 1);
       const int pr = pix / CC, pc = pix - pr * CC;
       const unsigned* row = in_s + (2 * pr + half) * (PWB / 2) + pc;  // window row `half`, first pixel pair
@@ -483,10 +500,11 @@ void launch_stem_bf16(const void* x, int x_u8, const void* wfrag, const float* s
                       hipStream_t s) {
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
-  dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
-  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<false, uint8_t, __bf16>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag),
+  using TC = StemTileS;   // (8 x 7: 0.126 against 0.118 ms - with one image and eight MFMAs per wave and tile this form is bound by staging and pooling)
+  dim3 grid(((Wp + TC::TPW - 1) / TC::TPW + TL - 1) / TL, (Hp + TC::TPH - 1) / TC::TPH, N);
+  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<false, uint8_t, __bf16, TC>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag),
                                scale, bias, static_cast<__bf16*>(out), H, W);
-  else hipLaunchKernelGGL((stem_bf16_kernel<false, float, __bf16>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag), scale, bias,
+  else hipLaunchKernelGGL((stem_bf16_kernel<false, float, __bf16, TC>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag), scale, bias,
                           static_cast<__bf16*>(out), H, W);
   OCR_HIP(hipGetLastError());
 }
@@ -495,10 +513,11 @@ void launch_stem_x3(const void* x, int x_u8, const void* wfrag3, const float* sc
                     hipStream_t s) {
   if (H % 32 || W % 32 || N <= 0 || N > 65535) fail(OCR_ERR_INVALID, "stem: bad shape N=%d H=%d W=%d", N, H, W);
   const int Hp = H / 4, Wp = W / 4;
-  dim3 grid(((Wp + TPW - 1) / TPW + TL - 1) / TL, (Hp + TPH - 1) / TPH, N);
-  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<true, uint8_t, float>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag3),
+  using TC = StemTileL;   // (4 x 6: 0.227 against 0.177 ms at 32 x 640 x 640)
+  dim3 grid(((Wp + TC::TPW - 1) / TC::TPW + TL - 1) / TL, (Hp + TC::TPH - 1) / TC::TPH, N);
+  if (x_u8) hipLaunchKernelGGL((stem_bf16_kernel<true, uint8_t, float, TC>), grid, dim3(NT), 0, s, static_cast<const uint8_t*>(x), static_cast<const u32x4*>(wfrag3),
                                scale, bias, out, H, W);
-  else hipLaunchKernelGGL((stem_bf16_kernel<true, float, float>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag3), scale, bias,
+  else hipLaunchKernelGGL((stem_bf16_kernel<true, float, float, TC>), grid, dim3(NT), 0, s, static_cast<const float*>(x), static_cast<const u32x4*>(wfrag3), scale, bias,
                           out, H, W);
   OCR_HIP(hipGetLastError());
 }

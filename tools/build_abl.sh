@@ -1,0 +1,16 @@
+#!/bin/bash
+# Compile-time ablations of conv_igemm.hip (IGEMM_ABL bits: 1 no A DMA, 2 no B DMA, 4 no split, 8 no MFMA, 32 no LDS fragment reads,
+# 64 no mid-step barrier, 128 no epilogue, 256 one K-step, 512 no wait for the DMA): builds ocr-rs_amd/lib_abl<N> from the objects of
+# ocr-rs_amd/lib with conv_igemm.o recompiled.   tools/build_abl.sh <N> [<N> ...]; then tools/abl_run.sh on the GPU box.
+# The results of an ablated kernel are garbage; only its time means something.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+for N in "$@"; do
+  D=$ROOT/ocr-rs_amd/lib_abl$N
+  rm -rf "$D" && mkdir -p "$D/obj" && cp "$ROOT"/ocr-rs_amd/lib/obj/*.o "$D/obj/"
+  (cd "$ROOT/ocr-rs_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DIGEMM_ABL=$N -c conv_igemm.hip -o "$D/obj/conv_igemm.o" 2>/dev/null)
+  OBJS=$(ls "$D"/obj/*.o | grep -v test_hooks)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$D/libocr_amd_test.so" "$D/obj/test_hooks.o" $OBJS -ldl
+  cp "$D/libocr_amd_test.so" "$D/libocr_amd.so"
+  echo "built lib_abl$N"
+done
