@@ -132,6 +132,8 @@ struct ConvArgs {
   int batch;    // batched GEMM: number of problems (grid slices along M); 1 otherwise
   int pyr_chunked;  // PYR4 tile order (see the kernel)
   int pyr_nsrc;     // PYR4: 4 = p5, p4, p3, p2; 3 = without p2
+  int win;          // STORE_PHASE, up 2, 128 columns: rows are 2 x 2 WINDOWS of the low-res grid ((Hin + 1) x (Win + 1) per image), the four phases
+                    // that read a window are its four column groups (see WING in the kernel); Ho / Wo hold the window grid
   int pyr_group;    // PYR4, split-bf16: 0 = one tile per phase; 1 = phase blocks as column groups (128-wide tiles); 2 = the four corner phases
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
   int debug;    // builds with -DIGEMM_DEBUG only (ocr_test_set_conv_debug): X3 ablations - 1 no A DMA, 2 no B DMA, 4 no split, 8 no MFMA
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // 1 x 2, 2 x 1) phases is ONE GEMM with 64 columns per phase: the A operand is fetched and split once for 128 columns instead
   // of once per 64, and 21 + 4 tiles gather a cell block's sources instead of 64.  Row groups ga = 0..4 <-> y mod 8 = {0}, {1,2},
   // {3,4}, {5,6}, {7}; a virtual tile is (ga, gb, 128-column half); the four corner phases (64 columns) run as launch kind 2.
-  constexpr bool PYRG = SRC == SRC_PYR4 && BN == 128;   // (the split-bf16 kernel and the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase)
+  constexpr bool PYRG = SRC == SRC_PYR4 && BN == 128;
+  constexpr bool WING = X3 && STORE == STORE_PHASE && SRC == SRC_PLAIN && KS == 2 && BN == 128;   // (run-time switch p.win)   // (the split-bf16 kernel and the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase)
   [[maybe_unused]] int g_nb = 1, g_half = 0;
   if constexpr (PYRG) {
     constexpr int CHS = 2, CH = 1 << CHS;
@@ -283,6 +286,14 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       pa = ph >> 3;
       pb = ph & 7;
     }
+  } else if (WING && p.win) {
+    // WING: window (wy, wx) = low-res rows {wy - 1, wy} x columns {wx - 1, wx} is what phase (1, 1) of cell (wy - 1, wx - 1), phase (1, 0) of
+    // (wy - 1, wx), (0, 1) of (wy, wx - 1) and (0, 0) of (wy, wx) read: with windows as the rows of the GEMM the four phases are four
+    // column groups of 64 (their own weight rows) over ONE gathered, once-split operand tile; it produces the outputs
+    // (2 wy - 1 + dy, 2 wx - 1 + dx), those outside the map are dropped.  Tiles (row tile, 128-column half) are neighbours in an XCD's run.
+    g_half = __builtin_amdgcn_readfirstlane(tile_m & 1);
+    tile_m >>= 1;
+    g_nb = 2;
   } else if constexpr (STORE == STORE_PHASE) {
     // order (chunk of CH row tiles | phase | tile in chunk): the up x up phases of a low-res tile read the same 3 x 3
     // neighbourhood - as consecutive tiles of one XCD's run they find it in that L2 instead of fetching it once per phase
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     nt = pyr_taps(0, pa) * nw;
   }
   const int m0 = tile_m * BM;
-  const int n0 = PYRG ? g_half * BN : tile_n * BN;
+  const int n0 = (PYRG || (WING && p.win)) ? g_half * BN : tile_n * BN;
   // PYRG: 64-column group q of the block -> its phase (pa + dpa, pb + dpb)
   [[maybe_unused]] auto group_dpa = [&](int q) { return g_nb == 2 ? q >> 1 : q; };
   [[maybe_unused]] auto group_dpb = [&](int q) { return g_nb == 2 ? q & 1 : 0; };
@@ -387,6 +398,12 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       if constexpr (PYRG) {   // weight rows [phase][64]: column group 2 g_half + i is its own phase
         const int q = 2 * g_half + i;
         brow = ((pa + group_dpa(q)) * 8 + pb + group_dpb(q)) * 64;
+      }
+      if constexpr (WING) {
+        if (p.win) {   // column group q = (dy, dx) is phase (1 - dy, 1 - dx): weight rows [phase = 2 a + b][64]
+          const int q = 2 * g_half + i;
+          brow = (3 - q) * 64;
+        }
       }
       bvoff[i] = (unsigned)(((brow >> 4) + wave) * nK * 3072 + lane * 16);
     }
@@ -995,7 +1012,14 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       colb = (unsigned)((group_dpa(q) * (p.Wo << 3) + group_dpb(q)) * 64 + ch) * 4u;
     }
     const int ush = p.up_shift;
-    const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)((((unsigned)p.M << (2 * ush)) * (unsigned)p.Cout) * 4u));
+    const bool win = WING && p.win;
+    const unsigned out_elems = win ? (unsigned)(p.N * p.Hin * p.Win * 4) * (unsigned)p.Cout : ((unsigned)p.M << (2 * ush)) * (unsigned)p.Cout;
+    const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(out_elems * 4u));
+    if (win) {
+      ch = col & 63;
+      colb = (unsigned)ch * 4u;
+    }
+    const int wdy = (col >> 6) >> 1, wdx = (col >> 6) & 1;   // WING: this thread's column group
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.out), 0, out_bytes, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.residual ? p.residual : p.out), 0, p.residual ? out_bytes : 0u, 0x00020000);
     unsigned ro[PASSES];
@@ -1009,6 +1033,11 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       const int ow = rem - oh * p.Wo;
       // rows beyond M get an out-of-range offset: loads return zeros, stores are dropped by the hardware
       ro[k] = m < p.M ? (unsigned)(((((n * p.Ho + oh) << ush) + pa) * (p.Wo << ush) + (ow << ush) + pb) * p.Cout) * 4u + colb : OOB;
+      if (win) {   // window (oh, ow) of image n, output (2 oh - 1 + dy, 2 ow - 1 + dx) where it exists
+        const int oy = 2 * oh - 1 + wdy, ox = 2 * ow - 1 + wdx;
+        const bool ok = m < p.M && (unsigned)oy < (unsigned)(2 * p.Hin) && (unsigned)ox < (unsigned)(2 * p.Win);
+        ro[k] = ok ? (unsigned)(((n * 2 * p.Hin + oy) * 2 * p.Win + ox) * p.Cout) * 4u + colb : OOB;
+      }
       res[k] = Elem<float>::bload4(r_rsrc, ro[k]);   // (no residual: an empty descriptor, zeros)
     }
     __syncthreads();              // every wave is done reading the last operand stage
@@ -1222,12 +1251,21 @@ void launch_inst(const ConvDesc& d, hipStream_t s) {
   a.pyr_group = d.pyr_group;
   a.debug = g_conv_debug;
   a.nblk = a.nblk_m * a.nblk_n * (STORE == STORE_PHASE ? d.up * d.up : a.batch);
+  if (d.win) {   // rows = windows, two 128-column halves per row tile
+    a.win = 1;
+    a.Ho = d.Hin + 1;
+    a.Wo = d.Win + 1;
+    a.M = d.N * a.Ho * a.Wo;
+    a.nblk_m = (a.M + BM - 1) / BM;
+    a.nblk_n = 1;
+    a.nblk = 2 * a.nblk_m;
+  }
   if (SRC == SRC_PYR4 && d.pyr_group) {   // 30 virtual tiles of 128 columns per cell block (60 phases), or the four corner phases
     a.nblk_n = 1;
     a.nblk = a.nblk_m * (d.pyr_group == 1 ? 30 : 4);
   }
-  make_magic((unsigned)(d.Ho * d.Wo), &a.mg_howo, &a.sh_howo);
-  make_magic((unsigned)d.Wo, &a.mg_wo, &a.sh_wo);
+  make_magic((unsigned)(a.Ho * a.Wo), &a.mg_howo, &a.sh_howo);
+  make_magic((unsigned)a.Wo, &a.mg_wo, &a.sh_wo);
   hipLaunchKernelGGL((conv_igemm<TI, TO, BM, BN, KS, STRIDE, SRC, STORE, X3>), dim3(a.nblk), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
 }
@@ -1244,6 +1282,9 @@ static void check(const ConvDesc& d) {
   const int ebw = d.x3 ? 6 : eb;
   if (d.pyr_group && (d.pyr_group < 0 || d.pyr_group > 2 || !(d.x3 || d.in_bf16) || d.src_mode != SRC_PYR4 || d.pyr_nsrc != 3))
     fail(OCR_ERR_INVALID, "%s: phase blocks (pyr_group %d) exist for the split-bf16 and bf16 PYR4 forms over p5, p4, p3", d.name, d.pyr_group);
+  if (d.win && (!d.x3 || d.store_mode != STORE_PHASE || d.src_mode != SRC_PLAIN || d.up != 2 || d.ks != 2 || d.Cout != 64 ||
+                (long long)d.N * (d.Hin + 1) * (d.Win + 1) >= (1ll << 31)))
+    fail(OCR_ERR_INVALID, "%s: the window-indexed form exists for the split-bf16 up-2 phase convs with 64 output channels", d.name);
   if (d.x3 && d.src_mode == SRC_PYR4 && d.pyr_nsrc != 3) fail(OCR_ERR_INVALID, "%s: the split-bf16 PYR4 form takes the three upsampled sources only", d.name);
   if (d.x3 && (d.in_bf16 || d.out_bf16 || d.src_mode == SRC_CAT4 || d.store_mode == STORE_SHUFFLE2))
     fail(OCR_ERR_INVALID, "%s: the split-bf16 form exists for f32 PLAIN / PYR4 convs with NHWC or PHASE stores", d.name);
@@ -1334,6 +1375,7 @@ static Tile pick_tile(const ConvDesc& d) {
     // 128 x 128 wherever Cout allows it, however few tiles that leaves (measured on every launch shape of the detector,
     // tools/profile_layers.py with the tile override: operand DMA per MFMA is what the wide tile saves)
     if (d.src_mode == SRC_PYR4) return d.pyr_group == 1 ? T128x128 : T128x64;
+    if (d.win) return T128x128;
     if (g_tile_override == 2 || d.Cout % 128) return T128x64;
     return T128x128;
   }

@@ -247,6 +247,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "bin_pyr") bin_pyr_on_ = num() != 0;
     else if (key == "pyr_p2_direct") pyr_p2_direct_ = num() != 0;
     else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
+    else if (key == "phase_windows") phase_windows_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") overlap_ = num();
     else if (key == "w43_cus") {
@@ -911,6 +912,8 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       d.wgt = cw.w_x3;
       d.wgt_bytes = cw.w_bytes / 4 * 6;
     }
+    // up-2 phase convs (the FPN's upsampled terms): rows = 2 x 2 windows, the four phases as column groups of one operand tile
+    if (d.x3 && ex.store == STORE_PHASE && !ex.pyr4 && cw.up == 2 && cw.cout == 64 && phase_windows_) d.win = 1;
     d.scale = cw.scale;
     d.bias = cw.bias;
     d.residual = ex.residual;

@@ -181,6 +181,7 @@ class Detector {
   // option bin_pyr=0 keeps the four-launch form.
   ConvW bin_pyr_;
   bool bin_pyr_on_ = true;
+  bool phase_windows_ = true;   // split-bf16 up-2 phase convs indexed by 2 x 2 windows: one operand tile for the four phases (0: one 64-column tile per phase)
   bool pyr_grouped_ = true;     // split-bf16 / bf16 bin_conv1 over p5..p3: phase blocks as 128-column tiles + the corner phases (0: one 64-column tile per phase)
   bool pyr_p2_direct_ = true;   // bf16 precision: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv instead of nine taps of the phase launch
   ConvW finish_composed(std::vector<float>&& t, int cout, int cin, int ks);

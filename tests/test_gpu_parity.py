@@ -386,6 +386,7 @@ def test_stem_exact_and_inexact_tiles(det, det_w):
     "winograd_fused=0",                                            # direct convs on the large grids, unfused Winograd layer3/4
     "winograd=0;winograd_fused=0",                                 # no Winograd at all
     "bin_pyr=0",                                                   # bin_conv1 as four launches
+    "phase_windows=0",                                             # the FPN's up-2 phase convs as one 64-column tile per phase (default: rows = 2 x 2 windows)
     "pyr_grouped=0",                                               # bin_conv1 over p5..p3 as one 64-column tile per phase (default: phase blocks)
     "fpn_unfused=1",                                               # layer-by-layer FPN
     "fpn_unfused=1;winograd=0;winograd_fused=0;tail_unfused=1",    # the plain graph
@@ -440,6 +441,24 @@ def test_phase_blocks_are_bit_identical(det_w):
         for sched in ("overlap=0", "overlap=3", "precision=bf16;overlap=0", "precision=bf16;overlap=3"):
             a = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";pyr_grouped=1")
             b = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";pyr_grouped=0")
+            try:
+                assert np.array_equal(a.forward_host(x), b.forward_host(x)), (n, h, w, sched)
+            finally:
+                a.close()
+                b.close()
+
+
+def test_window_indexed_phase_convs_are_bit_identical(det_w):
+    """The FPN's up-2 phase convs (conv_igemm.hip, WING): rows of the GEMM are the (H + 1) x (W + 1) 2 x 2 windows of the low-res grid, the four
+    phases that read a window are four column groups of one operand tile, outputs outside the map are dropped.  Per output the products and
+    their order are those of the one-tile-per-phase form: the same map bit for bit - odd and ragged low-res grids (windows past every
+    border), one cell row, several row tiles; the composed FPN with one phase launch for bin_conv1 and with four (bin_pyr=0: p3's up-2
+    term with a residual)."""
+    for (n, h, w) in ((2, 96, 160), (3, 224, 352), (1, 32, 64), (4, 320, 320)):
+        x = W.synth_image_batch(53, n, h, w)
+        for sched in ("overlap=0", "overlap=3", "overlap=0;bin_pyr=0"):
+            a = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";phase_windows=1")
+            b = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";phase_windows=0")
             try:
                 assert np.array_equal(a.forward_host(x), b.forward_host(x)), (n, h, w, sched)
             finally:
