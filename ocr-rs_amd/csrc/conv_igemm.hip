@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // of once per 64, and 21 + 4 tiles gather a cell block's sources instead of 64.  Row groups ga = 0..4 <-> y mod 8 = {0}, {1,2},
   // {3,4}, {5,6}, {7}; a virtual tile is (ga, gb, 128-column half); the four corner phases (64 columns) run as launch kind 2.
   constexpr bool PYRG = SRC == SRC_PYR4 && BN == 128;
-  constexpr bool WING = X3 && STORE == STORE_PHASE && SRC == SRC_PLAIN && KS == 2 && BN == 128;   // (run-time switch p.win)   // (the split-bf16 kernel and the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase)
+  constexpr bool WING = (X3 || sizeof(TI) == 2) && STORE == STORE_PHASE && SRC == SRC_PLAIN && KS == 2 && BN == 128;   // (run-time switch p.win; split-bf16 and bf16 kernels)   // (the split-bf16 kernel and the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase)
   [[maybe_unused]] int g_nb = 1, g_half = 0;
   if constexpr (PYRG) {
     constexpr int CHS = 2, CH = 1 << CHS;
@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       if constexpr (PYRG) {   // weight rows [phase][64]: column group 2 g_half + (i >> 1) is its own phase
         const int q = 2 * g_half + (i >> 1);
         brow = ((pa + group_dpa(q)) * 8 + pb + group_dpb(q)) * 64 + 32 * (i & 1);
+      }
+      if constexpr (WING) {
+        if (p.win) brow = (3 - (2 * g_half + (i >> 1))) * 64 + 32 * (i & 1);   // column group q = (dy, dx) is phase (1 - dy, 1 - dx)
       }
       bvoff[i] = (unsigned)((brow + r) * wrow * EB + gq * 16);
     }
@@ -999,25 +1002,27 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // row of the thread is requested BEFORE the tile goes through LDS - all loads in flight under the transpose instead of rounds of
   // load, wait, store behind it (the 128 x 128 phase-block tile's epilogue was a third of its launch: two workgroups per CU, and
   // the one in its epilogue multiplies nothing).  Row offsets by magic division per thread: no row table, one barrier less.
-  if constexpr (X3 && STORE == STORE_PHASE) {
+  if constexpr (STORE == STORE_PHASE && (X3 || sizeof(TI) == 2)) {
     constexpr int CPR = BN / 4, RPP = 256 / CPR, PASSES = BM / RPP;
+    constexpr unsigned ES = sizeof(TO);
+    static_assert(BM * BN * 4 <= 2 * STAGE, "accumulator tile must fit in the operand stages");
     float* tile = reinterpret_cast<float*>(lds);
     const int c4 = (tid % CPR) * 4, rr0 = tid / CPR;
     const int col = n0 + c4;
     int ch = col;
-    unsigned colb = (unsigned)col * 4u;
+    unsigned colb = (unsigned)col * ES;
     if constexpr (PYRG) {   // this thread's column group is the phase (pa + dpa, pb + dpb) of the same 64 channels: dpa output rows down, dpb pixels right
       const int q = col >> 6;
       ch = col & 63;
-      colb = (unsigned)((group_dpa(q) * (p.Wo << 3) + group_dpb(q)) * 64 + ch) * 4u;
+      colb = (unsigned)((group_dpa(q) * (p.Wo << 3) + group_dpb(q)) * 64 + ch) * ES;
     }
     const int ush = p.up_shift;
     const bool win = WING && p.win;
     const unsigned out_elems = win ? (unsigned)(p.N * p.Hin * p.Win * 4) * (unsigned)p.Cout : ((unsigned)p.M << (2 * ush)) * (unsigned)p.Cout;
-    const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(out_elems * 4u));
+    const unsigned out_bytes = __builtin_amdgcn_readfirstlane((int)(out_elems * ES));
     if (win) {
       ch = col & 63;
-      colb = (unsigned)ch * 4u;
+      colb = (unsigned)ch * ES;
     }
     const int wdy = (col >> 6) >> 1, wdx = (col >> 6) & 1;   // WING: this thread's column group
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.out), 0, out_bytes, 0x00020000);
@@ -1032,21 +1037,24 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
       const int oh = fast_div(rem, p.mg_wo, p.sh_wo);
       const int ow = rem - oh * p.Wo;
       // rows beyond M get an out-of-range offset: loads return zeros, stores are dropped by the hardware
-      ro[k] = m < p.M ? (unsigned)(((((n * p.Ho + oh) << ush) + pa) * (p.Wo << ush) + (ow << ush) + pb) * p.Cout) * 4u + colb : OOB;
+      ro[k] = m < p.M ? (unsigned)(((((n * p.Ho + oh) << ush) + pa) * (p.Wo << ush) + (ow << ush) + pb) * p.Cout) * ES + colb : OOB;
       if (win) {   // window (oh, ow) of image n, output (2 oh - 1 + dy, 2 ow - 1 + dx) where it exists
         const int oy = 2 * oh - 1 + wdy, ox = 2 * ow - 1 + wdx;
         const bool ok = m < p.M && (unsigned)oy < (unsigned)(2 * p.Hin) && (unsigned)ox < (unsigned)(2 * p.Win);
-        ro[k] = ok ? (unsigned)(((n * 2 * p.Hin + oy) * 2 * p.Win + ox) * p.Cout) * 4u + colb : OOB;
+        ro[k] = ok ? (unsigned)(((n * 2 * p.Hin + oy) * 2 * p.Win + ox) * p.Cout) * ES + colb : OOB;
       }
-      res[k] = Elem<float>::bload4(r_rsrc, ro[k]);   // (no residual: an empty descriptor, zeros)
+      res[k] = Elem<TO>::bload4(r_rsrc, ro[k]);   // (no residual: an empty descriptor, zeros)
     }
     __syncthreads();              // every wave is done reading the last operand stage
     {
       const int colq = lane & 31, rowq = (lane >> 5) * 4;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tile[(wm * WM + (e & 3) + 8 * (e >> 2) + rowq) * BN + j * 32 + colq] = acc[0][j][e];
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            tile[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + rowq) * BN + wn * WN + j * 32 + colq] = acc[i][j][e];
     }
     __syncthreads();
     const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
@@ -1058,7 +1066,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
       }
-      Elem<float>::bstore4(o_rsrc, ro[k], v);
+      Elem<TO>::bstore4(o_rsrc, ro[k], v);
     }
     return;
   }
@@ -1282,9 +1290,9 @@ static void check(const ConvDesc& d) {
   const int ebw = d.x3 ? 6 : eb;
   if (d.pyr_group && (d.pyr_group < 0 || d.pyr_group > 2 || !(d.x3 || d.in_bf16) || d.src_mode != SRC_PYR4 || d.pyr_nsrc != 3))
     fail(OCR_ERR_INVALID, "%s: phase blocks (pyr_group %d) exist for the split-bf16 and bf16 PYR4 forms over p5, p4, p3", d.name, d.pyr_group);
-  if (d.win && (!d.x3 || d.store_mode != STORE_PHASE || d.src_mode != SRC_PLAIN || d.up != 2 || d.ks != 2 || d.Cout != 64 ||
+  if (d.win && (!(d.x3 || d.in_bf16) || d.store_mode != STORE_PHASE || d.src_mode != SRC_PLAIN || d.up != 2 || d.ks != 2 || d.Cout != 64 ||
                 (long long)d.N * (d.Hin + 1) * (d.Win + 1) >= (1ll << 31)))
-    fail(OCR_ERR_INVALID, "%s: the window-indexed form exists for the split-bf16 up-2 phase convs with 64 output channels", d.name);
+    fail(OCR_ERR_INVALID, "%s: the window-indexed form exists for the split-bf16 / bf16 up-2 phase convs with 64 output channels", d.name);
   if (d.x3 && d.src_mode == SRC_PYR4 && d.pyr_nsrc != 3) fail(OCR_ERR_INVALID, "%s: the split-bf16 PYR4 form takes the three upsampled sources only", d.name);
   if (d.x3 && (d.in_bf16 || d.out_bf16 || d.src_mode == SRC_CAT4 || d.store_mode == STORE_SHUFFLE2))
     fail(OCR_ERR_INVALID, "%s: the split-bf16 form exists for f32 PLAIN / PYR4 convs with NHWC or PHASE stores", d.name);
@@ -1379,6 +1387,7 @@ static Tile pick_tile(const ConvDesc& d) {
     if (g_tile_override == 2 || d.Cout % 128) return T128x64;
     return T128x128;
   }
+  if (d.win) return T128x128;
   if (g_tile_override == 1 && d.Cout % 128 == 0) return T128x128;
   if (g_tile_override == 2) return T128x64;
   if (g_tile_override == 3) return T64x64;

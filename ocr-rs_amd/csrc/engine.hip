@@ -913,7 +913,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
       d.wgt_bytes = cw.w_bytes / 4 * 6;
     }
     // up-2 phase convs (the FPN's upsampled terms): rows = 2 x 2 windows, the four phases as column groups of one operand tile
-    if (d.x3 && ex.store == STORE_PHASE && !ex.pyr4 && cw.up == 2 && cw.cout == 64 && phase_windows_) d.win = 1;
+    if ((d.x3 || in_bf) && ex.store == STORE_PHASE && !ex.pyr4 && cw.up == 2 && cw.cout == 64 && phase_windows_) d.win = 1;
     d.scale = cw.scale;
     d.bias = cw.bias;
     d.residual = ex.residual;

@@ -453,10 +453,10 @@ def test_window_indexed_phase_convs_are_bit_identical(det_w):
     phases that read a window are four column groups of one operand tile, outputs outside the map are dropped.  Per output the products and
     their order are those of the one-tile-per-phase form: the same map bit for bit - odd and ragged low-res grids (windows past every
     border), one cell row, several row tiles; the composed FPN with one phase launch for bin_conv1 and with four (bin_pyr=0: p3's up-2
-    term with a residual)."""
+    term with a residual); the split-bf16 kernel and the bf16 kernel."""
     for (n, h, w) in ((2, 96, 160), (3, 224, 352), (1, 32, 64), (4, 320, 320)):
         x = W.synth_image_batch(53, n, h, w)
-        for sched in ("overlap=0", "overlap=3", "overlap=0;bin_pyr=0"):
+        for sched in ("overlap=0", "overlap=3", "overlap=0;bin_pyr=0", "precision=bf16;overlap=0", "precision=bf16;overlap=3"):
             a = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";phase_windows=1")
             b = capi.Detector(W.pack_blob(det_w), 0, options=sched + ";phase_windows=0")
             try:
