@@ -79,7 +79,7 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               {5,6} (same along x) read the same source rows - such a block of phases is one 128-column tile that fetches
  *                               and splits the operand once; the four corner phases are a second, small launch.  0 = one 64-column tile per
  *                               phase.  Bit-identical
- *   phase_windows=0|1    (1)    the FPN's up-2 phase convs (split-bf16 kernel): phase 1 of cell i and phase 0 of cell i + 1 read the same two low-res
+ *   phase_windows=0|1    (1)    the FPN's up-2 phase convs (split-bf16 and bf16 kernels): phase 1 of cell i and phase 0 of cell i + 1 read the same two low-res
  *                               rows, so the GEMM's rows are the (H + 1) x (W + 1) 2 x 2 windows and the four phases that read a window are four
  *                               column groups of one operand tile (outputs outside the map are dropped).  0 = one 64-column tile per phase.  Bit-identical
  *   pyr_p2_direct=0|1    (1)    bf16 precision only: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv on top of the phase
