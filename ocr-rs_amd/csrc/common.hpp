@@ -70,9 +70,9 @@ struct ConvDesc {
   // src_bytes / wgt_bytes cover all of them.  0 or 1 = a single problem.
   int batch;
   int pyr_nsrc;           // SRC_PYR4: 0 / 4 = all four sources, 3 = p5, p4, p3 only (p2's term is computed elsewhere)
-  int pyr_group;          // SRC_PYR4 with x3: 0 = all 64 phases, one 64-column tile each; 1 = the 60 phases that share their operand rows with a
+  int pyr_group;          // SRC_PYR4 over p5, p4, p3 (x3 or bf16 operands): 0 = all 64 phases, one 64-column tile each; 1 = the 60 phases that share their operand rows with a
                           // neighbour, as 128-column tiles of 2 x 2 / 1 x 2 / 2 x 1 phase blocks; 2 = the four corner phases (0 | 7, 0 | 7)
-  int win;                // STORE_PHASE with up 2, x3, Cout 64: the GEMM's rows are the (Hin + 1) x (Win + 1) 2 x 2 windows of the low-res grid and the four
+  int win;                // STORE_PHASE with up 2, Cout 64 (x3 or bf16 operands): the GEMM's rows are the (Hin + 1) x (Win + 1) 2 x 2 windows of the low-res grid and the four
                           // phases that read a window are the four 64-column groups of one 128-wide pair of tiles (same products, same order)
   const void* wgt;
   const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32

@@ -15,6 +15,11 @@
 //   SRC_PYR4    - bin_conv1 over the upsampled concat per output phase (y mod 8, x mod 8) with p5, p4, p3, p2
 //                 as four sources of one K loop;
 //   batch = 16  - the sixteen GEMMs of a Winograd F(2x2,3x3) conv (winograd.hip) as grid slices of one launch.
+// Phases that read the same operand rows share one operand tile (split-bf16 and bf16 kernels; bit-identical to one tile per phase):
+//   PYRG        - SRC_PYR4: output phases y mod 8 in {1,2}, {3,4}, {5,6} (same along x) see the same pixels of p5, p4, p3: a block of such
+//                 phases is one 128-column tile, 64 columns per phase;
+//   WING        - STORE_PHASE with up 2: phase 1 of cell i and phase 0 of cell i + 1 read the same two rows: the GEMM's rows are the 2 x 2
+//                 windows of the low-res grid, the four phases of a window its four column groups.
 //
 // Data movement: both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds):
 // no staging registers, no ds_write, no per-K-step address arithmetic (the K-step offset is
@@ -134,7 +139,7 @@ struct ConvArgs {
   int pyr_nsrc;     // PYR4: 4 = p5, p4, p3, p2; 3 = without p2
   int win;          // STORE_PHASE, up 2, 128 columns: rows are 2 x 2 WINDOWS of the low-res grid ((Hin + 1) x (Win + 1) per image), the four phases
                     // that read a window are its four column groups (see WING in the kernel); Ho / Wo hold the window grid
-  int pyr_group;    // PYR4, split-bf16: 0 = one tile per phase; 1 = phase blocks as column groups (128-wide tiles); 2 = the four corner phases
+  int pyr_group;    // PYR4 (split-bf16 / bf16 kernels): 0 = one tile per phase; 1 = phase blocks as column groups (128-wide tiles); 2 = the four corner phases
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;  // magic numbers: x / (Ho*Wo), x / Wo
   int debug;    // builds with -DIGEMM_DEBUG only (ocr_test_set_conv_debug): X3 ablations - 1 no A DMA, 2 no B DMA, 4 no split, 8 no MFMA
 };
@@ -214,13 +219,15 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
   // (same for columns) - with that phase's pre-summed weights; the up*up phases are consecutive slices of
   // the grid.
   int ph = 0, pa = 0, pb = 0;
-  // PYRG (SRC_PYR4, split-bf16, 128 columns): the phases y mod 8 in {1,2}, {3,4}, {5,6} read the SAME source rows of p5, p4 and p3 (their
+  // PYRG (SRC_PYR4, 128 columns): the phases y mod 8 in {1,2}, {3,4}, {5,6} read the SAME source rows of p5, p4 and p3 (their
   // 3x3 windows cover the same low-res pixels; only the pre-summed weights differ), likewise along x.  Such a block of 2 x 2 (or
   // 1 x 2, 2 x 1) phases is ONE GEMM with 64 columns per phase: the A operand is fetched and split once for 128 columns instead
   // of once per 64, and 21 + 4 tiles gather a cell block's sources instead of 64.  Row groups ga = 0..4 <-> y mod 8 = {0}, {1,2},
   // {3,4}, {5,6}, {7}; a virtual tile is (ga, gb, 128-column half); the four corner phases (64 columns) run as launch kind 2.
   constexpr bool PYRG = SRC == SRC_PYR4 && BN == 128;
-  constexpr bool WING = (X3 || sizeof(TI) == 2) && STORE == STORE_PHASE && SRC == SRC_PLAIN && KS == 2 && BN == 128;   // (run-time switch p.win; split-bf16 and bf16 kernels)   // (the split-bf16 kernel and the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase)
+  // (both forms exist in the split-bf16 kernel and in the bf16 kernel; f32 operands on the f32 MFMA keep one tile per phase.  WING is
+  // switched at run time by p.win - described where its tiles are decoded, below)
+  constexpr bool WING = (X3 || sizeof(TI) == 2) && STORE == STORE_PHASE && SRC == SRC_PLAIN && KS == 2 && BN == 128;
   [[maybe_unused]] int g_nb = 1, g_half = 0;
   if constexpr (PYRG) {
     constexpr int CHS = 2, CH = 1 << CHS;
@@ -998,7 +1005,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     return;
   }
 
-  // ---- epilogue of the split-bf16 phase convs: as epilogue B below (tile through LDS, row-major float4 traffic), but every residual
+  // ---- epilogue of the phase convs (split-bf16 and bf16 kernels): as epilogue B below (tile through LDS, row-major float4 traffic), but every residual
   // row of the thread is requested BEFORE the tile goes through LDS - all loads in flight under the transpose instead of rounds of
   // load, wait, store behind it (the 128 x 128 phase-block tile's epilogue was a third of its launch: two workgroups per CU, and
   // the one in its epilogue multiplies nothing).  Row offsets by magic division per thread: no row table, one barrier less.
