@@ -88,6 +88,79 @@ def free_port() -> int:
     return port
 
 
+# --------------------------------------------------------------------------------------------------
+# CPU placement of the ranks.  N ranks share one host: each rank's post-processing pool, staging threads and ATen pool stay on ITS
+# share of the cores - the ones nearest its GPU's NUMA node - instead of floating over both sockets.  Everything here reads sysfs
+# only (no GPU call): every rank computes the same plan and takes its own row, whichever launcher started it.
+def parse_cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpus(sysfs: str = "/sys"):
+    """Per GPU, in KFD topology order (the order HIP enumerates in), the CPUs of the NUMA node its PCIe device hangs off
+    (sysfs local_cpulist), or None where sysfs does not say.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES lists of indices are applied."""
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted((d for d in os.listdir(base) if d.isdigit()), key=int)
+    except OSError:
+        return None
+    gpus = []
+    for d in nodes:
+        try:
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue   # a CPU node
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+            cpus = parse_cpulist(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "local_cpulist")).read())
+            gpus.append(set(cpus) if cpus else None)
+        except (OSError, ValueError):
+            gpus.append(None)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        v = os.environ.get(var, "")
+        if v and all(t.strip().isdigit() for t in v.split(",")):
+            gpus = [gpus[int(t)] for t in v.split(",") if int(t) < len(gpus)]
+    return gpus or None
+
+
+def plan_affinity(world: int, allowed, per_rank: int, gpu_cpus=None):
+    """`world` disjoint CPU lists of (up to) `per_rank` CPUs out of `allowed`: rank r first takes free CPUs of its GPU's NUMA node
+    (gpu_cpus[r], see gpu_local_cpus), then - or when the topology is unknown - the next free ones in order (contiguous slices)."""
+    allowed = sorted(allowed)
+    per_rank = max(1, min(per_rank, len(allowed) // max(1, world))) if len(allowed) >= world else 1
+    free = list(allowed)
+    plan = []
+    for r in range(world):
+        near = gpu_cpus[r] if gpu_cpus and r < len(gpu_cpus) and gpu_cpus[r] else None
+        take = [c for c in free if near is None or c in near][:per_rank]
+        if len(take) < per_rank:
+            take += [c for c in free if c not in take][:per_rank - len(take)]
+        if not take:   # more ranks than CPUs: share
+            take = [allowed[r % len(allowed)]]
+        free = [c for c in free if c not in take]
+        plan.append(take)
+    return plan
+
+
+def pin_rank(local: int, world: int, per_rank: int):
+    """This process onto its row of the plan (before torch, the library or any thread pool exists).  Returns the CPUs, or None where
+    the platform has no sched_setaffinity / the call is refused (the rank then runs unpinned, as before)."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("OCR_BENCH_NO_PIN") == "1":
+        return None
+    try:
+        plan = plan_affinity(world, os.sched_getaffinity(0), per_rank, gpu_local_cpus())
+        os.sched_setaffinity(0, plan[local % world])
+        return plan[local % world]
+    except OSError:
+        return None
+
+
 def launch_ranks(n: int, argv) -> int:
     import tempfile
     port = int(os.environ.get("MASTER_PORT") or free_port())
@@ -160,6 +233,7 @@ def pmc_extract(dtype: str, n: int, s: int):
     return None, None, None
 
 
+PINNED_CPUS = None   # main(): the CPUs this rank pinned itself to (N > 1)
 STEM_FRAMES_BF16_EXACT = True  # main() clears it when the bench frames are not bf16-exact (they are raw luma: integers 0..255)
 
 
@@ -195,6 +269,7 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
     import torch
     from oracle import torch_ref as T
     from ocr_rs_amd import weights as W
+    from tests import fixtures as FX
     cores = host_cores()
 
     def det_rate(threads, batch, max_frames, budget):
@@ -228,7 +303,7 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
     # unclip - all on host threads; pinned to the reference's known answers by tests/test_oracle_postproc.py), one thread
     # and all cores, on the text-like maps the GPU leg uses
     from oracle import postproc_cpu as PC
-    maps = W.text_like_maps(32, size, 7)
+    maps = FX.text_like_maps(32, size, 7)
     ones = np.ones((32, 2))
     PC.get_boxes_and_box_scores(maps[:2], ones[:2], threads=1, skip_degenerate=True, counts_only=True)
 
@@ -259,17 +334,21 @@ def dry_run(a) -> None:
     if os.environ.get("OCR_BENCH_FAIL_RANK") == str(rank):
         sys.exit(3)  # test hook: a rank that dies must fail the launcher
     images = 0
+    masks = None
     if world > 1:
         dist.init_process_group("gloo")
         polys = [[[(rank, i), (rank + 1, i), (rank + 1, i + 1), (rank, i + 1)]] * (i % 3) for i in range(a.batch)]
         scores = [[0.9] * (i % 3) for i in range(a.batch)]
         all_p, _ = P.all_gather_results(polys, scores, torch.device("cpu"))
         images = len(all_p)
+        masks = [None] * world   # every rank's CPU mask as it stands after pin_rank (what the GPU run uses)
+        dist.all_gather_object(masks, sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         line = {"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "all_gather_results": {"images": images},
-                "cores_per_rank": int(os.environ.get("OCR_BENCH_CORES_PER_RANK") or max(1, host_cores() // world))}
+                "cores_per_rank": int(os.environ.get("OCR_BENCH_CORES_PER_RANK") or max(1, host_cores() // world)),
+                "rank_cpus": masks if world > 1 else None, "pinned": PINNED_CPUS is not None}
         if os.environ.get("OCR_BENCH_FAIL_EXCHANGE") == "1":   # test hook: the path a stalled / failed C-ABI exchange takes
             line["exchange_ok"] = False
             emit(line)
@@ -338,6 +417,13 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     reserve_stdout()
+    # a rank of N > 1 first moves onto its share of the host cores (nearest its GPU's NUMA node): before torch, the library or any pool
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    global PINNED_CPUS
+    # (the share is fixed BEFORE pinning - host_cores() reads the affinity mask - and kept in the environment for the later readers)
+    os.environ.setdefault("OCR_BENCH_CORES_PER_RANK", str(max(1, host_cores() // max(1, world_env))))
+    PINNED_CPUS = pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE") or world_env),
+                           int(os.environ["OCR_BENCH_CORES_PER_RANK"]))
     if a.dry_run:
         return dry_run(a)
 
@@ -347,6 +433,7 @@ def main():
     import ocr_rs_amd  # noqa: F401
     from ocr_rs_amd import capi
     from ocr_rs_amd import weights as W
+    from tests import fixtures as FX
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -587,7 +674,7 @@ def main():
     polys = scores = pm = adj = params = gathered = None
     try:
         params = capi.default_params(skip_degenerate=True)
-        maps = W.text_like_maps(n, s, seed=rank)
+        maps = FX.text_like_maps(n, s, seed=rank)
         pm = torch.from_numpy(maps).to(x.device)
         adj = np.ones((n, 2))
         torch.cuda.synchronize()
@@ -599,7 +686,7 @@ def main():
         post = {"postprocess_images_per_s": round(n * reps / (time.perf_counter() - t1), 1),
                 "postprocess_polygons_per_image": round(sum(len(p) for p in polys) / n, 2)}
         if rank == 0 and not a.no_extras:
-            dm = torch.from_numpy(W.dense_text_maps(n, s, 5)).to(x.device)
+            dm = torch.from_numpy(FX.dense_text_maps(n, s, 5)).to(x.device)
             npoly, _ = det.postprocess_counts(dm, n, s, s, adj, capi.MEM_DEVICE, params)
             t1 = time.perf_counter()
             for _ in range(reps):
@@ -943,6 +1030,7 @@ def main():
             line["det_options"] = a.det_options
         line["post_threads"] = min(16, cores_per_rank)
         line["cores_per_rank"] = cores_per_rank
+        line["rank_cpus"] = PINNED_CPUS   # N > 1: the CPUs this rank pinned itself to before any GPU call (nearest its GPU's NUMA node); None = unpinned
         if not a.no_cpu_baseline:   # every N: each line of a scaling sweep stands alone (the other ranks wait in the barrier below)
             try:
                 line["cpu_baseline"] = cpu_baseline(det_w, rec_w, s, a.cpu_seconds)

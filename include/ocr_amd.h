@@ -90,7 +90,10 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   overlap=0|1|2|3      (3)    second stream: 1 small independent launches; 2 the FPN branch as it stands; 3 the FPN's fused-Winograd
  *                               launches (lateral terms of p2 / p3) and bin_conv1's p2 term - f32 matrix instructions - beside layer2 / layer3 / layer4 /
  *                               the small FPN convs - bf16 matrix instructions and HBM-bound transforms: 2 % of the step in both precisions (default kernels;
- *                               otherwise, and under ocr_det_forward_profile, one stream).  Sums re-associate by one rounding
+ *                               otherwise, and under ocr_det_forward_profile, one stream).  Sums re-associate by one rounding.  Any other value is OCR_ERR_INVALID
+ *   w43_cus=<n>          (0)    tuning: size of the fused Winograd kernel's persistent grid in CUs (two workgroups each); 0 = every CU of the device.
+ *   w43_side_cus=<n>     (0)    the same for the fused Winograd launches that overlap=3 puts on the side stream; 0 = every CU.  Both 0..4096; any
+ *                               grid size gives the same bits (tests/test_gpu_conv_kernel.py)
  *   post_threads=<n>     (0)    host threads of the post-processing stages (contours, unclip), the calling thread included;
  *                               0 = min(16, CPU share of the process: cgroup quota or online cores).  One process per GPU on a
  *                               shared host should pass its share (cores / ranks)

@@ -76,13 +76,14 @@ struct ChainBuffers {
   int* totals() const { return reinterpret_cast<int*>(sc + o_hd); }
 };
 // Douglas-Peucker + job list, box scores, unclip of a batch whose contours are (or will be, stream order) in `cb`: everything on `s`
+// adj: host adjust values, uploaded here on `s` - or nullptr when the caller has already put them at o_adj of the slot (upload_adj below)
 static ChainBuffers enqueue_chain(ocr::Detector& det, int slot, const ContourBuffers& cb, const float* prob_dev, int n, int h, int w, const double* adj,
                                   const ocr_postproc_params_t& prm, hipStream_t s) {
   using namespace ocr;
   ChainBuffers ch(n);
   ch.sc = static_cast<char*>(det.scratch(slot, ch.total));
   const UnclipParams up{prm.box_thresh, prm.unclip_ratio, prm.min_size};
-  OCR_HIP(hipMemcpyAsync(ch.sc + ch.o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
+  if (adj) OCR_HIP(hipMemcpyAsync(ch.sc + ch.o_adj, adj, (size_t)n * 16, hipMemcpyHostToDevice, s));
   launch_candidates(reinterpret_cast<const int*>(cb.base + cb.o_hdr), reinterpret_cast<const uint32_t*>(cb.base + cb.o_pts), ContourBuffers::CAP,
                     reinterpret_cast<const int*>(cb.base + cb.o_st), ContourBuffers::MAXC, n, h, w, ch.sc + ch.o_cs, ch.jobs(), ch.max_jobs, ch.pts(), ch.max_pts,
                     reinterpret_cast<int*>(ch.sc + ch.o_tot), ch.totals(), s);
@@ -101,10 +102,22 @@ static void pretrace_pending(ocr::Detector& d) {
   Detector::Pending& p = d.pending();
   if (!contour_trace_fits(p.h, p.w)) return;
   hipStream_t ts = d.trace_stream();   // not the post-processing stream: crops of the batch that just came back must not queue behind this forward
+  const bool chain = d.device_polygons() && d.device_unclip() && p.h == p.w;
+  if (chain) {
+    // The adjust values do not depend on the forward: they go up FIRST, while the trace stream is idle (the batch that used scratch
+    // slot 4 before has been collected), from a pinned block.  Queued behind the wait for the forward from pageable memory the copy is
+    // staged and awaited on the host - this call would not return before forward k and its trace had finished, and the caller could
+    // not queue forward k + 1 behind forward k.
+    ChainBuffers ch(p.n);
+    ch.sc = static_cast<char*>(d.scratch(4, ch.total));
+    double* pin = static_cast<double*>(d.host_adj((size_t)p.n * 16));
+    std::memcpy(pin, p.adj.data(), (size_t)p.n * 16);
+    OCR_HIP(hipMemcpyAsync(ch.sc + ch.o_adj, pin, (size_t)p.n * 16, hipMemcpyHostToDevice, ts));
+  }
   OCR_HIP(hipStreamWaitEvent(ts, p.event, 0));
   const ContourBuffers cb = enqueue_contours(d, 3, p.prob, p.n, p.h, p.w, (float)p.params.thresh, ts);
-  if (d.device_polygons() && d.device_unclip() && p.h == p.w) {   // ... and the rest of the chain behind them: the call that comes back only collects
-    enqueue_chain(d, 4, cb, p.prob, p.n, p.h, p.w, p.adj.data(), p.params, ts);
+  if (chain) {   // ... and the rest of the chain behind them: the call that comes back only collects
+    enqueue_chain(d, 4, cb, p.prob, p.n, p.h, p.w, nullptr, p.params, ts);
     p.prechained = true;
   }
   OCR_HIP(hipEventRecord(d.trace_done_event(), ts));

@@ -249,7 +249,10 @@ void Detector::parse_options(const char* options) {
     else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
     else if (key == "phase_windows") phase_windows_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
-    else if (key == "overlap") overlap_ = num();
+    else if (key == "overlap") {
+      overlap_ = num();
+      if (overlap_ < 0 || overlap_ > 3) fail(OCR_ERR_INVALID, "detector option overlap: %d (0, 1, 2 or 3)", overlap_);
+    }
     else if (key == "w43_cus") {
       w43_cus_ = num();
       if (w43_cus_ < 0 || w43_cus_ > 4096) fail(OCR_ERR_INVALID, "detector option w43_cus: %d", w43_cus_);
@@ -575,6 +578,7 @@ Detector::~Detector() {
     if (ev) (void)hipEventDestroy(ev);
   free_workspace();
   if (host_scratch_) (void)hipHostFree(host_scratch_);
+  if (host_adj_) (void)hipHostFree(host_adj_);
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
   for (Staging& st : stage_)
@@ -696,6 +700,18 @@ void* Detector::host_scratch(size_t bytes) {
     host_scratch_bytes_ = want;
   }
   return host_scratch_;
+}
+
+void* Detector::host_adj(size_t bytes) {
+  if (bytes > host_adj_bytes_) {
+    if (host_adj_) OCR_HIP(hipHostFree(host_adj_));
+    host_adj_ = nullptr;
+    host_adj_bytes_ = 0;
+    const size_t want = bytes < 4096 ? 4096 : 2 * bytes;
+    OCR_HIP(hipHostMalloc(&host_adj_, want, hipHostMallocDefault));
+    host_adj_bytes_ = want;
+  }
+  return host_adj_;
 }
 
 void* Detector::scratch(int slot, size_t bytes) {

@@ -108,6 +108,8 @@ class Detector {
   void* scratch(int slot, size_t bytes);
   // growable PINNED host memory where the polygon chain's results land (one buffer per handle: a call collects before it returns)
   void* host_scratch(size_t bytes);
+  // pinned block for the adjust values of the batch a pipelined call leaves pending (its chain is queued with a really asynchronous upload)
+  void* host_adj(size_t bytes);
   // host threads of the post-processing stages (created on first use, one image per task)
   ThreadPool& pool();
   // ocr_det_detect_pipelined: the batch whose forward is in flight and whose post-processing is still owed
@@ -237,6 +239,8 @@ class Detector {
   int pipe_ev_next_ = 0;
   void* host_scratch_ = nullptr;
   size_t host_scratch_bytes_ = 0;
+  void* host_adj_ = nullptr;
+  size_t host_adj_bytes_ = 0;
   mutable int auto_threads_ = 0;   // min(16, CPU share), read once
   void* scratch_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes_[5] = {0, 0, 0, 0, 0};

@@ -364,8 +364,10 @@ double min_area_bounding_box(const std::vector<Pt>& pts, Pt res[4]) {
   res[1] = b[i2];
   res[2] = b[i3];
   res[3] = b[i4];
-  const double wl = std::hypot((double)res[0].x - res[1].x, (double)res[0].y - res[1].y);
-  const double hl = std::hypot((double)res[0].x - res[3].x, (double)res[0].y - res[3].y);
+  // geo's euclidean_length = libm's hypot (metrics.rs:145-146): the restatement pinned to the reference's environment
+  // (hypot_glibc.hpp, glibc 2.35 x86-64), the one definition host and device code share - not whatever libm is loaded here
+  const double wl = hypot_glibc((double)res[0].x - res[1].x, (double)res[0].y - res[1].y);
+  const double hl = hypot_glibc((double)res[0].x - res[3].x, (double)res[0].y - res[3].y);
   return std::min(wl, hl);
 }
 
@@ -390,7 +392,7 @@ double offset_distance(const std::vector<Pt>& poly, double factor) {  // polygon
   double per = 0.0;
   for (size_t i = 0; i < n; ++i) {
     const Pt &a = poly[i], &b = poly[(i + 1) % n];
-    per += std::hypot((double)(b.x - a.x), (double)(b.y - a.y));
+    per += hypot_glibc((double)(b.x - a.x), (double)(b.y - a.y));   // the same definition as unclip.hip: bit for bit on any host libm
   }
   return area * factor / per;
 }

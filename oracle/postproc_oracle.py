@@ -366,6 +366,32 @@ def min_area_rect(points: Sequence[Pt]) -> List[Pt]:
     ]
 
 
+def hypot_libm(x: float, y: float) -> float:
+    """libm's hypot as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/e_hypot.c, the branch without FMA that the x86-64 build
+    runs) for operands that need no scaling.  Rust's f64::hypot - what geo 0.15's euclidean_length calls
+    (/root/reference/src/polygon.rs:27, src/text_detection/metrics.rs:145-146) - is this routine, NOT CPython's math.hypot
+    (its own correctly rounded algorithm) and NOT sqrt(dx*dx + dy*dy): each differs from libm by an ulp on ~0.6 % of integer
+    pairs.  Every operation below is one separately rounded IEEE double operation, which is what Python floats give, so the
+    restatement reproduces libm bit for bit (tests/test_oracle_postproc.py checks it against libm.so.6 on 8.4 M integer pairs)."""
+    ax, ay = abs(x), abs(y)
+    if ax < ay:
+        ax, ay = ay, ax
+    if ay == 0.0:
+        return ax
+    h = math.sqrt(ax * ax + ay * ay)
+    if h <= 2.0 * ay:
+        delta = h - ay
+        t1 = ax * (2.0 * delta - ax)
+        t2 = (delta - 2.0 * (ax - ay)) * delta
+    else:
+        delta = h - ax
+        t1 = 2.0 * delta * (ax - 2.0 * ay)
+        t2 = (4.0 * delta - ay) * ay + delta * delta
+    h -= (t1 + t2) / (2.0 * h)
+    return h
+
+
+
 def get_min_area_bounding_box(contour: Sequence[Pt]) -> Tuple[List[Pt], float]:
     b = sorted(min_area_rect(contour), key=lambda p: p[0])  # stable, by x (metrics.rs:138)
     i1 = 0 if b[1][1] > b[0][1] else 1
@@ -373,8 +399,8 @@ def get_min_area_bounding_box(contour: Sequence[Pt]) -> Tuple[List[Pt], float]:
     i3 = 3 if b[3][1] > b[2][1] else 2
     i4 = 1 if b[1][1] > b[0][1] else 0
     res = [b[i1], b[i2], b[i3], b[i4]]
-    wlen = math.hypot(float(res[0][0]) - float(res[1][0]), float(res[0][1]) - float(res[1][1]))
-    hlen = math.hypot(float(res[0][0]) - float(res[3][0]), float(res[0][1]) - float(res[3][1]))
+    wlen = hypot_libm(float(res[0][0]) - float(res[1][0]), float(res[0][1]) - float(res[1][1]))
+    hlen = hypot_libm(float(res[0][0]) - float(res[3][0]), float(res[0][1]) - float(res[3][1]))
     return res, min(wlen, hlen)
 
 
@@ -403,7 +429,7 @@ def offset_distance(poly: Sequence[Pt], factor: float) -> float:
     per = 0.0
     for i in range(n):
         a, b = poly[i], poly[(i + 1) % n]
-        per += math.hypot(float(b[0] - a[0]), float(b[1] - a[1]))
+        per += hypot_libm(float(b[0] - a[0]), float(b[1] - a[1]))
     return area * factor / per
 
 

@@ -61,6 +61,49 @@ def test_world_8_rendezvous_and_core_shares():
     sys.path.insert(0, os.path.dirname(BENCH))
     import bench
     assert line["cores_per_rank"] == max(1, bench.host_cores() // 8)
+    # ... and has pinned itself to it: eight pairwise disjoint masks of that size (when the host has at least eight CPUs)
+    if len(os.sched_getaffinity(0)) >= 8:
+        masks = line["rank_cpus"]
+        assert line["pinned"] and len(masks) == 8
+        assert all(len(m) == line["cores_per_rank"] for m in masks), masks
+        assert len(set(c for m in masks for c in m)) == sum(len(m) for m in masks), masks
+
+
+def test_affinity_plan_follows_the_gpus_numa_nodes(tmp_path):
+    """plan_affinity / gpu_local_cpus on a made-up two-socket host (sysfs tree in a temp directory): 8 GPUs, four per NUMA node,
+    128 CPUs - each rank gets 16 CPUs of ITS GPU's node, all masks disjoint; without topology: contiguous slices."""
+    sys.path.insert(0, os.path.dirname(BENCH))
+    import bench
+    nodes = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for i in range(2):   # CPU nodes first, as KFD lists them
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    for g in range(8):
+        d = nodes / str(2 + g)
+        d.mkdir(parents=True)
+        bus = 0x10 + 0x10 * g
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndomain 0\nlocation_id {bus << 8}\n")
+        pci = tmp_path / "bus" / "pci" / "devices" / f"0000:{bus:02x}:00.0"
+        pci.mkdir(parents=True)
+        (pci / "local_cpulist").write_text("0-31,64-95\n" if g < 4 else "32-63,96-127\n")
+    old = {k: os.environ.pop(k, None) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES")}
+    try:
+        gpus = bench.gpu_local_cpus(str(tmp_path))
+    finally:
+        os.environ.update({k: v for k, v in old.items() if v is not None})
+    assert len(gpus) == 8 and gpus[0] == set(range(0, 32)) | set(range(64, 96)) and gpus[7] == set(range(32, 64)) | set(range(96, 128))
+    plan = bench.plan_affinity(8, range(128), 16, gpus)
+    assert all(len(m) == 16 for m in plan)
+    assert len(set(c for m in plan for c in m)) == 128
+    assert all(set(plan[r]) <= gpus[r] for r in range(8))
+    assert plan[0] == list(range(16)) and plan[4] == list(range(32, 48))
+    # unknown topology / a restricted mask: contiguous slices of what is allowed
+    plan = bench.plan_affinity(8, range(8, 40), 4, None)
+    assert plan == [list(range(8 + 4 * r, 12 + 4 * r)) for r in range(8)]
+    # a GPU whose node has too few free CPUs borrows from the rest, still disjoint
+    plan = bench.plan_affinity(2, range(8), 4, [{0, 1}, {0, 1}])
+    assert plan[0][:2] == [0, 1] and len(set(plan[0]) | set(plan[1])) == 8
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
 
 
 def test_failed_exchange_is_never_a_clean_exit():

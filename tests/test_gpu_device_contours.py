@@ -7,6 +7,7 @@ import pytest
 import ocr_rs_amd  # noqa: F401
 from ocr_rs_amd import capi
 from ocr_rs_amd import weights as W
+from tests import fixtures as FX
 from oracle import postproc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -37,10 +38,10 @@ def _cases():
     out.append(("checkerboard", ((np.add.outer(np.arange(64), np.arange(64))) % 2).astype(np.uint8)))
     out.append(("stripes", (np.arange(128)[None, :] % 3 == 0).astype(np.uint8).repeat(40, 0)))
     out.append(("diagonals", (np.add.outer(np.arange(96), np.arange(96)) % 7 < 2).astype(np.uint8)))
-    out.append(("text-like 640", (W.text_like_maps(1, 640, 3)[0, 0] > 0.6).astype(np.uint8)))
-    out.append(("dense 640", (W.dense_text_maps(1, 640, 4)[0, 0] > 0.6).astype(np.uint8)))
-    out.append(("text-like 640 b", (W.text_like_maps(1, 640, 13)[0, 0] > 0.6).astype(np.uint8)))
-    out.append(("dense 320", (W.dense_text_maps(1, 320, 14)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("text-like 640", (FX.text_like_maps(1, 640, 3)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("dense 640", (FX.dense_text_maps(1, 640, 4)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("text-like 640 b", (FX.text_like_maps(1, 640, 13)[0, 0] > 0.6).astype(np.uint8)))
+    out.append(("dense 320", (FX.dense_text_maps(1, 320, 14)[0, 0] > 0.6).astype(np.uint8)))
     return out
 
 
@@ -123,9 +124,9 @@ def test_postprocess_is_the_same_with_either_tracer():
     for _ in range(5):
         smooth = (smooth + np.roll(smooth, 1, 2) + np.roll(smooth, 1, 3) + np.roll(smooth, -1, 2) + np.roll(smooth, -1, 3)) / 5
     smooth = ((smooth - smooth.min()) / (smooth.max() - smooth.min())).astype(np.float32)
-    mixed = np.concatenate([W.dense_text_maps(2, 640, 7), noise[:1], W.text_like_maps(1, 640, 8)])
-    for name, maps in (("text", W.text_like_maps(4, 640, 1)), ("dense", W.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
-                       ("mixed", mixed), ("800", W.text_like_maps(1, 800, 9))):
+    mixed = np.concatenate([FX.dense_text_maps(2, 640, 7), noise[:1], FX.text_like_maps(1, 640, 8)])
+    for name, maps in (("text", FX.text_like_maps(4, 640, 1)), ("dense", FX.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
+                       ("mixed", mixed), ("800", FX.text_like_maps(1, 800, 9))):
         adj = np.ones((maps.shape[0], 2)) * np.array([1.25, 0.8])
         want = _post(host, maps, adj)
         for d in (dev, dev2, dev3, dev4):

@@ -6,6 +6,7 @@ import pytest
 import ocr_rs_amd  # noqa: F401
 from ocr_rs_amd import capi
 from ocr_rs_amd import weights as W
+from tests import fixtures as FX
 from oracle import postproc_oracle as O
 from oracle import torch_ref as T
 
@@ -63,7 +64,7 @@ def test_config0_800x800_default_dimensions(det, det_w):
 def test_postprocess_batch32_idempotent_and_order_free(det):
     """32 text-like 640x640 maps: results of a frame do not depend on its position in the batch, running
     twice gives identical blocks, and a sample of frames matches the oracle exactly."""
-    maps = W.text_like_maps(32, 640, seed=3)
+    maps = FX.text_like_maps(32, 640, seed=3)
     adj = np.tile(np.array([[1.25, 0.8]]), (32, 1))
     p = capi.default_params(skip_degenerate=True)
     polys, scores = det.postprocess(maps, 32, 640, 640, adj, capi.MEM_HOST, p)

@@ -11,6 +11,7 @@ import pytest
 import ocr_rs_amd  # noqa: F401
 from ocr_rs_amd import capi
 from ocr_rs_amd import weights as W
+from tests import fixtures as FX
 from oracle import postproc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -116,7 +117,7 @@ def test_real_candidates_are_settled_on_the_device_and_equal_the_host(det):
     every concave vertex makes the miter offset loop, and such rings are the host union's): all of what the device settles equals the
     host, and word boxes ARE settled there"""
     rng = np.random.default_rng(20)
-    for name, maps, most in (("dense", W.dense_text_maps(6, 640, 31), 0.9), ("text-like", W.text_like_maps(8, 800, 32), 0.2)):
+    for name, maps, most in (("dense", FX.dense_text_maps(6, 640, 31), 0.9), ("text-like", FX.text_like_maps(8, 800, 32), 0.2)):
         polys = _real_candidates(maps)
         assert len(polys) > 20, name
         scores = rng.uniform(0.65, 1.0, len(polys))
@@ -192,8 +193,8 @@ def test_postprocess_is_the_same_with_and_without_the_device_unclip():
     smooth = ((m - m.min()) / (m.max() - m.min())).astype(np.float32)
     smooth = np.clip((smooth - 0.5) * 6 + 0.55, 0, 1).astype(np.float32)
     total = 0
-    for name, maps in (("text", W.text_like_maps(4, 640, 1)), ("dense", W.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
-                       ("800", W.text_like_maps(1, 800, 9))):
+    for name, maps in (("text", FX.text_like_maps(4, 640, 1)), ("dense", FX.dense_text_maps(4, 640, 2)), ("noise", noise), ("smooth", smooth),
+                       ("800", FX.text_like_maps(1, 800, 9))):
         n = maps.shape[0]
         for adj in (np.ones((n, 2)), np.tile([[0.8, 0.53125]], (n, 1))):
             a = _post(dev, maps, adj)
@@ -249,7 +250,7 @@ def _random_maps(rng, n, s):
                 d = np.hypot(xx - cx, yy - cy)
                 m = np.where((d >= r0) & (d <= r0 + r1), rng.uniform(0.65, 0.95), m)
         elif s >= 128:
-            m = W.dense_text_maps(1, s, int(rng.integers(0, 1 << 30)))[0, 0]
+            m = FX.dense_text_maps(1, s, int(rng.integers(0, 1 << 30)))[0, 0]
         if rng.random() < 0.3:
             m = np.where(rng.random((s, s)) < 0.002, 0.9, m)
         maps[i, 0] = m

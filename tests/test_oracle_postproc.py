@@ -87,3 +87,30 @@ def test_compiled_cpu_postprocess_matches_python_oracle_on_real_valued_maps(gold
     for a, b in zip(got_s, want_s):
         assert np.allclose(a, b, rtol=0, atol=1e-12)
     assert cpu_lib.get_boxes_and_box_scores(pred, adj, threads=2, counts_only=True)[0] == sum(len(p) for p in want_p)
+
+
+def test_oracle_hypot_is_libm_hypot():
+    """The reference sums a polygon's perimeter and measures the box sides with Rust's f64::hypot = libm's
+    (/root/reference/src/polygon.rs:27, src/text_detection/metrics.rs:145-146, geo 0.15 euclidean_length).  The oracle's
+    restatement (O.hypot_libm) against libm.so.6 itself on every integer pair 0 <= b <= a <= 4100 (8.4 M pairs: the range of
+    edge vectors an 800 x 800 .. 4096 x 4096 map can hold), and the evidence that the distinction matters: CPython's math.hypot
+    and sqrt(a^2 + b^2) each differ from libm on some of them."""
+    import ctypes as C
+    import math
+    libm = C.CDLL("libm.so.6")
+    libm.hypot.restype = C.c_double
+    libm.hypot.argtypes = [C.c_double, C.c_double]
+    lh, oh = libm.hypot, O.hypot_libm
+    bad = n = 0
+    for a in range(0, 4101):
+        fa = float(a)
+        for b in range(0, a + 1):
+            n += 1
+            if oh(fa, float(b)) != lh(fa, float(b)):
+                bad += 1
+    assert n == 4101 * 4102 // 2 and bad == 0
+    # argument order / signs (the kernel orders by magnitude itself)
+    for a, b in ((3, -4), (-4, 3), (-5, -12), (0, -7), (-7, 0), (1234, -4099)):
+        assert oh(float(a), float(b)) == lh(float(a), float(b)) == oh(float(b), float(a))
+    assert any(lh(float(a), float(b)) != math.sqrt(a * a + b * b) for a in range(1, 300) for b in range(1, a))
+    assert any(lh(float(a), float(b)) != math.hypot(float(a), float(b)) for a in range(1, 600) for b in range(1, a))

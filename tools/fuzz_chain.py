@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ocr_rs_amd  # noqa
 from ocr_rs_amd import capi, weights as W
+from tests import fixtures as FX
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 blob = W.pack_blob(W.make_det_weights(0))
 host = capi.Detector(blob, 0, options="device_contours=0;device_unclip=0;post_threads=8")
@@ -42,7 +43,7 @@ for b in range(nb):
                 d = np.hypot(xx - cx, yy - cy)
                 m = np.where((d >= r0) & (d <= r0 + r1), rng.uniform(0.65, 0.95), m)
         else:              # text-like
-            m = W.dense_text_maps(1, s, int(rng.integers(0, 1 << 30)))[0, 0] if s >= 128 else m
+            m = FX.dense_text_maps(1, s, int(rng.integers(0, 1 << 30)))[0, 0] if s >= 128 else m
         if rng.random() < 0.3:
             m = np.where(rng.random((s, s)) < 0.002, 0.9, m)   # speckle
         maps[i, 0] = m

@@ -6,13 +6,14 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import ocr_rs_amd  # noqa
 from ocr_rs_amd import capi, weights as W
+from tests import fixtures as FX
 pt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 extra = sys.argv[2] if len(sys.argv) > 2 else ""
 det = capi.Detector(W.pack_blob(W.make_det_weights(0)), 0, options=f"post_threads={pt};{extra}")
 n, s = 32, 640
 params = capi.default_params(skip_degenerate=True)
 adj = np.ones((n, 2))
-for name, maps in (("text-like", W.text_like_maps(n, s, 0)), ("dense", W.dense_text_maps(n, s, 5))):
+for name, maps in (("text-like", FX.text_like_maps(n, s, 0)), ("dense", FX.dense_text_maps(n, s, 5))):
     pm = torch.from_numpy(maps).cuda(); torch.cuda.synchronize()
     polys, _ = det.postprocess(pm, n, s, s, adj, capi.MEM_DEVICE, params)
     best = 1e9
