@@ -58,6 +58,33 @@ class Polygons(C.Structure):
 
 
 _lib = None
+_hip_shared = False
+
+
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7) and libhsa-runtime64.so and
+    link to them by FILE name; libocr_amd.so needs `libamdhip64.so.7`.  Loaded after torch, the library binds to torch's copy (the SONAME
+    matches) and the process has one runtime.  Loaded BEFORE torch, it brings /opt/rocm's copy in, torch then loads its own beside it (its
+    NEEDED name matches no loaded SONAME) and the second runtime finds the device taken: torch's lazy init fails with "No HIP GPUs are
+    available".  So this harness loads torch's copy first when a torch installation exists and has not been imported yet - without
+    importing torch.  (A host that does not use torch - the Rust / C++ caller of INTEGRATION.md - has one runtime anyway.)"""
+    global _hip_shared
+    if _hip_shared:
+        return
+    _hip_shared = True
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:   # no torch, or an unusual layout: nothing to share
+        pass
 
 
 def lib() -> C.CDLL:
@@ -67,6 +94,7 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise OcrError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.ocr_last_error.restype = C.c_char_p
         L.ocr_version.restype = C.c_char_p
@@ -151,6 +179,7 @@ def test_lib() -> C.CDLL:
         lib()
         if not os.path.exists(TEST_LIB_PATH):
             raise OcrError(-1, f"{TEST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _share_torch_hip_runtime()
         L = C.CDLL(TEST_LIB_PATH)
         L.ocr_test_contour_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int, C.POINTER(C.c_int)]
