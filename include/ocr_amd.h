@@ -238,6 +238,12 @@ int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, 
                         const double* adj_xy, const ocr_postproc_params_t* params,
                         ocr_polygons_t** out);
 void ocr_polygons_free(ocr_polygons_t* p);
+/* Where the polygon chain of this handle's post-processing calls ran so far (cumulative counters; diagnostic - the reference has no
+ * counterpart, get_boxes_and_box_scores metrics.rs:37-127 runs on one core): out[0] images whose contours were traced on the GPU,
+ * out[1] images traced on the host (device_contours off, a map the tracer does not take, an image it gave up), out[2] candidate polygons
+ * the device unclip settled, out[3] candidates finished on the host, out[4] images whose whole chain - trace, Douglas-Peucker, box
+ * score, unclip - stayed on the device, out[5] post-processing passes.  Results never depend on where a step ran. */
+int ocr_det_post_stats(ocr_det_t* det, int64_t out[6]);
 
 /* forward_t + get_boxes_and_box_scores over a STREAM of batches, software-pipelined inside the library: the call
  * enqueues the forward of THIS batch (device pointers; x_dev N x 1 x H x W f32 -> prob_dev, which must stay untouched

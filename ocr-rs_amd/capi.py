@@ -26,7 +26,7 @@ EXPORTS = [
     "ocr_det_create", "ocr_det_create_with_options", "ocr_det_destroy", "ocr_det_set_stream", "ocr_det_set_precision", "ocr_det_forward",
     "ocr_det_forward_u8", "ocr_host_alloc", "ocr_host_free", "ocr_det_detect_pipelined_host",
     "ocr_det_forward_async", "ocr_det_synchronize", "ocr_det_forward_profile",
-    "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_det_detect_pipelined", "ocr_polygons_free",
+    "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_det_post_stats", "ocr_det_detect_pipelined", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_set_options", "ocr_rec_synchronize",
     "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet",
@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
                                            C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.ocr_postproc_default_params.argtypes = [C.POINTER(PostprocParams)]
         L.ocr_postproc_default_params.restype = None
+        L.ocr_det_post_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.ocr_det_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(PostprocParams),
                                           C.POINTER(C.POINTER(Polygons))]
@@ -462,6 +463,21 @@ class Detector:
                                            p(out), p(out2)))
         return out, out2
 
+    def debug_gemm_batched(self, x_bmk, w_bnk, variant=2, scale=None, bias=None, relu=False):
+        """B independent GEMMs out[b] = x[b] @ w[b].T through conv_igemm's batched 1x1 mode (test hook; what the Winograd GEMMs of layer3 /
+        layer4 launch): x B x M x K, w B x N x K -> B x M x N.  variant 0 f32 MFMA, 2 split-bf16 128-wide tiles, 3 the 256 x 128 form."""
+        x = np.ascontiguousarray(x_bmk, dtype=np.float32)
+        wg = np.ascontiguousarray(w_bnk, dtype=np.float32)
+        b, m, k = x.shape
+        _, nn, _ = wg.shape
+        out = np.empty((b, m, nn), np.float32)
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        sc, bi = f(scale), f(bias)
+        p = lambda a: None if a is None else _ptr(a)
+        check(test_lib().ocr_test_conv_run(self._h, 0, 0, _ptr(x), 1, 1, m, k, _ptr(wg), nn, 1, 1, p(sc), p(bi), None, None, int(relu), 0,
+                                           int(variant) | (b << 8), _ptr(out), None))
+        return out
+
     def debug_winograd_conv(self, x_nhwc, wgt_ohwi, scale=None, bias=None, residual=None, relu=False, unfused=False):
         """3x3 s1 p1 conv through the Winograd path on caller data (test hook): N x H x W x Cout f32."""
         f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
@@ -544,6 +560,13 @@ class Detector:
             return out.contents.n_polygons, out.contents.n_vertices
         finally:
             lib().ocr_polygons_free(out)
+
+    def post_stats(self) -> dict:
+        """Cumulative counters of where this handle's polygon chain ran (ocr_det_post_stats)."""
+        a = (C.c_int64 * 6)()
+        check(lib().ocr_det_post_stats(self._h, a))
+        return dict(zip(("images_device_traced", "images_host_traced", "candidates_device", "candidates_host", "images_device_chain", "passes"),
+                        (int(v) for v in a)))
 
     def postprocess(self, prob, n: int, h: int, w: int, adjust_values: np.ndarray, mem_kind: int = MEM_HOST,
                     params: Optional[PostprocParams] = None):
@@ -750,6 +773,28 @@ def device_contours(bitmap01: np.ndarray, max_pts: int = 1 << 20, max_polys: int
     L = test_lib()
     L.ocr_test_device_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     return _contours_call(L.ocr_test_device_contours, bitmap01, True, max_pts, max_polys, tail=(int(sequential),))
+
+
+def device_candidates(contours, h: int, w: int, max_pts: int = 1 << 18, max_polys: int = 1 << 14):
+    """candidates.hip on the given contours of one h x w map (lists of (x, y)): the candidate polygons after arc length, Douglas-Peucker
+    and the >= 4 points filter, in list order, and their clamped job boxes (min_x, min_y, bw, bh)."""
+    L = test_lib()
+    L.ocr_test_device_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.POINTER(C.c_int)]
+    lens = np.asarray([len(c) for c in contours] or [0], np.int32)
+    flat = np.asarray([v for c in contours for q in c for v in q] or [0, 0], np.int32)
+    xy = np.empty(2 * max_pts, np.int32)
+    cnt = np.empty(max_polys, np.int32)
+    box = np.empty(4 * max_polys, np.int32)
+    n = C.c_int(0)
+    check(L.ocr_test_device_candidates(_ptr(flat), _ptr(lens), len(contours), h, w, _ptr(xy), _ptr(cnt), _ptr(box), max_pts, max_polys, C.byref(n)))
+    out, boxes, pos = [], [], 0
+    for k in range(n.value):
+        c = int(cnt[k])
+        out.append([(int(xy[2 * (pos + i)]), int(xy[2 * (pos + i) + 1])) for i in range(c)])
+        boxes.append(tuple(int(v) for v in box[4 * k:4 * k + 4]))
+        pos += c
+    return out, boxes
 
 
 def host_expand_polygon(pts: Sequence[Tuple[int, int]], factor: float = 2.0):

@@ -250,6 +250,12 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
         first_job[n] = at;
         if (at != tj) fail(OCR_ERR_INTERNAL, "postprocess: device job list holds %d jobs, its image table %d", tj, at);
       }
+      for (int b = 0; b < n; ++b)
+        if (tot[2 * b] >= 0) {
+          ++det.post_stats[0];
+          ++det.post_stats[4];
+        }
+      for (int j = 0; j < tj; ++j) ++det.post_stats[ustatus[j] == UNCLIP_HOST ? 3 : 2];
       pool.parallel_for(n, [&](int b) {
         std::vector<geom::Pt> c;
         for (int j = first_job[b]; j < first_job[b + 1]; ++j) {
@@ -268,6 +274,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
       for (int b : todo) OCR_HIP(hipMemcpyAsync(bits.data() + (size_t)b * wpi, bits_dev + (size_t)b * wpi, wpi * 4, hipMemcpyDeviceToHost, s));
       OCR_HIP(hipStreamSynchronize(s));
       pool.parallel_for((int)todo.size(), [&](int k) { geom::contour_candidates_bits(bits.data() + (size_t)todo[k] * wpi, h, w, cands[todo[k]]); });
+      det.post_stats[1] += (long long)todo.size();
     }
   } else if (dev_trace) {
     // contour tracing on the device (contours.hip), Douglas-Peucker on the pool.  An image the device gives up on (buffers too
@@ -309,6 +316,8 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
       if (hdr[4 * b + 2] == 0) geom::contour_candidates_packed(cpts.data() + p_at[b], clens.data() + c_at[b], hdr[4 * b], cands[b]);
       else geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]);
     });
+    det.post_stats[0] += n - failed;
+    det.post_stats[1] += failed;
     for (int b = 0; b < n; ++b) todo.push_back(b);
   } else {
     launch_binarize_pack(prob_dev, bits_dev, (float)prm.thresh, n, hw, s);  // metrics.rs:41,129
@@ -321,6 +330,7 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
     // contour tracing + Douglas-Peucker (metrics.rs:78-98)
     pool.parallel_for(n, [&](int b) { geom::contour_candidates_bits(bits.data() + (size_t)b * wpi, h, w, cands[b]); });
     for (int b = 0; b < n; ++b) todo.push_back(b);
+    det.post_stats[1] += n;
   }
 #ifdef POSTPROC_TIMING
   if (!dev_chain) T2 = tnow();
@@ -405,6 +415,8 @@ void postprocess(ocr::Detector& det, const float* prob, int n, int h, int w, int
   T3 = tnow();
 #endif
 
+  ++det.post_stats[5];
+  for (int j = 0; j < nj; ++j) ++det.post_stats[(dev_unclip && ustatus[j] != UNCLIP_HOST) ? 2 : 3];
   // what the device did not settle - filters + unclip + coordinate adjustment (metrics.rs:100-123) - per image on the pool
   pool.parallel_for((int)todo.size(), [&](int k) {
     const int b = todo[k];
@@ -708,6 +720,13 @@ int ocr_det_postprocess(ocr_det_t* det, const float* prob, int n, int h, int w, 
     if (params) prm = *params;
     if (out) *out = nullptr;
     postprocess(det->impl, prob, n, h, w, mem_kind, adj, prm, out, det->impl.stream());
+  });
+}
+
+int ocr_det_post_stats(ocr_det_t* det, int64_t out[6]) {
+  return guard([&] {
+    if (!det || !out) ocr::fail(OCR_ERR_INVALID, "det_post_stats: null argument");
+    for (int i = 0; i < 6; ++i) out[i] = (int64_t)det->impl.post_stats[i];
   });
 }
 

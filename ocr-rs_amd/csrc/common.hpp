@@ -74,6 +74,7 @@ struct ConvDesc {
                           // neighbour, as 128-column tiles of 2 x 2 / 1 x 2 / 2 x 1 phase blocks; 2 = the four corner phases (0 | 7, 0 | 7)
   int win;                // STORE_PHASE with up 2, Cout 64 (x3 or bf16 operands): the GEMM's rows are the (Hin + 1) x (Win + 1) 2 x 2 windows of the low-res grid and the four
                           // phases that read a window are the four 64-column groups of one 128-wide pair of tiles (same products, same order)
+  int wide;               // x3: take the 256 x 128 persistent form (conv_x3w.hip) where it exists for the launch - same bits
   const void* wgt;
   const float* scale;     // per output column, may be null (then scale 1 / bias 0); always f32
   const float* bias;
@@ -89,6 +90,10 @@ struct ConvDesc {
 };
 
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s);
+// conv_x3w.hip: the split-bf16 convs with NHWC stores and Cout a multiple of 128 as 256 x 128 tiles on one persistent workgroup per CU
+// (bit-identical to conv_igemm's 128-wide split-bf16 tiles); `cus` = CUs of the device
+bool conv_x3_wide_applicable(const ConvDesc& d);
+void launch_conv_x3_wide(const ConvDesc& d, int cus, hipStream_t s);
 // hi / mid / lo bf16 planes of an f32 weight array whose rows are multiples of 16 long ([3][count] bf16; inside every
 // aligned group of 16 the k order is the one the split-bf16 kernel's A fragments have: 0-3, 8-11, 4-7, 12-15)
 std::vector<uint16_t> split3_weights(const float* w, size_t count);

@@ -247,6 +247,10 @@ __device__ int row_starts(const uint32_t* bits, int h, int w, int y, int* out) {
   }
   return n;
 }
+// Pool entry of a walked point: x in bits 0-11, y in bits 12-27, bit 28 = the pixel is the FIRST of its row's run (W neighbour background or
+// x == 0), bit 29 = the LAST of its run (E neighbour background or x + 1 == w), bit 31 = this visit leaves the pixel negative.  The two run
+// flags are what lets the scan keep ONE label bit per pixel (see the kernel): they come for free from the neighbourhood the walk reads anyway.
+constexpr uint32_t kPtRunStart = 1u << 28, kPtRunEnd = 1u << 29, kPtNeg = 1u << 31;
 // one border walked by one lane: its length (-1: longer than limit); with out != nullptr the points too
 __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int start, uint32_t* out, int limit) {
   auto fg = [&](unsigned i) -> unsigned { return (bits[i >> 5] >> (i & 31)) & 1u; };
@@ -267,8 +271,8 @@ __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int
       found = true;
     }
   }
-  if (!found) {
-    if (out) out[0] = ((uint32_t)y << 16) | (uint32_t)x | 0x80000000u;
+  if (!found) {   // an isolated pixel: a run of its own
+    if (out) out[0] = ((uint32_t)y << 12) | (uint32_t)x | kPtNeg | kPtRunStart | kPtRunEnd;
     return 1;
   }
   int p3x = x, p3y = y, base = d1, n = 0;
@@ -277,6 +281,7 @@ __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int
     const unsigned i3 = (unsigned)p3y * w + p3x;
     int dn = 0;
     bool right_edge = false;
+    uint32_t run = 0;
     if (p3x > 0 && p3y > 0 && p3x + 1 < w && p3y + 1 < h) {
       const unsigned top = get3(i3 - w - 1), mid = get3(i3 - 1), bot = get3(i3 + w - 1);
       const unsigned m = (mid & 1u) | (top & 1u) << 1 | (top & 2u) << 1 | (top & 4u) << 1 | (mid & 4u) << 2 | (bot & 4u) << 3 | (bot & 2u) << 5 | (bot & 1u) << 7;
@@ -284,6 +289,7 @@ __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int
       const int j = 31 - __builtin_clz(r);
       dn = (base + j) & 7;
       right_edge = ((4 - base) & 7) > j;
+      run = ((mid & 1u) ? 0u : kPtRunStart) | ((mid & 4u) ? 0u : kPtRunEnd);
     } else {
       for (int k = 1; k <= 8; ++k) {
         const int d = (base - k) & 7;
@@ -293,8 +299,9 @@ __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int
         }
         if (d == 4) right_edge = true;
       }
+      run = (nz(p3x - 1, p3y) ? 0u : kPtRunStart) | (nz(p3x + 1, p3y) ? 0u : kPtRunEnd);
     }
-    if (out) out[n] = ((uint32_t)p3y << 16) | (uint32_t)p3x | ((p3x + 1 == w || right_edge) ? 0x80000000u : 0u);
+    if (out) out[n] = ((uint32_t)p3y << 12) | (uint32_t)p3x | run | ((p3x + 1 == w || right_edge) ? kPtNeg : 0u);
     ++n;
     const int p4x = p3x + ddx(dn), p4y = p3y + ddy(dn);
     if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
@@ -305,23 +312,31 @@ __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int
   return n;
 }
 
+// LDS of the parallel form: ONE plane of a bit per pixel (+ a word), used twice - the bit image while the plausible starts are walked
+// (phase A: random access, LDS latency), then, zeroed, the label plane of the raster scan (phase B), whose foreground rows stream in from
+// global memory through a small band buffer behind the plane.  One label bit per pixel is enough because the scan only ever asks
+// "has a border passed" at the FIRST pixel of a run and "was it left negative" at the LAST pixel of a run:
+//     pixel is first of its run:            its bit = a border has passed
+//     last of its run, not first:           its bit = left negative
+//     first AND last (a one-pixel run):     the bit of the background pixel to its right = left negative
+// (that pixel is in the row - the scan never asks about the last column - and nobody else's bit).  A 640 x 640 map needs 55 KB instead of the
+// three planes' 150 KB, the reference's own 800 x 800 frames (/root/reference/src/text_detection/mod.rs:20-21) fit with 85 KB, and the CU keeps
+// room for the next forward's workgroups beside the tracer.
+constexpr int kBandRows = 64;
+template <int LW>
 __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* __restrict__ bits_all, int wpi, int h, int w, uint32_t* __restrict__ pts_all, int cap,
                                                               int* __restrict__ starts_all, int maxc, int* __restrict__ hdr_all, int* __restrict__ spec_all,
                                                               uint32_t* __restrict__ pool_all, int pool_cap) {
-  __shared__ uint32_t lds[kLdsWords];
+  __shared__ uint32_t lds[LW];
   __shared__ int sc[1024];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned npx = (unsigned)h * (unsigned)w, nw = (npx + 31) / 32;
-  uint32_t* bits = lds;
-  volatile uint32_t* seen = lds + nw + 1;
-  volatile uint32_t* neg = lds + 2 * nw + 1;
+  uint32_t* bits = lds;                        // phase A: nw + 1 words (get3 reads the word behind as well)
+  volatile uint32_t* lab = lds;                // phase B: the label plane, same words
+  volatile uint32_t* band = lds + nw + 1;      // phase B: kBandRows rows of the bit image
   const uint32_t* g = bits_all + (size_t)img * wpi;
-  for (unsigned i = tid; i < nw; i += 1024) {
-    bits[i] = g[i];
-    seen[i] = 0;
-    neg[i] = 0;
-  }
+  for (unsigned i = tid; i < nw; i += 1024) bits[i] = g[i];
   if (tid == 0) bits[nw] = 0;
   __syncthreads();
   int* keys = spec_all + (size_t)img * 3 * kMaxStarts;
@@ -392,6 +407,9 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
       walk_border(bits, h, w, px % w, px / w, (key & 1) ? 4 : 0, pool + roff[k], guard);
     }
   __syncthreads();
+  // the plane becomes the label plane
+  for (unsigned i = tid; i <= nw; i += 1024) lds[i] = 0;
+  __syncthreads();
   if (wave != 0) return;
   // ---- B: the raster scan with the label tests; borders come from the list
   uint32_t* pts = pts_all + (size_t)img * cap;
@@ -399,20 +417,28 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
   int ncont = 0, npts = 0, ka = 0;
   const int wr = w >> 5;
   for (int y = 0; y < h && !status; ++y) {
+    const int yb = y & ~(kBandRows - 1);
+    if (y == yb) {   // the next band of foreground rows: coalesced, every load in flight at once
+      const int words = min(kBandRows, h - yb) * wr;
+      const uint32_t* src = g + (size_t)yb * wr;
+      for (int i = lane; i < words; i += 64) band[i] = src[i];
+      __builtin_amdgcn_wave_barrier();   // (LDS serves a wave's operations in order: the reads below see these writes)
+    }
     // A pixel can start a border only at the first pixel of a run (outer border: label still clear, W neighbour zero) or at its last
-    // (hole border: not negative, E neighbour zero).  Both tests are word-wide bit arithmetic on the row's foreground, `seen` and `neg`
+    // (hole border: not negative, E neighbour zero).  Both tests are word-wide bit arithmetic on the row's foreground and label
     // words, one word per lane: the scan only stops at pixels that DO start a border (a few dozen per image) instead of stepping through
     // every run boundary (a few thousand, five dependent LDS reads each: that walk was most of the kernel).  A border traced in this row
     // changes the labels of pixels further right, so the masks are rebuilt after every trace, for x beyond it.
-    uint32_t rs = 0, re = 0;
+    uint32_t rsf = 0, rs = 0, re = 0;
     const size_t rw = (size_t)y * wr + lane;
     if (lane < wr) {
-      const uint32_t* row = bits + (size_t)y * wr;
+      const volatile uint32_t* row = band + (size_t)(y - yb) * wr;
       const uint32_t cur = row[lane];
       const uint32_t lbit = lane > 0 ? row[lane - 1] >> 31 : 0u;
       const uint32_t rbit = lane + 1 < wr ? row[lane + 1] & 1u : 0u;
-      rs = cur & ~((cur << 1) | lbit);            // first pixels of runs
+      rsf = cur & ~((cur << 1) | lbit);           // first pixels of runs
       re = cur & ~((cur >> 1) | (rbit << 31));    // last pixels of runs
+      rs = rsf;
       if (lane == 0) rs &= ~1u;                   // x > 0
       if (lane == wr - 1) re &= ~(1u << 31);      // x + 1 < w
     }
@@ -421,8 +447,11 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
     while (!status) {
       uint32_t t0 = 0, t1 = 0;
       if (lane < wr) {
-        const uint32_t sw = seen[rw], ng = neg[rw];
-        t0 = rs & ~sw;                            // value == 1 and the W neighbour is zero: outer border start
+        const uint32_t lw = lab[rw];
+        const uint32_t ln = lane + 1 < wr ? lab[rw + 1] & 1u : 0u;
+        t0 = rs & ~lw;                            // value == 1 and the W neighbour is zero: outer border start
+        // left negative: the pixel's own bit, or - for a one-pixel run, whose own bit says "passed" - the bit to its right
+        const uint32_t ng = (lw & ~rsf) | (((lw >> 1) | (ln << 31)) & rsf);
         t1 = re & ~ng & ~t0;                      // else value > 0 and the E neighbour is zero: hole border start
         const int lo = xmin - 32 * lane;          // only pixels at or beyond xmin
         const uint32_t keep = lo <= 0 ? ~0u : lo >= 32 ? 0u : ~0u << lo;
@@ -453,10 +482,14 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
       ++ncont;
       for (int q = lane; q < len; q += 64) {
         const uint32_t p = pool[off + q];
-        const unsigned pi = ((p >> 16) & 0x7fffu) * (unsigned)w + (p & 0xffffu);
-        atomicOr(const_cast<uint32_t*>(seen) + (pi >> 5), 1u << (pi & 31));
-        if (p >> 31) atomicOr(const_cast<uint32_t*>(neg) + (pi >> 5), 1u << (pi & 31));
-        pts[npts + q] = p & 0x7fffffffu;
+        const unsigned px = p & 0xfffu, py = (p >> 12) & 0xffffu;
+        const unsigned pi = py * (unsigned)w + px;
+        if (p & kPtRunStart) atomicOr(const_cast<uint32_t*>(lab) + (pi >> 5), 1u << (pi & 31));
+        if ((p & kPtNeg) && (p & kPtRunEnd) && px + 1 < (unsigned)w) {
+          const unsigned j = (p & kPtRunStart) ? pi + 1 : pi;
+          atomicOr(const_cast<uint32_t*>(lab) + (j >> 5), 1u << (j & 31));
+        }
+        pts[npts + q] = (py << 16) | px;
       }
       npts += len;
       __builtin_amdgcn_wave_barrier();   // the label ORs of every lane are issued before the masks are read again (LDS serves a wave in order)
@@ -492,26 +525,39 @@ __global__ __launch_bounds__(256) void contour_compact_kernel(const int* __restr
 
 }  // namespace
 
-bool contour_trace_fits(int h, int w) {
-  if (h <= 0 || w <= 0 || (w & 31) || w > 2048 || h > 32767) return false;
-  const size_t nw = ((size_t)h * w + 31) / 32;
-  return 3 * nw + 1 <= (size_t)kLdsWords;
-}
+// LDS words of the parallel form for an h x w map: the plane, its extra word, the band buffer
+static size_t parallel_words(int h, int w) { return ((size_t)h * w + 31) / 32 + 1 + (size_t)kBandRows * (w >> 5); }
+static bool shape_ok(int h, int w) { return h > 0 && w > 0 && !(w & 31) && w <= 2048 && h <= 32767; }
+// the one-wave form keeps the bit image and two label planes in LDS
+static bool sequential_fits(int h, int w) { return shape_ok(h, w) && 3 * (((size_t)h * w + 31) / 32) + 1 <= (size_t)kLdsWords; }
+static bool parallel_fits(int h, int w) { return shape_ok(h, w) && h <= 1024 && w <= 2047 + 1 && parallel_words(h, w) <= (size_t)kLdsWords; }
+
+bool contour_trace_fits(int h, int w) { return parallel_fits(h, w) || sequential_fits(h, w); }
 
 size_t contour_spec_bytes(int n) { return (size_t)n * (3 * (size_t)kMaxStarts * 4 + (size_t)kContourPool * 4); }
 
 void launch_contour_trace(const uint32_t* bits, size_t words_per_image, int n, int h, int w, uint32_t* pts, int cap, int* starts, int maxc, int* hdr,
                           uint32_t* pts_packed, int* lens_packed, void* spec, int sequential, hipStream_t s) {
   if (n <= 0) return;
-  if (!contour_trace_fits(h, w)) fail(OCR_ERR_INTERNAL, "contour_trace: a %dx%d map does not fit the wave's LDS", h, w);
+  if (!contour_trace_fits(h, w)) fail(OCR_ERR_INTERNAL, "contour_trace: a %dx%d map does not fit a CU's LDS", h, w);
   if (cap <= 0 || maxc <= 0 || words_per_image > 0x7fffffffu) fail(OCR_ERR_INTERNAL, "contour_trace: bad capacities");
-  if (sequential || h > 1024 || !spec) {
+  if (words_per_image < ((size_t)h * w + 31) / 32) fail(OCR_ERR_INTERNAL, "contour_trace: %zu words per image for a %dx%d map", words_per_image, h, w);
+  // the parallel form unless the one-wave form was asked for (and the map fits its three planes), or only the one-wave form takes the shape
+  const bool par = spec && parallel_fits(h, w) && !(sequential && sequential_fits(h, w));
+  if (!par) {
+    if (!sequential_fits(h, w)) fail(OCR_ERR_INTERNAL, "contour_trace: a %dx%d map needs the parallel form's scratch", h, w);
     hipLaunchKernelGGL(contour_trace_kernel, dim3((unsigned)n), dim3(64), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr);
   } else {
     int* spec_i = static_cast<int*>(spec);
     uint32_t* pool = reinterpret_cast<uint32_t*>(spec_i + (size_t)n * 3 * kMaxStarts);
-    hipLaunchKernelGGL(contour_parallel_kernel, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool,
-                       kContourPool);
+    // the smallest LDS footprint that holds the map: 56 KB up to 640 x 640, 88 KB up to 800 x 800, else the CU's
+    const size_t need = parallel_words(h, w);
+    if (need <= 14336)
+      hipLaunchKernelGGL(contour_parallel_kernel<14336>, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool, kContourPool);
+    else if (need <= 22528)
+      hipLaunchKernelGGL(contour_parallel_kernel<22528>, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool, kContourPool);
+    else
+      hipLaunchKernelGGL(contour_parallel_kernel<kLdsWords>, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool, kContourPool);
   }
   OCR_HIP(hipGetLastError());
   hipLaunchKernelGGL(contour_compact_kernel, dim3((unsigned)n), dim3(256), 0, s, hdr, pts, cap, starts, maxc, pts_packed, lens_packed);

@@ -1414,7 +1414,8 @@ static const char* tile_name(Tile t) { return t == T128x128 ? "128x128" : t == T
 
 const char* conv_igemm_kernel_name(const ConvDesc& d) {
   static thread_local char buf[96];
-  snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.x3 ? "x3" : d.in_bf16 ? "bf16" : "f32", tile_name(pick_tile(d)), d.ks, d.stride,
+  const bool wide = d.x3 && d.wide && conv_x3_wide_applicable(d);
+  snprintf(buf, sizeof buf, "conv_igemm_%s<%s,k%d,s%d,%s%s>", d.x3 ? "x3" : d.in_bf16 ? "bf16" : "f32", wide ? "256x128" : tile_name(pick_tile(d)), d.ks, d.stride,
            d.src_mode == SRC_CAT4 ? "CAT4" : d.src_mode == SRC_PYR4 ? "PYR4" : "PLAIN", d.store_mode == STORE_SHUFFLE2 ? ",SHUFFLE2" : d.store_mode == STORE_PHASE ? (d.up == 2 ? ",PHASE2" : d.up == 4 ? ",PHASE4" : ",PHASE8")
            : d.batch > 1 ? ",BATCHED" : "");
   // names must outlive the call: intern them
@@ -1490,8 +1491,23 @@ static void launch_x3(const ConvDesc& d, hipStream_t s) {
   else launch_inst<float, float, 128, 64, KS, STRIDE, SRC, STORE, true>(d, s);
 }
 
+// CUs of the current device (one query per process and device index)
+static int device_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  OCR_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cached[dev]) {
+    int n = 0;
+    OCR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cached[dev] = n > 0 ? n : 256;
+  }
+  return cached[dev];
+}
+
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s) {
   check(d);
+  if (d.x3 && d.wide && conv_x3_wide_applicable(d)) return launch_conv_x3_wide(d, device_cus(), s);
   if (d.x3) {
     if (d.src_mode == SRC_PYR4 && d.pyr_group == 1) return launch_inst<float, float, 128, 128, 3, 1, SRC_PYR4, STORE_PHASE, true>(d, s);
     if (d.src_mode == SRC_PYR4) return launch_inst<float, float, 128, 64, 3, 1, SRC_PYR4, STORE_PHASE, true>(d, s);

@@ -248,6 +248,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "pyr_p2_direct") pyr_p2_direct_ = num() != 0;
     else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
     else if (key == "phase_windows") phase_windows_ = num() != 0;
+    else if (key == "x3_wide") x3_wide_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") {
       overlap_ = num();
@@ -925,6 +926,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     d.wgt = in_bf ? cw.w_bf16 : static_cast<const void*>(cw.w);
     if (!bf && split_bf16_ && cw.w_x3 && !ex.cat4 && ex.store != STORE_SHUFFLE2 && !(ex.pyr4 && ex.pyr_nsrc != 3)) {
       d.x3 = 1;
+      d.wide = x3_wide_ ? 1 : 0;
       d.wgt = cw.w_x3;
       d.wgt_bytes = cw.w_bytes / 4 * 6;
     }
@@ -992,6 +994,7 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     d.wgt_bytes = cw.wino_bytes;
     if (split_bf16_ && cw.wino_x3) {
       d.x3 = 1;
+      d.wide = x3_wide_ ? 1 : 0;
       d.wgt = cw.wino_x3;
       d.wgt_bytes = cw.wino_bytes / 4 * 6;
     }

@@ -107,6 +107,10 @@ class Detector {
   // Growing a slot invalidates only that slot's previous contents.
   void* scratch(int slot, size_t bytes);
   // growable PINNED host memory where the polygon chain's results land (one buffer per handle: a call collects before it returns)
+  // where the polygon chain of this handle's post-processing calls ran, cumulative (ocr_det_post_stats): [0] images traced on the device,
+  // [1] images traced on the host (device_contours off, a map the tracer does not take, an image it gave up), [2] candidates the device
+  // unclip settled, [3] candidates the host finished, [4] images whose whole chain stayed on the device, [5] calls
+  long long post_stats[6] = {0, 0, 0, 0, 0, 0};
   void* host_scratch(size_t bytes);
   // pinned block for the adjust values of the batch a pipelined call leaves pending (its chain is queued with a really asynchronous upload)
   void* host_adj(size_t bytes);
@@ -183,6 +187,7 @@ class Detector {
   // option bin_pyr=0 keeps the four-launch form.
   ConvW bin_pyr_;
   bool bin_pyr_on_ = true;
+  bool x3_wide_ = true;         // split-bf16 convs with NHWC stores and Cout % 128 == 0 on the 256 x 128 persistent form (conv_x3w.hip); 0: conv_igemm's 128-wide tiles.  Same bits
   bool phase_windows_ = true;   // split-bf16 up-2 phase convs indexed by 2 x 2 windows: one operand tile for the four phases (0: one 64-column tile per phase)
   bool pyr_grouped_ = true;     // split-bf16 / bf16 bin_conv1 over p5..p3: phase blocks as 128-column tiles + the corner phases (0: one 64-column tile per phase)
   bool pyr_p2_direct_ = true;   // bf16 precision: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv instead of nine taps of the phase launch

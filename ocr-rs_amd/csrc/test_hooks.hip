@@ -81,6 +81,65 @@ int ocr_test_device_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_
     for (void* q : {(void*)d_bits, (void*)d_pts, (void*)d_pk, (void*)d_st, (void*)d_ln, (void*)d_hdr, d_spec}) (void)hipFree(q);
   });
 }
+// candidates.hip alone (arc length, Douglas-Peucker, the >= 4 points filter, job list with the clamped boxes) on contours GIVEN by the
+// caller - any map size, e.g. the oracle's contours of the reference's 800 x 800 fixtures - laid out as the device tracer would have
+// left them for one image.  Out: the candidate polygons in list order and per candidate its job box (min_x, min_y, bw, bh).
+int ocr_test_device_candidates(const int32_t* xy, const int32_t* lens, int nc, int h, int w, int32_t* xy_out, int32_t* counts_out, int32_t* box_out,
+                               int max_pts, int max_polys, int* n_polys) {
+  return guard([&] {
+    if (nc < 0 || nc > 65535 || h <= 0 || w <= 0 || h > 65535 || w > 65535) ocr::fail(OCR_ERR_INVALID, "device candidates: bad shape");
+    size_t total = 0;
+    for (int c = 0; c < nc; ++c) total += (size_t)lens[c];
+    const int cap = (int)std::max<size_t>(total, 64), maxc = std::max(nc, 1);
+    std::vector<uint32_t> pts((size_t)cap, 0u);
+    std::vector<int> starts((size_t)maxc + 1, 0);
+    size_t at = 0;
+    for (int c = 0; c < nc; ++c) {
+      starts[c] = (int)at;
+      for (int i = 0; i < lens[c]; ++i, ++at) pts[at] = ((uint32_t)xy[2 * at + 1] << 16) | ((uint32_t)xy[2 * at] & 0xffffu);
+    }
+    for (int c = nc; c <= maxc; ++c) starts[c] = (int)at;
+    const int hdr[4] = {nc, (int)total, 0, 0};
+    const size_t sb = ocr::candidates_scratch_bytes(1, cap, maxc);
+    char* d = nullptr;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_pts = al(16), o_st = o_pts + al((size_t)cap * 4), o_sc = o_st + al(((size_t)maxc + 1) * 4), o_jobs = o_sc + al(sb),
+                 o_xy = o_jobs + al((size_t)max_polys * sizeof(ocr::BoxScoreJob)), o_tot = o_xy + al((size_t)max_pts * 8), o_hd = o_tot + 256, end = o_hd + 256;
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d), end));
+    OCR_HIP(hipMemset(d, 0, end));
+    OCR_HIP(hipMemcpy(d, hdr, 16, hipMemcpyHostToDevice));
+    OCR_HIP(hipMemcpy(d + o_pts, pts.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    OCR_HIP(hipMemcpy(d + o_st, starts.data(), ((size_t)maxc + 1) * 4, hipMemcpyHostToDevice));
+    ocr::launch_candidates(reinterpret_cast<const int*>(d), reinterpret_cast<const uint32_t*>(d + o_pts), cap, reinterpret_cast<const int*>(d + o_st), maxc, 1, h, w,
+                           d + o_sc, reinterpret_cast<ocr::BoxScoreJob*>(d + o_jobs), max_polys, reinterpret_cast<int32_t*>(d + o_xy), max_pts,
+                           reinterpret_cast<int*>(d + o_tot), reinterpret_cast<int*>(d + o_hd), nullptr);
+    int totals[4] = {0, 0, 0, 0};
+    OCR_HIP(hipMemcpy(totals, d + o_hd, 12, hipMemcpyDeviceToHost));
+    if (totals[2] != 0) {
+      (void)hipFree(d);
+      ocr::fail(OCR_ERR_INVALID, "test buffer too small");
+    }
+    std::vector<ocr::BoxScoreJob> jobs((size_t)totals[0]);
+    std::vector<int32_t> oxy(2 * (size_t)totals[1]);
+    if (totals[0]) OCR_HIP(hipMemcpy(jobs.data(), d + o_jobs, jobs.size() * sizeof(ocr::BoxScoreJob), hipMemcpyDeviceToHost));
+    if (totals[1]) OCR_HIP(hipMemcpy(oxy.data(), d + o_xy, oxy.size() * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    size_t used = 0;
+    for (int j = 0; j < totals[0]; ++j) {
+      const auto& jb = jobs[j];
+      counts_out[j] = jb.n_pts;
+      box_out[4 * j] = jb.min_x;
+      box_out[4 * j + 1] = jb.min_y;
+      box_out[4 * j + 2] = jb.bw;
+      box_out[4 * j + 3] = jb.bh;
+      for (int i = 0; i < jb.n_pts; ++i, ++used) {
+        xy_out[2 * used] = oxy[2 * ((size_t)jb.pt_offset + i)];
+        xy_out[2 * used + 1] = oxy[2 * ((size_t)jb.pt_offset + i) + 1];
+      }
+    }
+    *n_polys = totals[0];
+  });
+}
 // the host tracer's raw contours, for the same comparison
 int ocr_test_host_contours(const uint8_t* bitmap01, int h, int w, int32_t* xy_out, int32_t* counts_out, int max_pts, int max_polys, int* n_polys) {
   return guard([&] {
@@ -193,7 +252,13 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
         in_e += (size_t)n * (h >> (3 - l)) * (w >> (3 - l)) * 64;
       }
     }
-    const size_t w_e = (size_t)cout * ks * ks * cin, out_e = (size_t)n * ho * wo * cout;
+    // variant: low byte = kernel form (0 conv_igemm, 1 conv3x3_bf16_c64, 2 split-bf16 128-wide tiles, 3 split-bf16 256 x 128 persistent form);
+    // variant >> 8 = B > 1: a batched GEMM of B problems (1x1 s1; in [B][n h w][cin], wgt [B][cout][cin], out [B][n h w][cout])
+    const int nbatch = variant >> 8 > 1 ? variant >> 8 : 1;
+    variant &= 0xff;
+    if (nbatch > 1 && (ks != 1 || stride != 1 || cat4 || residual || up_residual || out2)) fail(OCR_ERR_INVALID, "batched test GEMM: 1x1 s1, no residuals");
+    in_e *= (size_t)nbatch;
+    const size_t w_e = (size_t)nbatch * cout * ks * ks * cin, out_e = (size_t)nbatch * n * ho * wo * cout;
     const size_t up_e = (size_t)n * (ho / 2) * (wo / 2) * cout;
     auto bf16_bits = [](float f) {
       uint32_t u;
@@ -250,6 +315,7 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
     d.residual = up(residual, out_e, out_bf16);
     d.up_residual = up(up_residual, up_e, out_bf16);
     d.relu = relu; d.store_mode = STORE_NHWC; d.name = "test_conv";
+    d.batch = nbatch;
     void* d_out = nullptr;
     void* d_out2 = nullptr;
     if (out) { OCR_HIP(hipMalloc(&d_out, out_e * oes)); allocs.push_back(d_out); }
@@ -270,7 +336,9 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
       down(out, d_out, out_e, true);
       return;
     }
-    if (variant == 2) {  // the split-bf16 form of the f32 conv: weights as three bf16 planes
+    if (variant == 2 || variant == 3) {  // the split-bf16 form of the f32 conv: weights as three bf16 planes; 3: the 256 x 128 persistent kernel
+      if (variant == 3 && !conv_x3_wide_applicable([&] { ConvDesc t = d; t.x3 = 1; return t; }())) fail(OCR_ERR_INVALID, "variant 3: the wide split-bf16 form does not take this launch");
+      d.wide = variant == 3 ? 1 : 0;
       if (in_bf16 || out_bf16 || cat4) fail(OCR_ERR_INVALID, "variant 2 (split bf16) takes f32 tensors");
       const std::vector<uint16_t> planes = split3_weights_tiled(wgt, w_e, ks * ks * cin);
       void* d_pl = nullptr;
@@ -570,6 +638,8 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
     }
     const int x3 = (src_mode & 64) ? 1 : 0;  // split-bf16 form: the weight buffer is reinterpreted as three bf16 planes
     src_mode &= ~64;
+    const int wide = (src_mode & 128) ? 1 : 0;  // ... on the 256 x 128 persistent form (conv_x3w.hip) where it takes the launch
+    src_mode &= ~128;
     if (x3) {
       (void)hipFree(wt);
       OCR_HIP(hipMalloc(reinterpret_cast<void**>(&wt), w_e * 6));
@@ -581,6 +651,7 @@ int ocr_test_conv_bench(ocr_det_t* det, int n, int h, int w, int cin, int cout, 
     }
     ConvDesc d{};
     d.x3 = x3;
+    d.wide = wide;
     d.src[0] = in;
     d.src_mode = SRC_PLAIN;
     const int bf = src_mode == 16 ? 1 : 0;  // src_mode 16: bf16 operands and output (the buffers are just reinterpreted)

@@ -32,8 +32,8 @@ class PolygonScores:            # metrics.rs:32-35
 class FuncT:
     """What `resnet18(&nn::Path) -> FuncT<'static>` returns (model.rs:154-156)."""
 
-    def __init__(self, weights_blob: bytes, device: int = 0):
-        self._det = capi.Detector(weights_blob, device)
+    def __init__(self, weights_blob: bytes, device: int = 0, options: str = ""):
+        self._det = capi.Detector(weights_blob, device, options=options) if options else capi.Detector(weights_blob, device)
 
     @property
     def handle(self) -> capi.Detector:
@@ -74,8 +74,9 @@ class FuncT:
         self._det.close()
 
 
-def resnet18(weights_blob: bytes, device: int = 0) -> FuncT:
-    return FuncT(weights_blob, device)
+def resnet18(weights_blob: bytes, device: int = 0, options: str = "") -> FuncT:
+    """`options`: engine options of include/ocr_amd.h (the reference has none; "" = the defaults)."""
+    return FuncT(weights_blob, device, options)
 
 
 def preprocess_image(net: FuncT, rgba: np.ndarray, target_dim=(DEFAULT_WIDTH, DEFAULT_HEIGHT)):

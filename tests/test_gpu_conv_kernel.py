@@ -146,6 +146,52 @@ def test_conv_split_bf16_matches_aten(det, case):
     assert float(np.abs(out - out32).max()) / (float(np.abs(ref).max()) + 1e-12) < 5e-6
 
 
+WIDE_CASES = [
+    # n, h, w, cin, cout, ks, stride, bn, residual, relu      (the launches conv_x3w.hip takes: NHWC store, Cout % 128 == 0, >= 256 strips x column tiles)
+    (4, 160, 160, 64, 128, 3, 2, True, False, True),     # layer2.0 conv1: one column tile, 400 strips, K = 576
+    (9, 90, 90, 128, 256, 3, 2, True, True, True),       # two column tiles, odd grid, ragged last strip (M = 18 225), residual
+    (3, 80, 80, 256, 512, 3, 2, True, False, True),      # layer4.0 conv1 shape: four column tiles, K = 2 304, 75 strips: one-strip tiles, idle workgroups
+    (4, 160, 160, 64, 128, 1, 2, True, False, False),    # the downsample of layer2.0: two K-steps per tile
+    (2, 100, 100, 256, 256, 1, 1, False, False, False),  # in4-like lateral: 1x1 s1
+    (5, 64, 64, 32, 128, 1, 1, True, True, True),        # ONE K-step per tile: the flat sequence crosses a tile boundary at every step
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_wide_split_bf16_form_is_bit_identical(det, case):
+    """conv_x3w.hip (256 x 128 tiles, one persistent workgroup per CU, K-steps as one flat sequence across its tiles) computes the same
+    products in the same order as conv_igemm's 128-wide split-bf16 tiles: the SAME BITS, and the usual 2e-5 against ATen."""
+    n, h, w, cin, cout, ks, stride, bn, has_res, relu = case
+    rng = np.random.default_rng(hash(case[:7]) & 0xFFFF)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wg = (rng.standard_normal((cout, ks * ks, cin), dtype=np.float32) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    pad = (ks - 1) // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    scale = (0.5 + rng.random(cout, dtype=np.float32)) if bn else None
+    bias = rng.standard_normal(cout, dtype=np.float32) if bn else None
+    res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+    wide, _ = det.debug_conv_run(x, wg, stride, scale, bias, res, None, relu, None, False, False, True, False, variant=3)
+    out, _ = det.debug_conv_run(x, wg, stride, scale, bias, res, None, relu, None, False, False, True, False, variant=2)
+    assert np.array_equal(wide, out)
+    ref, _ = _ref(x, wg, stride, scale, bias, res, None, relu)
+    _check(wide, ref, False)
+
+
+@pytest.mark.parametrize("shape", [(36, 3200, 256, 256), (36, 800, 512, 512), (16, 1000, 128, 384)], ids=lambda s: "x".join(map(str, s)))
+def test_wide_split_bf16_batched_gemms_are_bit_identical(det, shape):
+    """the Winograd GEMMs of layer3 / layer4 (36 problems of [tiles x Cin] . [Cin x Cout]) and a ragged one: a tile never spans two
+    problems, the last strip of a problem is partly empty"""
+    b, m, k, nn = shape
+    rng = np.random.default_rng(b * 1000 + m)
+    x = rng.standard_normal((b, m, k), dtype=np.float32)
+    wg = (rng.standard_normal((b, nn, k), dtype=np.float32) / np.sqrt(k)).astype(np.float32)
+    wide = det.debug_gemm_batched(x, wg, variant=3)
+    out = det.debug_gemm_batched(x, wg, variant=2)
+    assert np.array_equal(wide, out)
+    ref = np.einsum("bmk,bnk->bmn", x.astype(np.float64), wg.astype(np.float64))
+    assert float(np.abs(wide - ref).max()) / float(np.abs(ref).max()) < 2e-5
+
+
 def test_conv_split_bf16_wide_exponents(det):
     """Operands spread over 24 binades and values that need all 24 significand bits: the three-term split is exact
     (no term under- or overflows in bf16's f32-sized exponent range), so the bar does not move."""

@@ -98,8 +98,10 @@ def test_device_contours_report_overflow_and_guard():
         assert status == 1
         _, status = capi.device_contours(bm, max_pts=16, max_polys=1 << 12, sequential=seq)      # more points
         assert status == 1
+    _, status = capi.device_contours(np.zeros((800, 800), np.uint8))          # the reference's frame size fits (one bit plane + a band of rows in LDS)
+    assert status == 0
     with pytest.raises(capi.OcrError):
-        capi.device_contours(np.zeros((800, 800), np.uint8))                  # three bit planes of 800 x 800 do not fit a CU's LDS
+        capi.device_contours(np.zeros((1024, 2048), np.uint8))                # a bit plane of 1024 x 2048 does not fit a CU's LDS
 
 
 def _post(det, maps, adj):
@@ -111,7 +113,7 @@ def test_postprocess_is_the_same_with_either_tracer():
     """ocr_det_postprocess with device_contours=1 (parallel form) / 2 (one wave per image) / 0 - with the contours the whole chain
     (Douglas-Peucker, job list, box scores, unclip: candidates.hip, unclip.hip) stays on the device unless device_polygons=0 -: identical polygon lists and
     scores on text-like and dense maps, on noise whose thousands of contours overflow the device buffers (those images fall back to the
-    host tracer inside the call), on a mixed batch, and on a size the device tracer does not take."""
+    host tracer inside the call), on a mixed batch, and at the reference's 800 x 800."""
     blob = W.pack_blob(W.make_det_weights(0))
     host = capi.Detector(blob, 0, options="device_contours=0")
     dev = capi.Detector(blob, 0, options="device_contours=1")

@@ -23,22 +23,39 @@ pytestmark = pytest.mark.gpu
 S, N = 640, 32
 
 
-def test_32_pages_frames_to_polygons_to_labels_against_the_oracle_chain():
-    det_w, rec_w = W.make_det_weights_text(), W.make_rec_weights(0)
-    det = capi.Detector(W.pack_blob(det_w), 0)
-    rec = capi.Recognizer(W.pack_blob(rec_w), 0)
-    frames, boxes = W.synth_text_pages(2026, N, S, S)
-    prob, polys, scores, crops, labels = run_pipeline(det, rec, frames, capi.PRECISION_F32)
-    det.close()
-    rec.close()
+# where the polygon chain runs: the engine's default for this box, everything on the host pool, everything on the device
+CHAINS = {"default": None, "host chain": "device_contours=0;device_unclip=0", "device chain": "device_contours=1;device_unclip=2"}
 
-    # ---- the oracle chain on ITS OWN map
+
+@pytest.fixture(scope="module")
+def oracle_32_pages():
+    """the oracle chain on ITS OWN map, once for every placement of the product's chain"""
+    det_w, rec_w = W.make_det_weights_text(), W.make_rec_weights(0)
+    frames, boxes = W.synth_text_pages(2026, N, S, S)
     ref_prob = np.concatenate([T.det_forward(det_w, frames[i:i + 8]) for i in range(0, N, 8)])
     adj = np.ones((N, 2))
     ref_polys, ref_scores = O.get_boxes_and_box_scores(ref_prob, adj, skip_degenerate=True)
     ref_crops = CR.extract_crops(frames, ref_polys, adj)
     ref_logits = T.rec_forward(rec_w, ref_crops)
     ref_labels, _ = T.rec_classify(ref_logits)
+    return det_w, rec_w, frames, boxes, ref_prob, ref_polys, ref_scores, ref_crops, ref_logits, ref_labels
+
+
+@pytest.mark.parametrize("chain", list(CHAINS), ids=list(CHAINS))
+def test_32_pages_frames_to_polygons_to_labels_against_the_oracle_chain(oracle_32_pages, chain):
+    det_w, rec_w, frames, boxes, ref_prob, ref_polys, ref_scores, ref_crops, ref_logits, ref_labels = oracle_32_pages
+    det = capi.Detector(W.pack_blob(det_w), 0, options=CHAINS[chain])
+    rec = capi.Recognizer(W.pack_blob(rec_w), 0)
+    prob, polys, scores, crops, labels = run_pipeline(det, rec, frames, capi.PRECISION_F32)
+    st = det.post_stats()
+    det.close()
+    rec.close()
+    if chain == "device chain":     # ... and it did run there: no page handed back to the host tracer, (almost) no polygon to the host unclip
+        assert st["images_device_chain"] == N and st["images_host_traced"] == 0, st
+        assert st["candidates_host"] <= 0.02 * st["candidates_device"], st
+    if chain == "host chain":
+        assert st["images_device_traced"] == 0 and st["candidates_device"] == 0, st
+    adj = np.ones((N, 2))
 
     # ---- maps: 1e-4, and how many pixels sit on the other side of the threshold
     d = np.abs(prob - ref_prob)
@@ -80,20 +97,30 @@ def test_32_pages_frames_to_polygons_to_labels_against_the_oracle_chain():
     assert n_poly > 10 * N
 
 
-def test_maps_that_straddle_the_threshold_differ_only_where_a_pixel_flipped():
+@pytest.fixture(scope="module")
+def oracle_soft_pages():
+    det_w = W.make_det_weights_text(gain=0.01, tau=84.5)
+    frames, boxes = W.synth_text_pages(2027, N, S, S)
+    ref_prob = np.concatenate([T.det_forward(det_w, frames[i:i + 8]) for i in range(0, N, 8)])
+    ref_polys, ref_scores = O.get_boxes_and_box_scores(ref_prob, np.ones((N, 2)), skip_degenerate=True)
+    return det_w, frames, ref_prob, ref_polys, ref_scores
+
+
+@pytest.mark.parametrize("chain", list(CHAINS), ids=list(CHAINS))
+def test_maps_that_straddle_the_threshold_differ_only_where_a_pixel_flipped(oracle_soft_pages, chain):
     """The same two chains on SOFT maps: the text-following weights with a flat sigmoid (gain 0.01 instead of 0.06) leave more than 1e-4 of
     the oracle's pixels within 1e-3 of the 0.6 threshold (/root/reference/src/text_detection/metrics.rs:38,129-131), so float rounding
     does move pixels across it.  Counted and explained: pages without a flipped pixel have identical polygon lists; on every other page
     each polygon that one side has and the other has not holds a flipped pixel inside its bounding box."""
-    det_w = W.make_det_weights_text(gain=0.01, tau=84.5)
-    det = capi.Detector(W.pack_blob(det_w), 0)
-    frames, boxes = W.synth_text_pages(2027, N, S, S)
+    det_w, frames, ref_prob, ref_polys, ref_scores = oracle_soft_pages
+    det = capi.Detector(W.pack_blob(det_w), 0, options=CHAINS[chain])
     prob = det.forward_host(frames)
     adj = np.ones((N, 2))
     polys, scores = det.postprocess(prob, N, S, S, adj, capi.MEM_HOST, capi.default_params(skip_degenerate=True))
+    st = det.post_stats()
     det.close()
-    ref_prob = np.concatenate([T.det_forward(det_w, frames[i:i + 8]) for i in range(0, N, 8)])
-    ref_polys, ref_scores = O.get_boxes_and_box_scores(ref_prob, adj, skip_degenerate=True)
+    if chain == "device chain":
+        assert st["images_device_chain"] == N and st["images_host_traced"] == 0, st
 
     d = np.abs(prob - ref_prob)
     near = float((np.abs(ref_prob - np.float32(0.6)) < 1e-3).mean())
