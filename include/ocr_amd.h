@@ -345,6 +345,13 @@ int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels,
                      int mem_kind);
 /* The label alphabet, utils.rs:7 ("A-Za-z0-9", 62 symbols, NUL terminated). */
 const char* ocr_rec_alphabet(void);
+/* EXTENSION - no counterpart in the reference (its recogniser classifies single 28 x 28 glyphs, char_recognition/model.rs:27-39):
+ * CTC greedy (best-path) decode of a sequence recogniser's output, the stage BASELINE.json's north_star names.  logits N x T x C f32
+ * (or any monotone transform of them), blank in [0, C): per crop the first class attaining each column's maximum, consecutive repeats
+ * collapsed, blanks dropped -> labels N x T int32 (row i: lengths[i] classes, then -1) and lengths N.  One wave per crop on the handle's
+ * GPU and stream; blocking; mem_kind says where the three buffers live.  Exact integers: oracle/ctc_oracle.py. */
+int ocr_ctc_greedy_decode(ocr_rec_t* rec, const float* logits, int n, int t, int c, int blank, int mem_kind, int32_t* labels,
+                          int32_t* lengths);
 
 /* ---------------------------------------------------------------------------
  * Multi-GPU exchange.  Frames and crops are independent (eval-mode batch norm), so a batch shards over the GPUs of

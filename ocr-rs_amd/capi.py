@@ -29,7 +29,7 @@ EXPORTS = [
     "ocr_preprocess_image", "ocr_postproc_default_params", "ocr_det_postprocess", "ocr_det_post_stats", "ocr_det_detect_pipelined", "ocr_polygons_free",
     "ocr_extract_crops", "ocr_evaluate_image", "ocr_combine_results",
     "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_set_stream", "ocr_rec_set_options", "ocr_rec_synchronize",
-    "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet",
+    "ocr_rec_forward", "ocr_rec_classify_async", "ocr_rec_classify_profile", "ocr_rec_classify", "ocr_rec_alphabet", "ocr_ctc_greedy_decode",
     "ocr_comm_unique_id", "ocr_comm_rccl_version", "ocr_comm_create", "ocr_comm_destroy",
     "ocr_comm_all_gather_polygons", "ocr_comm_all_gather_labels",
 ]
@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
         L.ocr_postproc_default_params.argtypes = [C.POINTER(PostprocParams)]
         L.ocr_postproc_default_params.restype = None
         L.ocr_det_post_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.ocr_ctc_greedy_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ocr_det_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(PostprocParams),
                                           C.POINTER(C.POINTER(Polygons))]
@@ -630,6 +631,18 @@ class Recognizer:
         probs = np.empty(n, np.float64)
         check(lib().ocr_rec_classify(self._h, _ptr(crops), n, _ptr(labels), _ptr(probs), MEM_HOST))
         return labels, probs
+
+    def ctc_greedy_decode(self, logits: np.ndarray, blank: int):
+        """EXTENSION (no reference counterpart): logits N x T x C f32 in host memory -> (labels N x T int32 padded with -1, lengths N)."""
+        x = np.ascontiguousarray(logits, dtype=np.float32)
+        n, t, c = x.shape
+        labels = np.empty((n, t), np.int32)
+        lengths = np.empty(n, np.int32)
+        check(lib().ocr_ctc_greedy_decode(self._h, _ptr(x), n, t, c, int(blank), MEM_HOST, _ptr(labels), _ptr(lengths)))
+        return labels, lengths
+
+    def ctc_greedy_decode_device(self, logits_ptr: int, n: int, t: int, c: int, blank: int, labels_ptr: int, lengths_ptr: int) -> None:
+        check(lib().ocr_ctc_greedy_decode(self._h, C.c_void_p(logits_ptr), n, t, c, int(blank), MEM_DEVICE, C.c_void_p(labels_ptr), C.c_void_p(lengths_ptr)))
 
     def classify_profile(self, crops_ptr: int, n: int, labels_ptr: int = 0, probs_ptr: int = 0):
         """[(kernel, ms, executed flops, bytes)] of one classify pass (device pointers)."""

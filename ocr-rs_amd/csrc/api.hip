@@ -904,6 +904,32 @@ int ocr_rec_classify(ocr_rec_t* rec, const float* crops, int n, int32_t* labels,
     }
   });
 }
+int ocr_ctc_greedy_decode(ocr_rec_t* rec, const float* logits, int n, int t, int c, int blank, int mem_kind, int32_t* labels, int32_t* lengths) {
+  return guard([&] {
+    using namespace ocr;
+    if (!rec || !logits || !labels || !lengths) fail(OCR_ERR_INVALID, "ctc_greedy_decode: null argument");
+    if (n < 0 || t <= 0 || c <= 0 || blank < 0 || blank >= c) fail(OCR_ERR_INVALID, "ctc_greedy_decode: N=%d T=%d C=%d blank=%d", n, t, c, blank);
+    if (n == 0) return;
+    OCR_HIP(hipSetDevice(rec->impl.device()));
+    hipStream_t s = rec->impl.stream();
+    if (mem_kind == OCR_MEM_DEVICE) {   // enqueued on the handle's stream and awaited (the lengths are usually read right away)
+      launch_ctc_greedy(logits, n, t, c, blank, labels, lengths, s);
+      OCR_HIP(hipStreamSynchronize(s));
+      return;
+    }
+    const size_t in_b = (size_t)n * t * c * 4, lab_b = (size_t)n * t * 4, len_b = (size_t)n * 4;
+    char* d = nullptr;
+    OCR_HIP(hipMalloc(reinterpret_cast<void**>(&d), align256(in_b) + align256(lab_b) + align256(len_b)));
+    struct Free { char* p; ~Free() { (void)hipFree(p); } } free_d{d};
+    int32_t* d_lab = reinterpret_cast<int32_t*>(d + align256(in_b));
+    int32_t* d_len = reinterpret_cast<int32_t*>(d + align256(in_b) + align256(lab_b));
+    OCR_HIP(hipMemcpyAsync(d, logits, in_b, hipMemcpyHostToDevice, s));
+    launch_ctc_greedy(reinterpret_cast<const float*>(d), n, t, c, blank, d_lab, d_len, s);
+    OCR_HIP(hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipMemcpyAsync(lengths, d_len, len_b, hipMemcpyDeviceToHost, s));
+    OCR_HIP(hipStreamSynchronize(s));
+  });
+}
 const char* ocr_rec_alphabet(void) { return "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"; }
 
 /* ---- multi-GPU exchange (comm.hip) */

@@ -89,6 +89,8 @@ struct ConvDesc {
   const char* name;
 };
 
+// ctc.hip (extension, no reference counterpart): CTC greedy decode, one wave per crop; logits [n][t][c] -> labels [n][t] (-1 padded), lengths [n]
+void launch_ctc_greedy(const float* logits_dev, int n, int t, int c, int blank, int32_t* labels_dev, int32_t* lengths_dev, hipStream_t s);
 void launch_conv_igemm(const ConvDesc& d, hipStream_t s);
 // conv_x3w.hip: the split-bf16 convs with NHWC stores and Cout a multiple of 128 as 256 x 128 tiles on one persistent workgroup per CU
 // (bit-identical to conv_igemm's 128-wide split-bf16 tiles); `cus` = CUs of the device

@@ -280,6 +280,7 @@ class Recognizer {
                 std::vector<ProfileEntry>* prof = nullptr);
   void forward_host(const float* crops, int n, float* logits, int32_t* labels, double* probs);
   int device() const { return device_; }
+  hipStream_t stream() const { return stream_; }
   static constexpr int kChunk = 65536;  // crops per pass: bounds the feat / hidden workspace (6144 bytes per crop)
 
  private:
