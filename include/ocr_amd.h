@@ -86,7 +86,7 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               launch over p5, p4, p3 (0: all four sources in the phase launch)
  *   tail_unfused=0|1     (0)    1 = probability head as two launches
  *   transform_fuse=0|1   (0)    layer3 / layer4, block 1: conv1's Winograd output transform and conv2's input transform in one launch (the
- *                               activation between them stays in LDS); bit-identical, and measured to buy nothing
+ *                               activation between them stays in LDS); bit-identical, and measured to buy nothing (docs/history.md)
  *   overlap=0|1|2|3      (3)    second stream: 1 small independent launches; 2 the FPN branch as it stands; 3 the FPN's fused-Winograd
  *                               launches (lateral terms of p2 / p3) and bin_conv1's p2 term - f32 matrix instructions - beside layer2 / layer3 / layer4 /
  *                               the small FPN convs - bf16 matrix instructions and HBM-bound transforms: 2 % of the step in both precisions (default kernels;
