@@ -901,8 +901,11 @@ def main():
                 pin[k2] = hb
             pr2 = [torch.empty_like(dev["text"]), torch.empty_like(dev["text"])]
             kk = 6
-            for threads in (1, 2, 4, 16):
-                dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local, options=f"post_threads={threads}")
+            # (threads, options, key): the engine's default placement of the polygon chain per pool size, and at 16 threads the whole
+            # chain forced onto the device (what device_contours=auto picks for small pools) beside it
+            for threads, extra, key in ((1, "", "1"), (2, "", "2"), (4, "", "4"), (16, "", "16"),
+                                        (16, ";device_contours=1;device_unclip=2", "16_device_chain")):
+                dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local, options=f"post_threads={threads}" + extra)
                 dt.set_stream(stream.cuda_stream)
                 row = {}
                 for prec in ("f32", "bf16"):
@@ -932,7 +935,8 @@ def main():
                         row[f"{prec}_{kind}"] = {"detect_postprocess_pipelined_images_per_s": round(n * kk / el_d, 1),
                                                  "host_to_polygons_images_per_s": round(n * kk / el_h, 1),
                                                  "polygons_per_image": round(found / (n * kk), 1)}
-                sweep[str(threads)] = row
+                row["where"] = dt.post_stats()
+                sweep[key] = row
                 dt.close()
             for hb in pin.values():
                 hb.close()
@@ -991,6 +995,30 @@ def main():
             roof_rec["achieved"] = roof_rec["b65536"]["achieved"]
             roof_rec["frac"] = roof_rec["b65536"]["frac"]
             extras["roofline_rec"] = roof_rec
+            # EXTENSION (never the headline; the reference has no sequence recogniser): CTC greedy decode of BASELINE configs[2]'s literal
+            # shape - 256 crops of 32 x 128 -> T = 32 columns, C = 63 classes (utils.rs:7 alphabet + blank), logits resident in HBM
+            try:
+                nc, tt, cc = 256, 32, 63
+                g = torch.Generator(device="cpu").manual_seed(5)
+                lg = torch.randn((nc, tt, cc), generator=g).to(x.device)
+                lab = torch.empty((nc, tt), dtype=torch.int32, device=x.device)
+                ln = torch.empty(nc, dtype=torch.int32, device=x.device)
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    rec.ctc_greedy_decode_device(lg.data_ptr(), nc, tt, cc, cc - 1, lab.data_ptr(), ln.data_ptr())
+                t1 = time.perf_counter()
+                it = 50
+                for _ in range(it):
+                    rec.ctc_greedy_decode_device(lg.data_ptr(), nc, tt, cc, cc - 1, lab.data_ptr(), ln.data_ptr())
+                wall = time.perf_counter() - t1
+                from oracle import ctc_oracle as CT   # (the checker, outside the timed region)
+                wl, wn = CT.ctc_greedy_decode(lg.cpu().numpy(), cc - 1)
+                ok = bool((lab.cpu().numpy() == wl).all() and (ln.cpu().numpy() == wn).all())
+                extras["extension"] = {"ctc_decode_crops_per_s": round(nc * it / wall, 1), "crops": nc, "T": tt, "C": cc, "blank": cc - 1,
+                                       "matches_oracle": ok, "bytes_per_call": nc * tt * (cc + 1) * 4,
+                                       "note": "ocr_ctc_greedy_decode, blocking call per batch (launch + sync latency decides at this size); no reference counterpart"}
+            except Exception as e:
+                extras["extension"] = {"error": f"{type(e).__name__}: {e}"}
             rec.close()
         except Exception as e:  # side numbers never hide the headline
             extras["rec_error"] = f"{type(e).__name__}: {e}"
@@ -1051,7 +1079,10 @@ def main():
             "e2e_pages_per_s": line.get("e2e_pages_per_s"),
             "detect_postprocess_pipelined_images_per_s": line.get("detect_postprocess_pipelined_images_per_s"),
             "postprocess_images_per_s": {"text": line.get("postprocess_images_per_s"), "dense": line.get("postprocess_dense_images_per_s")},
-            "post_threads_2": {k2: v2.get("detect_postprocess_pipelined_images_per_s") for k2, v2 in sw.items()} if sw else None,
+            "post_threads_2": {k2: v2.get("detect_postprocess_pipelined_images_per_s") for k2, v2 in sw.items() if isinstance(v2, dict) and "detect_postprocess_pipelined_images_per_s" in v2} if sw else None,
+            "post_threads_16_device_chain": {k2: v2.get("detect_postprocess_pipelined_images_per_s") for k2, v2 in ((line.get("post_threads_sweep") or {}).get("16_device_chain") or {}).items()
+                                             if isinstance(v2, dict) and "detect_postprocess_pipelined_images_per_s" in v2} or None,
+            "extension": line.get("extension"),
             "rec_crops_per_s": {"b256": line.get("rec_crops_per_s_b256"), "b65536": line.get("rec_crops_per_s_b65536")},
             "cpu_baseline": {"images_per_s": cb.get("value"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "one_thread": (cb.get("one_thread") or {}).get("value"),

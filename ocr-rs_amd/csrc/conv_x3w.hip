@@ -69,6 +69,15 @@ __device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// compile-time ablations (make EXTRA=-DX3W_ABL=<bits>, tools/build_abl_x3w.sh): what is left of a launch's time without one ingredient -
+// 1 no A DMA, 2 no B DMA, 4 no split, 8 no MFMA, 32 no LDS fragment reads, 64 no mid-step barrier, 128 no epilogue, 512 no wait for the DMA.
+// The results of an ablated kernel are garbage; only its time means something.
+#if defined(X3W_ABL)
+#define X3W_DBG(bit) ((X3W_ABL & (bit)) != 0)
+#else
+#define X3W_DBG(bit) false
+#endif
+
 template <int I0, int I1, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I0 < I1) {
@@ -151,13 +160,14 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
     bvoff = (unsigned)((((t.bz * p.Cout + n0) >> 4) + wave) * nK * 3072 + lane * 16);
   };
   int it_c = 0, it_t = 0;
-  unsigned cur_av[4];
+  unsigned cur_av[4], cur_bv = 0;   // (the step's own copies: advancing into the next tile rewrites the tables)
   int cur_soff_a = 0, cur_soff_b = 0;
   auto select_next = [&] {   // the step the iterator points at; then advance (into the next tile when this one is through)
     const int kh = it_t / KS, kw = it_t - kh * KS;
     const unsigned dist = (unsigned)((kh * p.Win + kw) * p.Cin * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur_av[i] = (amask[i] >> it_t) & 1u ? abase[i] + dist : OOB;
+    cur_bv = bvoff;
     cur_soff_a = it_c * ROWB;
     cur_soff_b = (it_t * csteps + it_c) * 3072;
     if (++it_t == NTAP) {
@@ -174,10 +184,10 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
   auto dma_piece = [&](int stage, auto piece_c) {
     constexpr int P = decltype(piece_c)::value;
     if constexpr (P < 4) {
-      dma16(a_rsrc, uni((int)(lds0 + (unsigned)(stage * STAGE + (8 * wave + 64 * P) * ROWB))), cur_av[P], cur_soff_a);
+      if (!X3W_DBG(1)) dma16(a_rsrc, uni((int)(lds0 + (unsigned)(stage * STAGE + (8 * wave + 64 * P) * ROWB))), cur_av[P], cur_soff_a);
     } else {
       constexpr int pl = P - 4;
-      dma16(b_rsrc, uni((int)(lds0 + (unsigned)(stage * STAGE + A_BYTES + pl * BN * 64 + 16 * wave * 64))), bvoff, cur_soff_b + pl * 1024);
+      if (!X3W_DBG(2)) dma16(b_rsrc, uni((int)(lds0 + (unsigned)(stage * STAGE + A_BYTES + pl * BN * 64 + 16 * wave * 64))), cur_bv, cur_soff_b + pl * 1024);
     }
   };
   auto dma_all = [&](int stage) { static_for<0, NP>([&](auto i) { dma_piece(stage, i); }); };
@@ -209,6 +219,13 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
   struct Raw { f32x4 a0[MT], a1[MT]; };
   auto read_frag = [&](int stage, int kk, Raw& rw, Frag& f) {
     const unsigned char* st = lds + stage * STAGE;
+    if (X3W_DBG(32)) {   // no LDS reads: operands from whatever the registers hold
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rw.a0[i]), "+v"(rw.a1[i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(f.bh[j]), "+v"(f.bm[j]), "+v"(f.bl[j]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       rw.a0[i] = *reinterpret_cast<const f32x4*>(st + a_row + i * 32 * ROWB + xoff[2 * kk]);
@@ -225,6 +242,17 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
   // elements [E0, E1) of the 16 this lane holds (row tile e >> 3): x = hi + mid + lo, round to nearest even at every level
   auto split_part = [&](const Raw& rw, Frag& f, auto e0c, auto e1c) {
     constexpr int E0 = decltype(e0c)::value, E1 = decltype(e1c)::value;
+    if (X3W_DBG(4)) {
+      if constexpr (E0 == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          f.ah[i] = __builtin_bit_cast(bf16x8, rw.a0[i]);
+          f.am[i] = __builtin_bit_cast(bf16x8, rw.a1[i]);
+          f.al[i] = __builtin_bit_cast(bf16x8, rw.a0[i] + rw.a1[i]);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int e = E0; e < E1; ++e) {
       const int i = e >> 3, k = e & 7;
@@ -242,6 +270,10 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
   // accumulators; per accumulator the order of the six products is conv_igemm's
   auto mfma_at = [&](const Frag& f, auto idx_c) {
     constexpr int idx = decltype(idx_c)::value, t = idx % (MT * NT), i = t / NT, j = t % NT, pr = idx / (MT * NT);
+    if (X3W_DBG(8)) {
+      asm volatile("" ::"v"(f.al[i]), "v"(f.ah[i]), "v"(f.am[i]), "v"(f.bh[j]), "v"(f.bm[j]), "v"(f.bl[j]));
+      return;
+    }
     if constexpr (pr == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
     if constexpr (pr == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
     if constexpr (pr == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[i], f.bm[j], acc[i][j], 0, 0, 0);
@@ -311,7 +343,12 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
   // ---- epilogue of one tile, straight from the accumulators (C/D map of a 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) +
   // 4 (lane >> 5)); rows beyond M fall outside the descriptor's range and are dropped by the hardware
   auto epilogue = [&](const Tile& t) {
-    if (wm < t.cnt) {
+    if (X3W_DBG(128)) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if (wm < t.cnt) {
       const int colq = lane & 31, rowq = (lane >> 5) * 4;
       const unsigned row_b = (unsigned)p.Cout * 4u;
       const int r0 = t.m0 + wm * 64;
@@ -379,8 +416,9 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
     for (int k = 0; k < total; ++k) {
       phase(act, fx, par, 1, rw, fy, -1);
       // this wave's reads of stage par are complete and its share of the next step's DMA has landed; after the barrier so is everyone's
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (X3W_DBG(512)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (!X3W_DBG(64)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const bool more = !d_done;   // the flat sequence has a step two ahead of this one
       if (more) select_next();

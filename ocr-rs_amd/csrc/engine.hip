@@ -249,6 +249,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
     else if (key == "phase_windows") phase_windows_ = num() != 0;
     else if (key == "x3_wide") x3_wide_ = num() != 0;
+    else if (key == "w43_dynamic") w43_dynamic_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") {
       overlap_ = num();
@@ -580,6 +581,7 @@ Detector::~Detector() {
   free_workspace();
   if (host_scratch_) (void)hipHostFree(host_scratch_);
   if (host_adj_) (void)hipHostFree(host_adj_);
+  if (w43_ctr_) (void)hipFree(w43_ctr_);
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
   for (Staging& st : stage_)
@@ -850,6 +852,11 @@ void Detector::forward(const void* x, int n, int h, int w, float* prob, uint8_t*
 void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                              std::vector<ProfileEntry>* prof, int x_u8) {
   ensure_workspace(n, h, w);
+  if (w43_dynamic_ && !bf16_) {   // the block counters of this chunk's fused Winograd launches (the side stream's start behind main-stream events)
+    if (!w43_ctr_) OCR_HIP(hipMalloc(reinterpret_cast<void**>(&w43_ctr_), (size_t)kW43Slots * 32 * sizeof(int)));
+    OCR_HIP(hipMemsetAsync(w43_ctr_, 0, (size_t)kW43Slots * 32 * sizeof(int), stream_));
+    w43_slot_ = 0;
+  }
   Recorder rec(prof, stream_);
 
   struct Extra {
@@ -1058,9 +1065,11 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     if (!bf && cw.wino43_fused) {  // transforms fused into the GEMM kernel
       {
         rec.begin();
+        int* ctr = nullptr;   // this launch's counters (zeroed at the start of the chunk)
+        if (w43_dynamic_ && w43_ctr_ && w43_slot_ < kW43Slots) ctr = w43_ctr_ + 32 * w43_slot_++;
         launch_winograd43_fused(static_cast<const float*>(src), cw.wino43_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
                                 relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout,
-                                cs != stream_ && w43_side_cus_ > 0 ? w43_side_cus_ : w43_cus_ > 0 ? w43_cus_ : cs == stream_ ? grid_cus : num_cus_, cs);
+                                cs != stream_ && w43_side_cus_ > 0 ? w43_side_cus_ : w43_cus_ > 0 ? w43_cus_ : (cs == stream_ && !ctr) ? grid_cus : num_cus_, cs, ctr);
         const double px43 = (double)n * hh * ww;
         rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : cw.cin == 128 ? "winograd43_fused<c128>" : "winograd43_fused<c256>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
                 px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 4);

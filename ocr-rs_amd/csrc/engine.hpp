@@ -187,6 +187,10 @@ class Detector {
   // option bin_pyr=0 keeps the four-launch form.
   ConvW bin_pyr_;
   bool bin_pyr_on_ = true;
+  bool w43_dynamic_ = true;     // fused Winograd launches hand their blocks out through counters (winograd43_fused.hip); 0: static shares
+  int* w43_ctr_ = nullptr;      // kW43Slots x 32 counters, zeroed at the start of every forward chunk; one slot per fused launch
+  int w43_slot_ = 0;
+  static constexpr int kW43Slots = 64;
   bool x3_wide_ = true;         // split-bf16 convs with NHWC stores and Cout % 128 == 0 on the 256 x 128 persistent form (conv_x3w.hip); 0: conv_igemm's 128-wide tiles.  Same bits
   bool phase_windows_ = true;   // split-bf16 up-2 phase convs indexed by 2 x 2 windows: one operand tile for the four phases (0: one 64-column tile per phase)
   bool pyr_grouped_ = true;     // split-bf16 / bf16 bin_conv1 over p5..p3: phase blocks as 128-column tiles + the corner phases (0: one 64-column tile per phase)
