@@ -905,7 +905,8 @@ def main():
             # chain forced onto the device (what device_contours=auto picks for small pools) beside it
             for threads, extra, key in ((1, "", "1"), (2, "", "2"), (4, "", "4"), (16, "", "16"),
                                         (16, ";device_contours=1;device_unclip=2", "16_device_chain")):
-                dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local, options=f"post_threads={threads}" + extra)
+                dt = capi.Detector(W.pack_blob(W.make_det_weights_text()), local,
+                                   options=f"post_threads={threads}" + extra + (";" + a.det_options if a.det_options else ""))
                 dt.set_stream(stream.cuda_stream)
                 row = {}
                 for prec in ("f32", "bf16"):

@@ -91,6 +91,9 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               launches (lateral terms of p2 / p3) and bin_conv1's p2 term - f32 matrix instructions - beside layer2 / layer3 / layer4 /
  *                               the small FPN convs - bf16 matrix instructions and HBM-bound transforms: 2 % of the step in both precisions (default kernels;
  *                               otherwise, and under ocr_det_forward_profile, one stream).  Sums re-associate by one rounding.  Any other value is OCR_ERR_INVALID
+ *   x3_wide=0|1          (0)    the split-bf16 convs with plain NHWC stores and Cout % 128 == 0 (stride-2 3x3, 1x1, the Winograd GEMMs) as 256 x 128 tiles
+ *                               on one persistent workgroup per CU (conv_x3w.hip): 30 % fewer operand bytes per MFMA, bit-identical, and measured 0-35 %
+ *                               SLOWER than the 128-wide tiles at two workgroups per CU: kept for A/B
  *   w43_cus=<n>          (0)    tuning: size of the fused Winograd kernel's persistent grid in CUs (two workgroups each); 0 = every CU of the device.
  *   w43_side_cus=<n>     (0)    the same for the fused Winograd launches that overlap=3 puts on the side stream; 0 = every CU.  Both 0..4096; any
  *                               grid size gives the same bits (tests/test_gpu_conv_kernel.py)
@@ -108,8 +111,10 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               word-wide bit arithmetic (0.35-0.5 ms per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
  *                               contours either way.  auto: 1 where the host pool (post_threads) has at most four threads, else 0: by
  *                               measurement
- *   head_cus_yield=0|1   (1)    pipelined calls: while the polygon chain of the previous batch runs (its tracer holds one CU per image), layer1's
- *                               persistent grids are sized for the CUs that are free
+ *   head_cus_yield=0..4  (2)    pipelined calls, while the polygon chain of the previous batch runs beside this forward's first launches: layer1's persistent
+ *                               grids (their blocks are dealt statically: a workgroup that shares its CU with the tracer's waves holds the launch up) are
+ *                               1: sized for the CUs the tracer leaves (the form of the whole-CU tracer), 2..4: launched with that many workgroups per
+ *                               resident slot, so that the hardware hands the later ones to whichever CU drains first.  0: nothing
  *   post_priority=0|1    (1)    the post-processing / trace streams at the device's highest stream priority: their short kernels are placed as
  *                               soon as a CU drains instead of queueing behind the next forward's workgroups
  *   device_polygons=0|1  (1)    with device contours on square maps: Douglas-Peucker, the >= 4 points filter and the box-score job list on

@@ -137,10 +137,8 @@ void launch_winograd_output(const float* mm, const float* scale, const float* bi
                             float* y, int N, int H, int W, int K, int m, hipStream_t s);
 // The same conv with both transforms fused into the GEMM kernel, F(4x4,3x3) (winograd43_fused.hip): C = 64, 128 or 256, K a multiple of 64.  ufrag: winograd43_fragments(winograd_weights(.., 4)).
 std::vector<float> winograd43_fragments(const std::vector<float>& u, int cout, int cin);
-// ctr: 32 ZEROED ints of device memory for this launch - its workgroups then fetch their blocks from counters instead of walking a static
-// share (a workgroup that shares its CU with another kernel takes fewer blocks); null = static.  Same bits either way.
 void launch_winograd43_fused(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual,
-                             int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s, int* ctr = nullptr);
+                             int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s);
 // ... and with its GEMMs on the bf16 matrix cores, f32 operands as three bf16 terms each (winograd43_x3.hip; mfma=split_bf16):
 // two pixel blocks per workgroup, one workgroup per CU.  ufrag: winograd43_x3_fragments(winograd_weights(.., 4)).
 std::vector<uint16_t> winograd43_x3_fragments(const std::vector<float>& u, int cout, int cin);

@@ -249,7 +249,6 @@ void Detector::parse_options(const char* options) {
     else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
     else if (key == "phase_windows") phase_windows_ = num() != 0;
     else if (key == "x3_wide") x3_wide_ = num() != 0;
-    else if (key == "w43_dynamic") w43_dynamic_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") {
       overlap_ = num();
@@ -275,7 +274,10 @@ void Detector::parse_options(const char* options) {
       }
     }
     else if (key == "post_priority") post_priority_ = num() != 0;
-    else if (key == "head_cus_yield") head_cus_yield_ = num() != 0;
+    else if (key == "head_cus_yield") {
+      head_cus_yield_ = num();
+      if (head_cus_yield_ < 0 || head_cus_yield_ > 4) fail(OCR_ERR_INVALID, "detector option head_cus_yield: %d (0 .. 4)", head_cus_yield_);
+    }
     else if (key == "transform_fuse") transform_fuse_ = num() != 0;
     else if (key == "device_unclip") {
       device_unclip_ = num();
@@ -581,7 +583,6 @@ Detector::~Detector() {
   free_workspace();
   if (host_scratch_) (void)hipHostFree(host_scratch_);
   if (host_adj_) (void)hipHostFree(host_adj_);
-  if (w43_ctr_) (void)hipFree(w43_ctr_);
   for (void* p : scratch_)
     if (p) (void)hipFree(p);
   for (Staging& st : stage_)
@@ -852,11 +853,6 @@ void Detector::forward(const void* x, int n, int h, int w, float* prob, uint8_t*
 void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, uint8_t* bitmap, float thresh,
                              std::vector<ProfileEntry>* prof, int x_u8) {
   ensure_workspace(n, h, w);
-  if (w43_dynamic_ && !bf16_) {   // the block counters of this chunk's fused Winograd launches (the side stream's start behind main-stream events)
-    if (!w43_ctr_) OCR_HIP(hipMalloc(reinterpret_cast<void**>(&w43_ctr_), (size_t)kW43Slots * 32 * sizeof(int)));
-    OCR_HIP(hipMemsetAsync(w43_ctr_, 0, (size_t)kW43Slots * 32 * sizeof(int), stream_));
-    w43_slot_ = 0;
-  }
   Recorder rec(prof, stream_);
 
   struct Extra {
@@ -877,8 +873,13 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
   // that finds its CU taken starts late and still carries its full share - the launch takes twice as long.  While the polygon chain of
   // the PREVIOUS batch runs (pipelined calls: its tracer holds one whole CU per image for about a millisecond, right when this forward
   // starts), layer1's launches are sized for the CUs that are free: + 14 % on four launches instead of + 100 %
-  const int busy_cus = head_cus_yield_ && pending_.valid && pending_.prechained ? std::min(pending_.n, num_cus_ / 4) : 0;
+  // (head_cus_yield=1, the round-5 form, while the tracer held a whole CU per image.)  With the tracer's one-plane LDS image a forward workgroup
+  // shares the CU with it and runs at a fraction of its speed; head_cus_yield >= 2 OVERSUBSCRIBES layer1's grids instead - that many workgroups
+  // per resident slot, so the hardware hands the later ones to whichever CU drains first: a CU that is shared simply gets fewer of them.
+  const bool chain_beside = pending_.valid && pending_.prechained;
+  const int busy_cus = head_cus_yield_ == 1 && chain_beside ? std::min(pending_.n, num_cus_ / 4) : 0;
   int grid_cus = num_cus_ - busy_cus;
+  if (head_cus_yield_ >= 2 && chain_beside) grid_cus = num_cus_ * head_cus_yield_;
   const bool overlap3 = overlap_ >= 3 && !prof && fpn_composed_ && bin_pyr_on_ && fused_tail_ &&
                         (bf16_ ? (fpn_a_[0].w_bf16_c64 && bin_p2_.w_bf16_c64 && pyr_p2_direct_)
                                : (fpn_a_[0].wino43_fused && fpn_a_[1].wino43_fused && bin_p2_.wino43_fused && !fpn_a_[0].wino43_x3 && split_bf16_));
@@ -1065,11 +1066,9 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     if (!bf && cw.wino43_fused) {  // transforms fused into the GEMM kernel
       {
         rec.begin();
-        int* ctr = nullptr;   // this launch's counters (zeroed at the start of the chunk)
-        if (w43_dynamic_ && w43_ctr_ && w43_slot_ < kW43Slots) ctr = w43_ctr_ + 32 * w43_slot_++;
         launch_winograd43_fused(static_cast<const float*>(src), cw.wino43_fused, cw.scale, cw.bias, static_cast<const float*>(residual),
                                 relu ? 1 : 0, static_cast<float*>(out), n, hh, ww, cw.cin, cw.cout,
-                                cs != stream_ && w43_side_cus_ > 0 ? w43_side_cus_ : w43_cus_ > 0 ? w43_cus_ : (cs == stream_ && !ctr) ? grid_cus : num_cus_, cs, ctr);
+                                cs != stream_ && w43_side_cus_ > 0 ? w43_side_cus_ : w43_cus_ > 0 ? w43_cus_ : cs == stream_ ? grid_cus : num_cus_, cs);
         const double px43 = (double)n * hh * ww;
         rec.end(cw.cin == 64 ? "winograd43_fused<c64>" : cw.cin == 128 ? "winograd43_fused<c128>" : "winograd43_fused<c256>", 2.0 * 36.0 * (px43 / 16.0) * cw.cin * cw.cout,
                 px43 * 4.0 * (cw.cin + cw.cout * (residual ? 2.0 : 1.0)) + 36.0 * cw.cin * cw.cout * 4);

@@ -187,11 +187,7 @@ class Detector {
   // option bin_pyr=0 keeps the four-launch form.
   ConvW bin_pyr_;
   bool bin_pyr_on_ = true;
-  bool w43_dynamic_ = true;     // fused Winograd launches hand their blocks out through counters (winograd43_fused.hip); 0: static shares
-  int* w43_ctr_ = nullptr;      // kW43Slots x 32 counters, zeroed at the start of every forward chunk; one slot per fused launch
-  int w43_slot_ = 0;
-  static constexpr int kW43Slots = 64;
-  bool x3_wide_ = true;         // split-bf16 convs with NHWC stores and Cout % 128 == 0 on the 256 x 128 persistent form (conv_x3w.hip); 0: conv_igemm's 128-wide tiles.  Same bits
+  bool x3_wide_ = false;        // split-bf16 convs with NHWC stores and Cout % 128 == 0 on the 256 x 128 persistent form (conv_x3w.hip); 0: conv_igemm's 128-wide tiles.  Same bits
   bool phase_windows_ = true;   // split-bf16 up-2 phase convs indexed by 2 x 2 windows: one operand tile for the four phases (0: one 64-column tile per phase)
   bool pyr_grouped_ = true;     // split-bf16 / bf16 bin_conv1 over p5..p3: phase blocks as 128-column tiles + the corner phases (0: one 64-column tile per phase)
   bool pyr_p2_direct_ = true;   // bf16 precision: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv instead of nine taps of the phase launch
@@ -267,7 +263,7 @@ class Detector {
   int device_contours_ = -1;  // option device_contours (-1 = auto)
   int device_unclip_ = 1;     // option device_unclip: 0 host, 1 device where it pays (default), 2 device always
   bool device_polygons_ = true;   // option device_polygons
-  bool head_cus_yield_ = true;    // option head_cus_yield: layer1's persistent grids leave the previous batch's tracer its CUs (pipelined calls)
+  int head_cus_yield_ = 2;        // option head_cus_yield: layer1's persistent grids leave the previous batch's tracer its CUs (pipelined calls)
   bool post_priority_ = true;     // option post_priority: post-processing / trace streams at the device's highest stream priority
 };
 

@@ -46,11 +46,6 @@ __device__ __forceinline__ void load16(f32x4& v, R rsrc, unsigned voff, unsigned
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void settle(f32x4& v) { asm volatile("" : "+v"(v)::"memory"); }
-// returning atomic add as inline asm, for the same reason (v: the addend in, the counter's previous value out - once waited for)
-template <typename R>
-__device__ __forceinline__ void atomic_add_ret(int& v, R rsrc, unsigned voff) {
-  asm volatile("buffer_atomic_add %0, %1, %2, 0 offen sc0" : "+v"(v) : "v"(voff), "s"(rsrc) : "memory");
-}
 
 struct W43Args {
   const float* x;         // [N][H][W][C]
@@ -66,8 +61,6 @@ struct W43Args {
   int nblocks;
   int xcd_chunks;         // 1: every XCD (blockIdx & 7) walks its own contiguous run of blocks (launcher: grid % (8 kblocks) == 0)
   int debug;              // builds with -DW43_DEBUG only (ocr_test_w43_debug): 1 skip B loads, 2 skip the input transform, 4 skip patch DMA, 8 skip stores
-  int* ctr;               // dynamic hand-out of pixel blocks: 32 counters (XCD x output-channel block), ZERO before the launch; null = every
-                          // workgroup walks its static share (block q, q + stride, ...)
 };
 
 constexpr int PP = 18;                          // patch rows / columns
@@ -151,7 +144,6 @@ template <int NCH>
 __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
-  __shared__ int next_fetch;   // dynamic hand-out: what the counter returned for this workgroup's next block
 #ifdef W43_STAMPS
   __shared__ long long stamp_lds[2 * 4 * 32];
   __shared__ long long step_lds[2 * 4 * 26];
@@ -191,14 +183,6 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
     count = (c + (j < rem ? 1 : 0)) * p.kblocks;
   }
   const int kb = q % p.kblocks;   // constant over a workgroup's blocks: stride is a multiple of kblocks
-  // Dynamic hand-out (p.ctr): a workgroup's first block is block q as before; every further one comes from the counter of its (XCD,
-  // output-channel block), fetched one block ahead - during chunk 0 of the current block - so that the next patch can still be requested
-  // from inside the last chunk.  A workgroup that shares its CU with another kernel's waves (the polygon chain of the previous batch, the
-  // side stream's launches) then simply takes fewer blocks instead of holding the whole launch up with a full static share.
-  const bool dyn = p.ctr != nullptr;
-  const int per_kb = stride / p.kblocks;
-  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(dyn ? p.ctr : reinterpret_cast<int*>(const_cast<float*>(p.x)), 0, dyn ? 128u : 0u, 0x00020000);
-  const unsigned c_voff = (unsigned)((((p.xcd_chunks ? (blockIdx.x & 7) : 0) * 4 + kb) & 31) * 4);
 
   // ---- patch DMA, one patch row (18 pixels x 64 B = 1152 B) in two pieces: 16 pixels (a full 1 KB instruction; waves 0, 2)
   // and 2 pixels (lanes 0..7 only; waves 1, 3).  36 pieces, nine per wave = rows (wave >> 1) + 2 m.  The row part of the
@@ -248,13 +232,12 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
   const unsigned char* a_ptr = lds + V_OFF + (lane >> 4) * 256 + ((lane & 15) ^ (((lane >> 4) & 1) << 2)) * 16;
 
   bool patch_in_flight = false;  // chunk 0 of this block's patch was requested during the previous block
-  for (int lb = q; lb < count;) {
+  for (int lb = q; lb < count; lb += stride) {
     const int blk = first + lb;
     int n, y0, x0;
     coords(blk, n, y0, x0);
     W43_STAMP(0);
-    int next_lb = lb + stride;                 // (dynamic: replaced before the last chunk reads it)
-    bool has_next_block = next_lb < count;
+    const bool has_next_block = lb + stride < count;
     if (!patch_in_flight) {
       patch_columns(x0);
       issue_patch(n, y0, 0, 0);
@@ -272,14 +255,6 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
       if (c < 4) W43_STAMP(2 + 4 * c);   // (the first four chunks: c128 / c256 have more)
       // the B stream of a chunk starts here (the transform covers its latency) and drains inside the chunk: a value loaded by
       // inline asm must not be in flight across the loop's back edge, where the compiler may copy registers it believes ready
-      int fetched = 1;   // the addend; the counter's previous value once the chunk's loads have drained (it is the OLDEST of them: the
-                         // hand-counted waits below only ever wait for more than they did)
-      const bool fetch_here = dyn && c == 0 && wave == 0 && lane == 0;
-      if (fetch_here) atomic_add_ret(fetched, c_rsrc, c_voff);
-      if (dyn && c + 1 == NCH) {   // the last chunk: which block comes next (written during chunk 0, several barriers ago)
-        next_lb = (per_kb + *reinterpret_cast<volatile int*>(&next_fetch)) * p.kblocks + kb;
-        has_next_block = next_lb < count;
-      }
       issue_b(c * 12 + 0, ring[0]);
       issue_b(c * 12 + 1, ring[1]);
       issue_b(c * 12 + 2, ring[2]);
@@ -334,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         if (t == 0 && has_patch) {
           if (last_chunk) {
             int nn, ny0, nx0;
-            coords(first + next_lb, nn, ny0, nx0);
+            coords(blk + stride, nn, ny0, nx0);
             patch_columns(nx0);
             issue_patch(nn, ny0, 0, 0);
             patch_in_flight = true;
@@ -377,10 +352,6 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) acur[q] = anext[q];
-      }
-      if (fetch_here) {   // every load of the chunk has drained (vmcnt(0) at its last step), the atomic with them
-        asm volatile("" : "+v"(fetched)::"memory");
-        *reinterpret_cast<volatile int*>(&next_fetch) = fetched;
       }
     };
     // (Touching the residual block's lines one chunk ahead - 4 bytes per line into a dump area - made the epilogue's loads L2
@@ -470,7 +441,6 @@ __global__ __launch_bounds__(256, 2) void winograd43_fused_kernel(W43Args p) {
 #ifdef W43_STAMPS
     ++blk_count;
 #endif
-    lb = next_lb;
   }
 #ifdef W43_STAMPS
   __syncthreads();
@@ -512,7 +482,7 @@ void winograd43_set_debug(int d) { g_w43_debug = d; }
 int winograd43_get_debug() { return g_w43_debug; }
 
 void launch_winograd43_fused(const float* x, const float* ufrag, const float* scale, const float* bias, const float* residual,
-                             int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s, int* ctr) {
+                             int relu, float* y, int N, int H, int W, int C, int K, int num_cus, hipStream_t s) {
   if (N <= 0 || H <= 0 || W <= 0 || (C != 64 && C != 128 && C != 256) || K % 64)
     fail(OCR_ERR_INVALID, "fused Winograd F(4x4): bad shape N=%d H=%d W=%d C=%d K=%d", N, H, W, C, K);
   const long long xb = (long long)N * H * W * C * 4, ub = (long long)36 * C * K * 4;
@@ -539,7 +509,6 @@ void launch_winograd43_fused(const float* x, const float* ufrag, const float* sc
   if (blocks >= (1ll << 31)) fail(OCR_ERR_INVALID, "fused Winograd F(4x4): too many blocks");
   a.nblocks = (int)blocks;
   a.debug = g_w43_debug;
-  a.ctr = a.kblocks <= 4 ? ctr : nullptr;   // (32 counters: XCD x output-channel block)
   // persistent workgroups, two per CU; a multiple of kblocks so that each keeps its output-channel block, and of 8 kblocks
   // (when there are that many blocks) so that the eight XCDs can each walk a contiguous run of blocks
   long long grid = std::min<long long>(blocks, 2ll * (num_cus > 0 ? num_cus : 256));

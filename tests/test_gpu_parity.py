@@ -398,6 +398,8 @@ def test_stem_exact_and_inexact_tiles(det, det_w):
     "winograd43_x3=1",                                             # the fused F(4x4) convs on the bf16 matrix cores too (winograd43_x3.hip)
     "out4_fused=1",                                                # out4 on the fused kernel, out5 as a direct conv
     "winograd43_x3=1;out4_fused=1",                                # ... out4 through the 256-channel instantiation of winograd43_x3.hip
+    "x3_wide=1",                                                   # the split-bf16 NHWC convs on the 256 x 128 persistent form (conv_x3w.hip)
+    "x3_wide=1;overlap=0",
 ])
 def test_engine_modes_agree(det, det_w, options):
     """Every graph-level option of the engine (ocr_det_create_with_options) computes the same
@@ -428,6 +430,23 @@ def test_fused_transforms_are_bit_identical(det_w):
         finally:
             a.close()
             b.close()
+
+
+def test_wide_form_and_oversubscribed_grids_are_bit_identical(det_w):
+    """Which workgroup computes which tile is not part of the result: the split-bf16 NHWC convs on the 256 x 128 persistent form against the
+    128-wide tiles, and the fused Winograd launches on twice as many workgroups as the chip holds (head_cus_yield=2: what the pipelined calls
+    use while the previous batch's polygon chain shares the CUs) - the same map bit for bit, on a configs[1]-shaped batch and a ragged small one."""
+    for (n, h, w) in ((8, 640, 640), (3, 96, 160)):
+        x = W.synth_image_batch(47, n, h, w)
+        outs = []
+        for opt in ("overlap=0;x3_wide=0", "overlap=0;x3_wide=1", "overlap=0;w43_cus=512", "overlap=0;w43_cus=96"):
+            d = capi.Detector(W.pack_blob(det_w), 0, options=opt)
+            try:
+                outs.append((opt, d.forward_host(x)))
+            finally:
+                d.close()
+        for opt, o in outs[1:]:
+            assert np.array_equal(o, outs[0][1]), (opt, n, h, w)
 
 
 def test_phase_blocks_are_bit_identical(det_w):
