@@ -323,12 +323,17 @@ __device__ int walk_border(const uint32_t* bits, int h, int w, int x, int y, int
 // three planes' 150 KB, the reference's own 800 x 800 frames (/root/reference/src/text_detection/mod.rs:20-21) fit with 85 KB, and the CU keeps
 // room for the next forward's workgroups beside the tracer.
 constexpr int kBandRows = 64;
+constexpr int kParWords = 35840;   // largest LDS image of the parallel form (140 KB + scan scratch + the start cache): 1024 x 1024 fits
+constexpr int kKeyCache = 1024;   // plausible starts whose (key, length, offset) the scan reads from LDS instead of global memory
 template <int LW>
 __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* __restrict__ bits_all, int wpi, int h, int w, uint32_t* __restrict__ pts_all, int cap,
                                                               int* __restrict__ starts_all, int maxc, int* __restrict__ hdr_all, int* __restrict__ spec_all,
                                                               uint32_t* __restrict__ pool_all, int pool_cap) {
   __shared__ uint32_t lds[LW];
   __shared__ int sc[1024];
+  // the scan of phase B looks a start up in the list by a serial walk (one wave, dependent loads): from global memory that walk - a
+  // microsecond per entry, a few hundred entries per page - was most of the kernel; the first kKeyCache entries come from LDS
+  __shared__ int ckey[kKeyCache], clen[kKeyCache], coff[kKeyCache];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned npx = (unsigned)h * (unsigned)w, nw = (npx + 31) / 32;
@@ -409,8 +414,14 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
   __syncthreads();
   // the plane becomes the label plane
   for (unsigned i = tid; i <= nw; i += 1024) lds[i] = 0;
+  if (!status && tid < K && tid < kKeyCache) {
+    ckey[tid] = keys[tid];
+    clen[tid] = rlen[tid];
+    coff[tid] = roff[tid];
+  }
   __syncthreads();
   if (wave != 0) return;
+  auto key_at = [&](int i) -> int { return i < kKeyCache ? ckey[i] : keys[i]; };
   // ---- B: the raster scan with the label tests; borders come from the list
   uint32_t* pts = pts_all + (size_t)img * cap;
   int* starts = starts_all + (size_t)img * (maxc + 1);
@@ -468,12 +479,12 @@ __global__ __launch_bounds__(1024) void contour_parallel_kernel(const uint32_t* 
       xmin = x + 1;
       const unsigned i = (unsigned)y * w + x;
       const int key = 2 * (int)i + type;
-      while (ka < K && uni(keys[ka]) < key) ++ka;
-      if (ka >= K || uni(keys[ka]) != key) {   // a start the list does not hold: this image goes to the host tracer
+      while (ka < K && uni(key_at(ka)) < key) ++ka;
+      if (ka >= K || uni(key_at(ka)) != key) {   // a start the list does not hold: this image goes to the host tracer
         status = 3;
         break;
       }
-      const int len = uni(rlen[ka]), off = uni(roff[ka]);
+      const int len = uni(ka < kKeyCache ? clen[ka] : rlen[ka]), off = uni(ka < kKeyCache ? coff[ka] : roff[ka]);
       if (ncont >= maxc || npts + len > cap) {
         status = 1;
         break;
@@ -530,7 +541,7 @@ static size_t parallel_words(int h, int w) { return ((size_t)h * w + 31) / 32 + 
 static bool shape_ok(int h, int w) { return h > 0 && w > 0 && !(w & 31) && w <= 2048 && h <= 32767; }
 // the one-wave form keeps the bit image and two label planes in LDS
 static bool sequential_fits(int h, int w) { return shape_ok(h, w) && 3 * (((size_t)h * w + 31) / 32) + 1 <= (size_t)kLdsWords; }
-static bool parallel_fits(int h, int w) { return shape_ok(h, w) && h <= 1024 && w <= 2047 + 1 && parallel_words(h, w) <= (size_t)kLdsWords; }
+static bool parallel_fits(int h, int w) { return shape_ok(h, w) && h <= 1024 && parallel_words(h, w) <= (size_t)kParWords; }
 
 bool contour_trace_fits(int h, int w) { return parallel_fits(h, w) || sequential_fits(h, w); }
 
@@ -557,7 +568,7 @@ void launch_contour_trace(const uint32_t* bits, size_t words_per_image, int n, i
     else if (need <= 22528)
       hipLaunchKernelGGL(contour_parallel_kernel<22528>, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool, kContourPool);
     else
-      hipLaunchKernelGGL(contour_parallel_kernel<kLdsWords>, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool, kContourPool);
+      hipLaunchKernelGGL(contour_parallel_kernel<kParWords>, dim3((unsigned)n), dim3(1024), 0, s, bits, (int)words_per_image, h, w, pts, cap, starts, maxc, hdr, spec_i, pool, kContourPool);
   }
   OCR_HIP(hipGetLastError());
   hipLaunchKernelGGL(contour_compact_kernel, dim3((unsigned)n), dim3(256), 0, s, hdr, pts, cap, starts, maxc, pts_packed, lens_packed);
