@@ -234,6 +234,15 @@ def pmc_extract(dtype: str, n: int, s: int):
 
 
 PINNED_CPUS = None   # main(): the CPUs this rank pinned itself to (N > 1)
+def in_schedule_ms(name: str):
+    """Average duration of a kernel's launches in the SHIPPED two-stream schedule, from the committed rocprofv3 pass over the headline
+    command (profiles/pmc.json, `in_schedule`; tools/publish_profiles.sh): `avg_launch_ms` is measured live on ONE stream."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))["f32"]["in_schedule"]["kernels"][name]["avg_ms"]
+    except Exception:
+        return None
+
+
 STEM_FRAMES_BF16_EXACT = True  # main() clears it when the bench frames are not bf16-exact (they are raw luma: integers 0..255)
 
 
@@ -319,6 +328,16 @@ def cpu_baseline(det_w, rec_w, size: int, budget_s: float):
                           "sample": f"{it} x 32 text-like maps, oracle/postproc_cpu.cpp (product's host geometry, DESIGN 6), {el:.1f} s"}
     it1, el1 = post_rate(1, 1.5)
     out["postprocess"]["one_thread"] = {"value": round(it1 * 32 / el1, 1), "unit": "images/s", "cores": 1, "sample": f"{it1} x 32 maps, {el1:.1f} s"}
+    # ... and an INDEPENDENT one: the pure-Python restatement (oracle/postproc_oracle.py) - none of the product's code, one interpreter
+    # thread, a handful of maps.  (The compiled path above shares its geometry source with the library; this one shares nothing.)
+    from oracle import postproc_oracle as O
+    t0, k = time.perf_counter(), 0
+    while k < 8 and time.perf_counter() - t0 < 4.0:
+        O.get_boxes_and_box_scores(maps[k:k + 1], ones[:1], skip_degenerate=True)
+        k += 1
+    el2 = time.perf_counter() - t0
+    out["postprocess"]["python_oracle"] = {"value": round(k / el2, 2), "unit": "images/s", "cores": 1, "kind": "port",
+                                           "sample": f"{k} text-like maps, oracle/postproc_oracle.py (pure Python), {el2:.1f} s"}
     return out
 
 
@@ -557,6 +576,7 @@ def main():
                                 "FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; SQ_INSTS_VALU_MFMA_MOPS_F32/BF16 x 512; "
                                 "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE per XCD)",
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
+                "avg_launch_ms_in_schedule": in_schedule_ms(name),
                 "avg_launch_note": "one stream (ocr_det_forward_profile).  In the timed steps (engine option overlap=3, default) two of this kernel's six launches per step run on the "
                                    "side stream beside layer3 / layer4 and stretch; rocprofv3's average over ALL launches of the default command is therefore higher "
                                    "(profiles/README.md); with --det-options overlap=0 it is this number",
@@ -1074,7 +1094,7 @@ def main():
         line["summary"] = {
             "ms_per_step": line["ms_per_step"], "images_per_s": line["value"], "n_gpus": world, "dtype": a.dtype,
             "roofline": {"kernel": roof.get("kernel"), "frac": roof.get("frac"), "achieved_tflops": roof.get("achieved"), "peak_tflops": roof.get("peak"),
-                         "avg_launch_ms": roof.get("avg_launch_ms"), "traffic_bytes": roof.get("traffic"), "mfma_busy": roof.get("mfma_busy")},
+                         "avg_launch_ms": roof.get("avg_launch_ms"), "avg_launch_ms_in_schedule": roof.get("avg_launch_ms_in_schedule"), "traffic_bytes": roof.get("traffic"), "mfma_busy": roof.get("mfma_busy")},
             "f32_mfma_only_ms": (line.get("f32_mfma_only") or {}).get("ms_per_step"),
             "bf16": {k2: b16.get(k2) for k2 in ("ms_per_step", "images_per_s", "e2e_pages_per_s")} if b16 else None,
             "e2e_pages_per_s": line.get("e2e_pages_per_s"),

@@ -9,7 +9,7 @@
 # Back on the build box: tools/rocprof_stats_csv.py <out>/stats and tools/make_pmc_json.py turn the outputs into the CSV / JSON
 # files under profiles/.
 set -o pipefail
-O=$PWD/gpurun_out/${1:-r05/final}
+O=$PWD/gpurun_out/${1:-r06/final}
 mkdir -p $O
 export TMPDIR=/tmp
 python3 -c "import bench; print(bench.csrc_hash())" > $O/csrc_sha.txt   # the kernel sources these passes ran (stamps profiles/pmc.json)
@@ -39,5 +39,11 @@ python3 tools/profile_layers.py 32 640 5 0 "precision=bf16" > $O/layers_bf16.txt
 python3 bench.py --steps 20 --warmup 3 --dtype bf16 > $O/bench_line_bf16.json 2>/dev/null || exit 1
 python3 tools/accuracy_report.py > $O/accuracy_modes.txt 2>/dev/null || exit 1
 python3 tools/bench_rec.py > $O/rec_batches.txt 2>/dev/null || exit 1
+# the polygon chain beside the forward: per-kernel durations of pipelined detect calls (dense pages, chain on the device) and of forwards alone
+rocprofv3 --kernel-trace --stats -d $O/stats_chain -o t -- python3 tools/pipeline_trace.py chain > $O/pipeline_chain.txt 2>/dev/null || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats_fwd -o t -- python3 tools/pipeline_trace.py forward > $O/pipeline_forward.txt 2>/dev/null || exit 1
+# the 256 x 128 persistent split-bf16 form against the 128-wide tiles, launch shape by launch shape
+python3 tools/bench_x3w.py > $O/x3w_ab.txt 2>/dev/null || exit 1
+echo "chain / wide-form passes done"
 python3 bench.py --steps 20 --warmup 3 > $O/bench_line_plain.json 2>/dev/null || exit 1
 echo "all done"

@@ -108,50 +108,55 @@ def per_label(rows):
     return agg
 
 
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (csrc_hash)
+def main():
+    global LABELS
+    sys.path.insert(0, ROOT)
+    import bench  # (csrc_hash)
+    args = sys.argv[1:]
+    if "--labels" in args:
+        i = args.index("--labels")
+        LABELS = [m.group(1) for m in (re.match(r"\s*\d+\s+(\S+)\s+[0-9.]+\s", ln) for ln in open(args[i + 1])) if m]
+        del args[i:i + 2]
+    dtype, d_fetch, d_write, d_mops, d_busy = args[:5]
+    tag = args[5] if len(args) > 5 else "r04"
+    fetch = per_label(second_half(load(d_fetch, "FETCH_SIZE")))
+    write = per_label(second_half(load(d_write, "WRITE_SIZE")))
+    mf32 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_F32")))
+    mbf16 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_BF16")))
+    busy = per_label(second_half(load(d_busy, "SQ_VALU_MFMA_BUSY_CYCLES")))
+    gui = per_label(second_half(load(d_busy, "GRBM_GUI_ACTIVE")))
+    sha_file = os.path.join(os.path.dirname(os.path.abspath(d_fetch)), "csrc_sha.txt")   # written on the GPU box by collect_profiles.sh
+    csrc_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else bench.csrc_hash()
+    entry = {"batch": 32, "size": 640, "csrc_sha": csrc_sha,
+             "source": f"rocprofv3 --pmc, one counter set per pass over tools/profile_layers.py 32 640 1 ({dtype}); profiles/{tag}_pmc_{dtype}.csv",
+             "kernels": {}}
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{dtype}.csv"), "w") as fcsv:
+        fcsv.write("kernel,launches,fetch_bytes_per_launch_corrected,write_bytes_per_launch,mfma_flops_f32_per_launch,mfma_flops_bf16_per_launch,mfma_busy\n")
+        for k, (f, n) in fetch.items():
+            w = write.get(k, [0.0, n])[0]
+            ff = mf32.get(k, [0.0, n])[0] * 512
+            fb = mbf16.get(k, [0.0, n])[0] * 512
+            bz = busy.get(k, [0.0, n])[0]
+            g = gui.get(k, [0.0, n])[0]
+            share = bz / (1024.0 * g / 8.0) if g > 0 else None
+            entry["kernels"][k] = {"launches": n, "fetch_bytes": round(f * 1024 * 2 / n), "write_bytes": round(w * 1024 / n),
+                                   "hbm_bytes": round((f * 1024 * 2 + w * 1024) / n), "mfma_flops": round((ff + fb) / n),
+                                   "mfma_flops_f32": round(ff / n), "mfma_flops_bf16": round(fb / n),
+                                   "mfma_busy": None if share is None else round(share, 4)}
+            fcsv.write(f'"{k}",{n},{f * 1024 * 2 / n:.0f},{w * 1024 / n:.0f},{ff / n:.0f},{fb / n:.0f},{"" if share is None else f"{share:.4f}"}\n')
+    if len(args) > 7:   # recogniser passes (tools/profile_rec.py 65536): fetch dir, write dir
+        rf, rw = per_label(second_half(load(args[6], "FETCH_SIZE"), False)), per_label(second_half(load(args[7], "WRITE_SIZE"), False))
+        entry["recogniser_b65536"] = {("rec_fc1" if k.startswith("conv_igemm") else k): {"launches": n, "hbm_bytes": round((f * 1024 * 2 + rw.get(k, [0.0, n])[0] * 1024) / n)}
+                                      for k, (f, n) in rf.items()}
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    try:
+        allp = json.load(open(path))
+    except Exception:
+        allp = {}
+    allp[dtype] = entry
+    json.dump(allp, open(path, "w"), indent=1)
+    print(json.dumps(entry["kernels"], indent=1))
 
-args = sys.argv[1:]
-if "--labels" in args:
-    i = args.index("--labels")
-    LABELS = [m.group(1) for m in (re.match(r"\s*\d+\s+(\S+)\s+[0-9.]+\s", ln) for ln in open(args[i + 1])) if m]
-    del args[i:i + 2]
-dtype, d_fetch, d_write, d_mops, d_busy = args[:5]
-tag = args[5] if len(args) > 5 else "r04"
-fetch = per_label(second_half(load(d_fetch, "FETCH_SIZE")))
-write = per_label(second_half(load(d_write, "WRITE_SIZE")))
-mf32 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_F32")))
-mbf16 = per_label(second_half(load(d_mops, "SQ_INSTS_VALU_MFMA_MOPS_BF16")))
-busy = per_label(second_half(load(d_busy, "SQ_VALU_MFMA_BUSY_CYCLES")))
-gui = per_label(second_half(load(d_busy, "GRBM_GUI_ACTIVE")))
-sha_file = os.path.join(os.path.dirname(os.path.abspath(d_fetch)), "csrc_sha.txt")   # written on the GPU box by collect_profiles.sh
-csrc_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else bench.csrc_hash()
-entry = {"batch": 32, "size": 640, "csrc_sha": csrc_sha,
-         "source": f"rocprofv3 --pmc, one counter set per pass over tools/profile_layers.py 32 640 1 ({dtype}); profiles/{tag}_pmc_{dtype}.csv",
-         "kernels": {}}
-with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{dtype}.csv"), "w") as fcsv:
-    fcsv.write("kernel,launches,fetch_bytes_per_launch_corrected,write_bytes_per_launch,mfma_flops_f32_per_launch,mfma_flops_bf16_per_launch,mfma_busy\n")
-    for k, (f, n) in fetch.items():
-        w = write.get(k, [0.0, n])[0]
-        ff = mf32.get(k, [0.0, n])[0] * 512
-        fb = mbf16.get(k, [0.0, n])[0] * 512
-        bz = busy.get(k, [0.0, n])[0]
-        g = gui.get(k, [0.0, n])[0]
-        share = bz / (1024.0 * g / 8.0) if g > 0 else None
-        entry["kernels"][k] = {"launches": n, "fetch_bytes": round(f * 1024 * 2 / n), "write_bytes": round(w * 1024 / n),
-                               "hbm_bytes": round((f * 1024 * 2 + w * 1024) / n), "mfma_flops": round((ff + fb) / n),
-                               "mfma_flops_f32": round(ff / n), "mfma_flops_bf16": round(fb / n),
-                               "mfma_busy": None if share is None else round(share, 4)}
-        fcsv.write(f'"{k}",{n},{f * 1024 * 2 / n:.0f},{w * 1024 / n:.0f},{ff / n:.0f},{fb / n:.0f},{"" if share is None else f"{share:.4f}"}\n')
-if len(args) > 7:   # recogniser passes (tools/profile_rec.py 65536): fetch dir, write dir
-    rf, rw = per_label(second_half(load(args[6], "FETCH_SIZE"), False)), per_label(second_half(load(args[7], "WRITE_SIZE"), False))
-    entry["recogniser_b65536"] = {("rec_fc1" if k.startswith("conv_igemm") else k): {"launches": n, "hbm_bytes": round((f * 1024 * 2 + rw.get(k, [0.0, n])[0] * 1024) / n)}
-                                  for k, (f, n) in rf.items()}
-path = os.path.join(ROOT, "profiles", "pmc.json")
-try:
-    allp = json.load(open(path))
-except Exception:
-    allp = {}
-allp[dtype] = entry
-json.dump(allp, open(path, "w"), indent=1)
-print(json.dumps(entry["kernels"], indent=1))
+
+if __name__ == "__main__":
+    main()
