@@ -740,7 +740,13 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs p) {
     // arithmetic - to its first use behind the barrier, where no MFMA of this wave covers it)
     auto phase = [&](const Frag& cur, int rd_stage, int rd_kk, Raw& nraw, Frag& nxt, int dma_stage) {   // dma_stage < 0: no DMA in this phase
       constexpr int Q = 6 * NT / 4;   // MFMAs per region
+#if defined(IGEMM_DMA_EARLY)      // experiment: every piece behind the first region / behind the last one
+      constexpr int D1 = NP, D2 = NP, D3 = NP;
+#elif defined(IGEMM_DMA_LATE)
+      constexpr int D1 = 0, D2 = 0, D3 = 0;
+#else
       constexpr int D1 = NP == 10 ? 3 : 2, D2 = NP == 10 ? 6 : 4, D3 = NP == 10 ? 8 : 6;
+#endif
       constexpr int E1 = NT == 4 ? 4 : 3;   // split elements per region: [0, E1), [E1, 6), [6, 8) (NT = 4: whole cvt_pk pairs)
       read_frag(rd_stage, rd_kk, nraw, nxt);
       static_for<0, Q>([&](auto i) { mfma_at(cur, i); });

@@ -295,8 +295,15 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       }
     }
+#if defined(X3W_DMA_EARLY)   // experiments: every piece behind the first region / behind the last one
+    constexpr int P1 = NP, P2 = NP, P3 = NP;
+#elif defined(X3W_DMA_LATE)
+    constexpr int P1 = 0, P2 = 0, P3 = 0;
+#else
+    constexpr int P1 = 2, P2 = 4, P3 = 6;
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    if (dma_stage >= 0) static_for<0, 2>([&](auto i) { dma_piece(dma_stage, i); });
+    if (dma_stage >= 0) static_for<0, P1>([&](auto i) { dma_piece(dma_stage, i); });
     if (active) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(nraw.a0[i]), "+v"(nraw.a1[i]));
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (dma_stage >= 0) static_for<2, 4>([&](auto i) { dma_piece(dma_stage, i); });
+    if (dma_stage >= 0) static_for<P1, P2>([&](auto i) { dma_piece(dma_stage, i); });
     if (active) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(nraw.a0[i]), "+v"(nraw.a1[i]));
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (dma_stage >= 0) static_for<4, 6>([&](auto i) { dma_piece(dma_stage, i); });
+    if (dma_stage >= 0) static_for<P2, P3>([&](auto i) { dma_piece(dma_stage, i); });
     if (active) {
       asm volatile("" : "+v"(nraw.a0[1]), "+v"(nraw.a1[1]));
       static_for<3 * Q, 4 * Q>([&](auto i) { mfma_at(cur, i); });
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (dma_stage >= 0) static_for<6, NP>([&](auto i) { dma_piece(dma_stage, i); });
+    if (dma_stage >= 0) static_for<P3, NP>([&](auto i) { dma_piece(dma_stage, i); });
   };
 
   // ---- epilogue of one tile, straight from the accumulators (C/D map of a 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) +
@@ -406,6 +413,9 @@ __global__ __launch_bounds__(512) void conv_x3_wide(Args p) {
     split_part(rw, fx, std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
   }
   int par = 0;
+#if defined(X3W_PRIO)   // experiment: static priority for the second-dispatched half (the arbitration loser of every SIMD pair)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   for (;;) {
     const bool act = wm < mt.cnt;
     const int nxt_cur = m_cur + mt.cnt;

@@ -143,3 +143,32 @@ def test_all_reference_fixtures_device_chain_equals_the_oracle(blob, golden_dir)
     # the host inside the same call: one of the twelve here)
     assert st["images_device_chain"] == 4 and st["images_host_traced"] == 0 and st["candidates_host"] <= 2, st
     assert st["candidates_device"] + st["candidates_host"] == 12 and sum(len(p) for p in polys) >= 10
+
+
+def test_frames_to_polygons_at_the_reference_frame_size_against_the_oracle_chain():
+    """The reference's default frame (text_detection/mod.rs:20-21: 800 x 800) from FRAMES to polygons with the forward and every step of
+    the chain on the device, against the oracle chain on its own map (ATen CPU -> Python restatement): dense pages (about 100 words each),
+    pages without a binarisation flip must give identical lists."""
+    from oracle import torch_ref as T
+    n, s = 3, 800
+    det_w = W.make_det_weights_text()
+    frames, boxes = W.synth_text_pages(2031, n, s, s, dense=True)
+    det = capi.Detector(W.pack_blob(det_w), 0, options=CHAIN)
+    prob = det.forward_host(frames)
+    adj = np.array([[800 / 300, 533 / 200], [1.0, 1.0], [1.25, 0.8]])
+    polys, scores = det.postprocess(prob, n, s, s, adj, capi.MEM_HOST, capi.default_params(skip_degenerate=True))
+    st = det.post_stats()
+    det.close()
+    ref_prob = np.concatenate([T.det_forward(det_w, frames[i:i + 1]) for i in range(n)])
+    ref_polys, ref_scores = O.get_boxes_and_box_scores(ref_prob, adj, skip_degenerate=True)
+    assert float(np.abs(prob - ref_prob).max()) < 1e-4
+    assert st["images_device_chain"] == n and st["images_host_traced"] == 0, st
+    flips = ((prob > np.float32(0.6)) != (ref_prob > np.float32(0.6))).reshape(n, -1).sum(axis=1)
+    assert sum(len(p) for p in ref_polys) > 60 * n
+    same = 0
+    for i in range(n):
+        if flips[i] == 0:
+            assert polys[i] == ref_polys[i], f"page {i}"
+            assert np.allclose(scores[i], ref_scores[i], rtol=0, atol=1e-6)
+            same += 1
+    assert same >= n - 1
