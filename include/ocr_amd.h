@@ -105,8 +105,8 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *                               the ring is simple or only crosses itself at its concave vertices, min-size test, round(p / adj).  What it does
  *                               not settle (other self-intersections, squared-off corners, a short side within 3 px of min_size) the host
  *                               finishes inside the same call; results are bit for bit the host path's (0)
- *   device_contours=auto|0|1|2 (auto)  the contour tracing of ocr_det_postprocess / the pipelined calls on the GPU (contours.hip; maps up to
- *                               640 x 640 - larger ones, and images the kernel gives up on, take the host tracer inside the same call).
+ *   device_contours=auto|0|1|2 (auto)  the contour tracing of ocr_det_postprocess / the pipelined calls on the GPU (contours.hip; one bit plane of the map
+ *                               in LDS: up to 1024 x 1024, the reference's 800 x 800 included - larger maps, and images the kernel gives up on, take the host tracer inside the same call).
  *                               1: plausible border starts walked in parallel, the raster scan only replays the label tests, a row at a time as
  *                               word-wide bit arithmetic (0.35-0.5 ms per batch; the pipelined calls request it when they queue a batch); 2: one wave per image.  Identical
  *                               contours either way.  auto: 1 where the host pool (post_threads) has at most four threads, else 0: by

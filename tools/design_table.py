@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Rows of DESIGN.md section 3.1 from profiles/<tag>_layers_f32.txt and profiles/pmc.json: per launch label the launches of a step, their
 summed time, executed MFMA FLOPs / time / the peak of the instruction issued, the MFMA-busy counter, HBM bytes per launch.
-usage: tools/design_table.py [tag, default r05]"""
+usage: tools/design_table.py [tag, default r06]"""
 import collections, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))["f32"]["kernels"]
 t = collections.OrderedDict()
 for ln in open(os.path.join(ROOT, "profiles", f"{tag}_layers_f32.txt")):
