@@ -113,3 +113,16 @@ def test_failed_exchange_is_never_a_clean_exit():
     assert r.returncode != 0
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["exchange_ok"] is False
+
+
+def test_committed_counter_extract_belongs_to_the_committed_kernels():
+    """profiles/pmc.json (HBM traffic, MFMA counters, in-schedule launch averages that bench.py's roofline block cites) is stamped with a
+    hash of ocr-rs_amd/csrc taken on the GPU box: the committed extract must be the one of the committed kernel sources, or the line
+    says `traffic_stale: true`."""
+    sys.path.insert(0, os.path.dirname(BENCH))
+    import bench
+    j = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))
+    assert j["f32"]["csrc_sha"] == j["bf16"]["csrc_sha"] == bench.csrc_hash()
+    k, src, stale = bench.pmc_extract("f32", 32, 640)
+    assert stale is False and "winograd43_fused<c64>" in k
+    assert bench.in_schedule_ms("winograd43_fused<c64>") > 0.15
