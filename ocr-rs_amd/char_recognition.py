@@ -38,6 +38,15 @@ class Net:
         labels, probs = self._rec.classify_host(np.ascontiguousarray(xs, dtype=np.float32).reshape(-1, 784))
         return [(VALUES[int(i)], float(p)) for i, p in zip(labels, probs)]
 
+    def ctc_greedy_decode(self, logits: np.ndarray, blank: int = VALUES_COUNT) -> List[str]:
+        """EXTENSION (the reference has no sequence recogniser): CTC best-path decode of N x T x C logits over the reference's alphabet
+        (utils.rs:7: classes 0..61 = VALUES) plus a blank (default: class 62) -> one string per crop."""
+        labels, lengths = self._rec.ctc_greedy_decode(np.ascontiguousarray(logits, dtype=np.float32), blank)
+        out = []
+        for row, n in zip(labels, lengths):
+            out.append("".join(VALUES[int(k)] if 0 <= int(k) < VALUES_COUNT else "?" for k in row[:int(n)]))
+        return out
+
     def close(self):
         self._rec.close()
 

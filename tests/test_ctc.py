@@ -82,3 +82,19 @@ def test_device_ctc_greedy_decode_equals_the_oracle():
     with pytest.raises(capi.OcrError):
         rec.ctc_greedy_decode(x, 63)
     rec.close()
+
+
+@pytest.mark.gpu
+def test_reference_named_mirror_decodes_to_strings():
+    """char_recognition.Net.ctc_greedy_decode: classes 0..61 are the reference's alphabet (utils.rs:7), class 62 the blank"""
+    import ocr_rs_amd  # noqa: F401
+    from ocr_rs_amd import char_recognition as cr
+    from ocr_rs_amd import weights as W
+    net = cr.Net(W.pack_blob(W.make_rec_weights(0)), 0)
+    word = [7, 7, 62, 30, 62, 37, 37, 62, 37, 40, 62, 62, 52, 53]        # H e l l o 0 1 with repeats and blanks
+    x = np.full((2, len(word), 63), -4.0, np.float32)
+    for t, k in enumerate(word):
+        x[0, t, k] = 3.0
+    x[1, :, 62] = 1.0                                                     # all blank
+    assert net.ctc_greedy_decode(x) == ["Hello01", ""]
+    net.close()
