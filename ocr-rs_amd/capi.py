@@ -194,6 +194,8 @@ def test_lib() -> C.CDLL:
         L.ocr_test_conv_run.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] +
                                         [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 2)
         L.ocr_test_set_conv_tile.argtypes = [C.c_int]
+        L.ocr_test_bf16_basic_block.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 6 + [C.c_int] * 3 +
+                                                [C.c_void_p, C.POINTER(C.c_float)])
         L.ocr_test_winograd_conv.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int] +
                                              [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p])
         L.ocr_test_det_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -463,6 +465,21 @@ class Detector:
                                            stride, p(sc), p(bi), p(rs), p(ur), int(relu), int(bool(cat4_shape)), int(variant),
                                            p(out), p(out2)))
         return out, out2
+
+    def debug_bf16_basic_block(self, x_nhwc, w1, w2, scale1=None, bias1=None, scale2=None, bias2=None, fused=True, num_cus=0, iters=1):
+        """one BasicBlock 64 -> 64 of the bf16 precision (test hook): fused = basic_block_bf16_c64.hip (one launch), otherwise two
+        conv3x3_bf16_c64 launches.  x N x H x W x 64 f32 (rounded to bf16 inside), w [64][9][64].  Returns (out f32, ms per block)."""
+        x = np.ascontiguousarray(x_nhwc, dtype=np.float32)
+        n, h, w, c = x.shape
+        assert c == 64
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        p = lambda a: None if a is None else _ptr(a)
+        w1, w2, s1, b1, s2, b2 = f(w1), f(w2), f(scale1), f(bias1), f(scale2), f(bias2)
+        out = np.empty_like(x)
+        ms = C.c_float(0.0)
+        check(test_lib().ocr_test_bf16_basic_block(self._h, _ptr(x), n, h, w, _ptr(w1), p(s1), p(b1), _ptr(w2), p(s2), p(b2), int(bool(fused)),
+                                                   int(num_cus), int(iters), _ptr(out), C.byref(ms)))
+        return out, ms.value
 
     def debug_gemm_batched(self, x_bmk, w_bnk, variant=2, scale=None, bias=None, relu=False):
         """B independent GEMMs out[b] = x[b] @ w[b].T through conv_igemm's batched 1x1 mode (test hook; what the Winograd GEMMs of layer3 /

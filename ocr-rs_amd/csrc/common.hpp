@@ -125,6 +125,12 @@ void launch_stem_x3(const void* x, int x_u8, const void* wfrag3, const float* sc
 std::vector<uint16_t> conv3x3_bf16_c64_fragments(const float* ohwi);
 void launch_conv3x3_bf16_c64(const void* x, const void* wfrag, const float* scale, const float* bias, const void* residual, int relu,
                              void* y, int N, int H, int W, int num_cus, hipStream_t s);
+// bf16 precision: one BasicBlock 64 -> 64 (conv3x3 + BN + ReLU, conv3x3 + BN, + x, ReLU) as one launch, the activation between the two
+// convs held in LDS (basic_block_bf16_c64.hip); fragments of both convs from conv3x3_bf16_c64_fragments.  Bit-identical to two
+// launch_conv3x3_bf16_c64 calls.  num_cus sizes the persistent grid (one workgroup per CU)
+bool basic_block_bf16_c64_applicable(int N, int H, int W);
+void launch_basic_block_bf16_c64(const void* x, const void* wfrag1, const float* scale1, const float* bias1, const void* wfrag2, const float* scale2,
+                                 const float* bias2, void* y, int N, int H, int W, int num_cus, hipStream_t s);
 // Winograd F(m x m, 3x3) transforms, m = 2 or 4, around a batched GEMM of (m+2)^2 problems (winograd.hip): 3x3 s1 p1 convs
 // of the deep, small-grid layers.  x: [N][H][W][C] f32 -> v: [(m+2)^2][T][C], T = N * ceil(H/m) * ceil(W/m) tiles (zero
 // padding and ragged sizes handled here); mm: [(m+2)^2][T][K] -> y: [N][H][W][K] with folded BN, residual and ReLU.

@@ -4,7 +4,11 @@
 // at best for 64 output channels: 460-620 TFLOP/s measured, neither roofline).  Here the input is staged ONCE:
 //   * a workgroup owns an 8 x 16 pixel block and all 64 output channels; its 10 x 18 x 64 bf16 patch (23 KB, one
 //     128-byte LDS row per pixel) arrives by LDS-DMA, double-buffered across the blocks of a persistent workgroup;
-//   * the nine taps are nine shifted reads of that patch (ds_read_b128, XOR-swizzled by pixel);
+//   * the nine taps are nine shifted reads of that patch (ds_read_b128).  Pixel (row, col) of the patch sits in LDS row row * 18 + col,
+//     its 16-byte chunk c in slot c ^ sw, sw = ((col >> 1) & 7) ^ 4 (row & 1); an MFMA row tile is 2 patch rows x 16 columns with the
+//     second row's columns XOR 8 (lane l31 >= 16 -> column (l31 & 15) ^ 8).  A ds_read_b128 is served in the lane groups {0-3, 12-15,
+//     20-27}, {4-11, 16-19, 28-31} (+ 32): with this map a group's sixteen lanes read sixteen different 16-byte bank slots for every
+//     tap - 4 LDS cycles per read, where the first layout (swizzle by linear pixel index, plain second row) took 8;
 //   * the weights live in REGISTERS for the whole launch: wave w owns output channels 32 (w & 1) .. + 31 and pixel
 //     rows 4 (w >> 1) .. + 3 of the block (two 32-pixel MFMA row tiles): 9 taps x 4 k-steps x 4 VGPRs = 144 VGPRs.
 // HBM traffic is the compulsory one (+ 40 % halo from L2): the kernel is bound by HBM, not by operand staging.
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
     n_ = bb / p.bh;
   };
   // the patch of block bb into buffer `buf`: 23 DMA instructions of 8 pixels (zero padding = out-of-range lanes);
-  // pixel px of the patch lands in row px, its 16-byte chunk c in slot c ^ ((px >> 1) & 7)
+  // pixel px = (py, pxx) of the patch lands in row px, its 16-byte chunk c in slot c ^ ((pxx >> 1) & 7) ^ 4 (py & 1)
   auto issue_patch = [&](int bb, int buf) {
     int pn, py0, px0;
     coords(bb, pn, py0, px0);
@@ -98,16 +102,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
       const int py = px / PWD, pxx = px - py * PWD;
       const int yy = py0 - 1 + py, xx = px0 - 1 + pxx;
       const bool inside = px < PH * PWD && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const int chunk = slot ^ ((px >> 1) & 7);
+      const int chunk = slot ^ ((pxx >> 1) & 7) ^ ((py & 1) << 2);
       const unsigned off = inside ? (unsigned)((((pn * p.H + yy) * p.W + xx) * 64 + chunk * 8) * 2) : OOB;
       dma16(x_rsrc, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * PATCH_BYTES + k * 1024)), off, 0);
     }
   };
 
-  // this lane's pixels: row tile r of the wave covers block rows 4 rp + 2 r, + 1; lane -> (row l31 >> 4, column l31 & 15)
-  int pix0[2];
+  // this lane's pixels: row tile r of the wave covers block rows 4 rp + 2 r, + 1; lane -> (row l31 >> 4, column l31 & 15, XOR 8 in
+  // the second row); key = col + 8 row: the swizzle of the pixel a tap reads is ((key + 8 ty + tx) >> 1) & 7
+  int pix0[2], key0[2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) pix0[r] = (4 * rp + 2 * r + (l31 >> 4)) * PWD + (l31 & 15);
+  for (int r = 0; r < 2; ++r) {
+    const int row = 4 * rp + 2 * r + (l31 >> 4), col = l31 < 16 ? l31 : ((l31 & 15) ^ 8);
+    pix0[r] = row * PWD + col;
+    key0[r] = col + 8 * row;
+  }
 
   float* ex = reinterpret_cast<float*>(lds + 2 * PATCH_BYTES);
   issue_patch(blockIdx.x, 0);
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
       for (int r = 0; r < 2; ++r) {
         const int pix = pix0[r] + toff + opaque;
         const unsigned char* row = patch + pix * 128;
-        const int sw = (pix >> 1) & 7;
+        const int sw = ((key0[r] + 8 * (t / 3) + (t % 3) + opaque) >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(row + (((2 * s + half) ^ sw) << 4));
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
       // scratch and 0.09-0.12 ms instead of 0.076-0.087) spills the register-resident weights
       __builtin_amdgcn_sched_barrier(0);
     }
-    // folded BN, then pixel-major through LDS: row = pixel of the block (y * 16 + x), column = output channel
+    // folded BN, then through LDS: row = 32 x row tile + tile row, column = output channel
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -185,8 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
       const int yy = y0 + (px >> 4), xx = x0 + (px & 15);
       if (yy < p.H && xx < p.W) {
         const size_t o = (((size_t)n * p.H + yy) * p.W + xx) * 64 + c8;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ex[px * EXROW + c8]);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ex[px * EXROW + c8 + 4]);
+        const int prow = px >> 4, pcol = px & 15;
+        const int er = 32 * (prow >> 1) + ((prow & 1) ? 16 + (pcol ^ 8) : pcol);   // the exchange row of this pixel
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ex[er * EXROW + c8]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ex[er * EXROW + c8 + 4]);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (p.residual) {
           const bf16x8 rr = __builtin_bit_cast(bf16x8, res[k]);

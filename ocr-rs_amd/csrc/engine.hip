@@ -249,6 +249,7 @@ void Detector::parse_options(const char* options) {
     else if (key == "pyr_grouped") pyr_grouped_ = num() != 0;
     else if (key == "phase_windows") phase_windows_ = num() != 0;
     else if (key == "x3_wide") x3_wide_ = num() != 0;
+    else if (key == "bf16_block_fuse") bf16_block_fuse_ = num() != 0;
     else if (key == "tail_unfused") fused_tail_ = num() == 0;
     else if (key == "overlap") {
       overlap_ = num();
@@ -1129,38 +1130,56 @@ void Detector::forward_chunk(const void* x, int n, int h, int w, float* prob, ui
     const int hin = l == 0 ? h4 : (h >> (1 + l)), win = l == 0 ? w4 : (w >> (1 + l));
     const int ho = h >> (2 + l), wo = w >> (2 + l);
     const int stride = l == 0 ? 1 : 2;
-    Extra sc;
-    sc.residual = cur;
-    if (l > 0 && overlap_small) {
-      fork([&] { conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false); });
-      conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
-      join();
-      sc.residual = d_[l];
-    } else {
-      if (l == 0) conv3x3("layer.conv1", layer_[l][0][0], cur, hin, win, t_[l], nullptr);  // stride 1 in layer1
-      else conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
-      if (l > 0) {
-        conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
-        sc.residual = d_[l];
+    const bool block_fused = l == 0 && bf && bf16_block_fuse_ && layer_[0][0][0].w_bf16_c64 && layer_[0][0][1].w_bf16_c64 && layer_[0][1][0].w_bf16_c64 &&
+        layer_[0][1][1].w_bf16_c64 && basic_block_bf16_c64_applicable(n, ho, wo);
+    if (block_fused) {
+      // bf16 precision: each of layer1's BasicBlocks as ONE launch, the activation between its two convs stays in LDS (same bits as
+      // the two conv3x3_bf16_c64 launches; model.rs:40-55)
+      const void* bin = cur;
+      void* bout[2] = {a_[0], x_[0]};
+      for (int b = 0; b < 2; ++b) {
+        const ConvW &c1 = layer_[0][b][0], &c2 = layer_[0][b][1];
+        rec.begin();
+        launch_basic_block_bf16_c64(bin, c1.w_bf16_c64, c1.scale, c1.bias, c2.w_bf16_c64, c2.scale, c2.bias, bout[b], n, ho, wo,
+                                    cs == stream_ ? grid_cus : num_cus_, cs);
+        const double px = (double)n * ho * wo;
+        rec.end("basic_block_bf16_c64", 2.0 * 2.0 * px * 64 * 576, px * 2.0 * 64 * 2.0 + 2.0 * 9.0 * 64 * 64 * 2);
+        bin = bout[b];
       }
-    }
-    if (transform_fuse_ && wino43_unfused(layer_[l][0][1], ho, wo) && wino43_unfused(layer_[l][1][0], ho, wo) && wino43_unfused(layer_[l][1][1], ho, wo)) {
-      // three unfused F(4x4) convs in a row (layer3 / layer4): conv1's output inside block 1 is read by conv2 only - M -> y -> V in one
-      // launch, the activation never reaches HBM (model.rs:40-55)
-      // (the pair around the block boundary keeps its two launches: there y = a_[l] must be written anyway - the residual of block 1 -
-      // and the fused launch, one workgroup per CU for its LDS image, is slower than the two streaming kernels: 0.107 vs 0.077 ms at H/16)
-      wino_in(layer_[l][0][1], t_[l], ho, wo);
-      wino_gemm("layer.conv2", layer_[l][0][1], ho, wo);
-      wino_out(layer_[l][0][1], ho, wo, a_[l], sc.residual, true);
-      wino_in(layer_[l][1][0], a_[l], ho, wo);
-      wino_gemm("layer.conv1", layer_[l][1][0], ho, wo);
-      wino_out_in(layer_[l][1][0], ho, wo, nullptr, nullptr, true);
-      wino_gemm("layer.conv2", layer_[l][1][1], ho, wo);
-      wino_out(layer_[l][1][1], ho, wo, x_[l], a_[l], true);
     } else {
-      conv3x3("layer.conv2", layer_[l][0][1], t_[l], ho, wo, a_[l], sc.residual);
-      conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
-      conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
+      Extra sc;
+      sc.residual = cur;
+      if (l > 0 && overlap_small) {
+        fork([&] { conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false); });
+        conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
+        join();
+        sc.residual = d_[l];
+      } else {
+        if (l == 0) conv3x3("layer.conv1", layer_[l][0][0], cur, hin, win, t_[l], nullptr);  // stride 1 in layer1
+        else conv("layer.conv1", layer_[l][0][0], cur, hin, win, stride, t_[l], true);
+        if (l > 0) {
+          conv("layer.downsample", down_[l], cur, hin, win, stride, d_[l], false);
+          sc.residual = d_[l];
+        }
+      }
+      if (transform_fuse_ && wino43_unfused(layer_[l][0][1], ho, wo) && wino43_unfused(layer_[l][1][0], ho, wo) && wino43_unfused(layer_[l][1][1], ho, wo)) {
+        // three unfused F(4x4) convs in a row (layer3 / layer4): conv1's output inside block 1 is read by conv2 only - M -> y -> V in one
+        // launch, the activation never reaches HBM (model.rs:40-55)
+        // (the pair around the block boundary keeps its two launches: there y = a_[l] must be written anyway - the residual of block 1 -
+        // and the fused launch, one workgroup per CU for its LDS image, is slower than the two streaming kernels: 0.107 vs 0.077 ms at H/16)
+        wino_in(layer_[l][0][1], t_[l], ho, wo);
+        wino_gemm("layer.conv2", layer_[l][0][1], ho, wo);
+        wino_out(layer_[l][0][1], ho, wo, a_[l], sc.residual, true);
+        wino_in(layer_[l][1][0], a_[l], ho, wo);
+        wino_gemm("layer.conv1", layer_[l][1][0], ho, wo);
+        wino_out_in(layer_[l][1][0], ho, wo, nullptr, nullptr, true);
+        wino_gemm("layer.conv2", layer_[l][1][1], ho, wo);
+        wino_out(layer_[l][1][1], ho, wo, x_[l], a_[l], true);
+      } else {
+        conv3x3("layer.conv2", layer_[l][0][1], t_[l], ho, wo, a_[l], sc.residual);
+        conv3x3("layer.conv1", layer_[l][1][0], a_[l], ho, wo, t_[l], nullptr);
+        conv3x3("layer.conv2", layer_[l][1][1], t_[l], ho, wo, x_[l], a_[l]);
+      }
     }
     cur = x_[l];
     if (l == 0) grid_cus = num_cus_;   // (the tracer of the previous batch is done by now: 1.1 ms against stem + layer1 = 1.1 ms f32)

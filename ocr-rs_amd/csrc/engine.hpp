@@ -188,6 +188,7 @@ class Detector {
   ConvW bin_pyr_;
   bool bin_pyr_on_ = true;
   bool x3_wide_ = false;        // split-bf16 convs with NHWC stores and Cout % 128 == 0 on the 256 x 128 persistent form (conv_x3w.hip); 0: conv_igemm's 128-wide tiles.  Same bits
+  bool bf16_block_fuse_ = true;  // bf16 precision: layer1's BasicBlocks as one launch each (basic_block_bf16_c64.hip); 0: two conv3x3_bf16_c64 launches.  Same bits
   bool phase_windows_ = true;   // split-bf16 up-2 phase convs indexed by 2 x 2 windows: one operand tile for the four phases (0: one 64-column tile per phase)
   bool pyr_grouped_ = true;     // split-bf16 / bf16 bin_conv1 over p5..p3: phase blocks as 128-column tiles + the corner phases (0: one 64-column tile per phase)
   bool pyr_p2_direct_ = true;   // bf16 precision: p2's 3x3 term of bin_conv1 as the patch-staged 64 -> 64 conv instead of nine taps of the phase launch

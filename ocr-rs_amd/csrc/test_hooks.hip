@@ -355,6 +355,77 @@ int ocr_test_conv_run(ocr_det_t* det, int in_bf16, int out_bf16, const float* in
     down(out2, d_out2, out_e, out_bf16);
   });
 }
+// one BasicBlock 64 -> 64 of the bf16 precision on caller data (f32 arrays, rounded to bf16 on the way in, widened on the way out):
+// fused != 0: basic_block_bf16_c64.hip, one launch (num_cus sizes its persistent grid, 0 = 256); fused == 0: the same block as two
+// conv3x3_bf16_c64 launches.  x: NHWC, w1 / w2: [64][9][64]; iters > 1 repeats the block and returns the average time in ms
+int ocr_test_bf16_basic_block(ocr_det_t* det, const float* x, int n, int h, int w, const float* w1, const float* scale1, const float* bias1,
+                              const float* w2, const float* scale2, const float* bias2, int fused, int num_cus, int iters, float* out, float* ms_out) {
+  return guard([&] {
+    using namespace ocr;
+    if (!det || !x || !w1 || !w2 || !out) fail(OCR_ERR_INVALID, "null argument");
+    OCR_HIP(hipSetDevice(det->impl.device()));
+    hipStream_t s = det->impl.stream();
+    const size_t e = (size_t)n * h * w * 64;
+    auto bf16_bits = [](float f) {
+      uint32_t u;
+      std::memcpy(&u, &f, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    std::vector<void*> allocs;
+    struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } free_all{allocs};
+    auto dev = [&](const void* src, size_t bytes) -> void* {
+      void* d = nullptr;
+      OCR_HIP(hipMalloc(&d, bytes));
+      allocs.push_back(d);
+      if (src) OCR_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+      return d;
+    };
+    std::vector<uint16_t> xb(e);
+    for (size_t i = 0; i < e; ++i) xb[i] = bf16_bits(x[i]);
+    void* d_x = dev(xb.data(), e * 2);
+    void* d_t = dev(nullptr, e * 2);
+    void* d_y = dev(nullptr, e * 2);
+    const std::vector<uint16_t> f1 = conv3x3_bf16_c64_fragments(w1), f2 = conv3x3_bf16_c64_fragments(w2);
+    void* d_f1 = dev(f1.data(), f1.size() * 2);
+    void* d_f2 = dev(f2.data(), f2.size() * 2);
+    const float* d_s1 = scale1 ? static_cast<const float*>(dev(scale1, 256)) : nullptr;
+    const float* d_b1 = bias1 ? static_cast<const float*>(dev(bias1, 256)) : nullptr;
+    const float* d_s2 = scale2 ? static_cast<const float*>(dev(scale2, 256)) : nullptr;
+    const float* d_b2 = bias2 ? static_cast<const float*>(dev(bias2, 256)) : nullptr;
+    const int cus = num_cus > 0 ? num_cus : 256;
+    auto run = [&] {
+      if (fused) {
+        launch_basic_block_bf16_c64(d_x, d_f1, d_s1, d_b1, d_f2, d_s2, d_b2, d_y, n, h, w, cus, s);
+      } else {
+        launch_conv3x3_bf16_c64(d_x, d_f1, d_s1, d_b1, nullptr, 1, d_t, n, h, w, cus, s);
+        launch_conv3x3_bf16_c64(d_t, d_f2, d_s2, d_b2, d_x, 1, d_y, n, h, w, cus, s);
+      }
+    };
+    run();
+    OCR_HIP(hipStreamSynchronize(s));
+    if (iters > 1) {
+      hipEvent_t e0, e1;
+      OCR_HIP(hipEventCreate(&e0));
+      OCR_HIP(hipEventCreate(&e1));
+      OCR_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; ++i) run();
+      OCR_HIP(hipEventRecord(e1, s));
+      OCR_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      OCR_HIP(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      if (ms_out) *ms_out = ms / iters;
+    }
+    std::vector<uint16_t> yb(e);
+    OCR_HIP(hipMemcpy(yb.data(), d_y, e * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < e; ++i) {
+      const uint32_t u = (uint32_t)yb[i] << 16;
+      std::memcpy(&out[i], &u, 4);
+    }
+  });
+}
 // one 3x3 s1 p1 conv (+ scale / bias / residual / ReLU) through the Winograd F(2x2,3x3) path on caller data:
 // weight transform, input transform, batched 16-problem GEMM, output transform.  x: NHWC, wgt: [cout][9][cin].
 int ocr_test_winograd_conv(ocr_det_t* det, const float* x, int n, int h, int w, int cin, const float* wgt, int cout,

@@ -407,3 +407,55 @@ def test_bf16_c64_patch_conv_matches_aten(det, shape, has_res, relu, bn):
     ref, _ = _ref(x, wg, 1, scale, bias, res, None, relu)
     _check(out, ref, True)
 
+
+
+BLOCK_SHAPES = [(2, 16, 32), (1, 9, 21), (3, 1, 1), (2, 160, 160), (1, 8, 16), (5, 24, 40), (1, 64, 272), (1, 7, 15), (2, 17, 33), (1, 200, 200)]
+
+
+def _block_operands(seed, n, h, w, bn=True):
+    rng = np.random.default_rng(seed)
+    x = _q(np.maximum(rng.standard_normal((n, h, w, 64), dtype=np.float32), 0))
+    w1 = _q((rng.standard_normal((64, 9, 64), dtype=np.float32) / np.sqrt(9 * 64)).astype(np.float32))
+    w2 = _q((rng.standard_normal((64, 9, 64), dtype=np.float32) / np.sqrt(9 * 64)).astype(np.float32))
+    s1 = (0.5 + rng.random(64, dtype=np.float32)) if bn else None
+    b1 = rng.standard_normal(64, dtype=np.float32) if bn else None
+    s2 = (0.5 + rng.random(64, dtype=np.float32)) if bn else None
+    b2 = rng.standard_normal(64, dtype=np.float32) if bn else None
+    return x, w1, w2, s1, b1, s2, b2
+
+
+@pytest.mark.parametrize("shape", BLOCK_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("bn", [True, False])
+def test_bf16_basic_block_one_launch_equals_two_launches_bit_for_bit(det, shape, bn):
+    """basic_block_bf16_c64.hip (model.rs:40-55 as ONE launch, the activation between the convs in LDS) against the same block as two
+    conv3x3_bf16_c64 launches: the same bits - at the image edge (the intermediate's zero padding), ragged blocks, one-pixel images,
+    the full 160 x 160 of configs[1]."""
+    n, h, w = shape
+    x, w1, w2, s1, b1, s2, b2 = _block_operands(hash(shape) & 0xFFFF, n, h, w, bn)
+    two, _ = det.debug_bf16_basic_block(x, w1, w2, s1, b1, s2, b2, fused=False)
+    one, _ = det.debug_bf16_basic_block(x, w1, w2, s1, b1, s2, b2, fused=True)
+    assert np.isfinite(one).all() and float(np.abs(two).max()) > 0.1
+    assert np.array_equal(one, two)
+
+
+@pytest.mark.parametrize("num_cus", [1, 3, 8, 24, 100, 256, 512, 1000])
+def test_bf16_basic_block_any_persistent_grid(det, num_cus):
+    """the persistent grid is one workgroup per CU; whatever its size (fewer than the XCDs, not a multiple of eight, oversubscribed for
+    head_cus_yield, more workgroups than blocks) every block is computed exactly once"""
+    x, w1, w2, s1, b1, s2, b2 = _block_operands(num_cus, 3, 40, 56)
+    two, _ = det.debug_bf16_basic_block(x, w1, w2, s1, b1, s2, b2, fused=False)
+    one, _ = det.debug_bf16_basic_block(x, w1, w2, s1, b1, s2, b2, fused=True, num_cus=num_cus)
+    assert np.array_equal(one, two)
+
+
+def test_bf16_basic_block_matches_aten(det):
+    """... and against ATen on the same bf16-rounded operands, the intermediate rounded to bf16 as the kernel rounds it: one bf16 ulp"""
+    x, w1, w2, s1, b1, s2, b2 = _block_operands(5, 2, 24, 40)
+    got, _ = det.debug_bf16_basic_block(x, w1, w2, s1, b1, s2, b2, fused=True)
+    mid, _ = _ref(x, w1, 1, s1, b1, None, None, True)
+    ref, _ = _ref(_q(mid), w2, 1, s2, b2, x, None, True)
+    refq = _q(ref)
+    scale = float(np.abs(ref).max())
+    # one bf16 ulp of the result + what a one-ulp flip of an intermediate value (ATen's accumulation order is not the kernel's) moves it by
+    assert (np.abs(got - refq) <= np.abs(refq) * 2.0 ** -7 + 1e-3 * scale).all()
+    assert float((got != refq).mean()) < 0.02
