@@ -19,15 +19,12 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "bf16_c64_tiles.hpp"
 
 namespace ocr {
 namespace {
+using namespace bf16_c64;
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
 
 template <typename R>
 __device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, int soff) {
@@ -67,70 +64,6 @@ constexpr int EXROW = 36;                   // floats per exchange row (32 chann
 constexpr int EX_WAVE_BYTES = 64 * EXROW * 4;
 constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * MID_BYTES + 4 * EX_WAVE_BYTES;   // 147 456: one workgroup per CU
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;
-
-// compile-time ablations (tools/build_abl_bb.sh; results are wrong, only the time matters): 1 no fragment reads, 2 no MFMAs, 4 no patch
-// DMA, 8 no stores of the intermediate, 16 no conv2 epilogue, 32 conv1 waves idle, 64 conv2 waves idle
-#ifndef BB_ABL
-#define BB_ABL 0
-#endif
-
-// LDS images (patch of x, intermediate): one 128-byte row per pixel, pixel (row, col) in LDS row row * PITCH + col (PITCH even), its
-// 16-byte chunk c in slot c ^ sw, sw = ((col + K row) >> 1) & 7.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27},
-// {4-11, 16-19, 28-31} (+ 32), one LDS cycle per group when its sixteen lanes touch sixteen different 16-byte bank slots, i.e.
-// sixteen different values of (col + K row) mod 16.  An MFMA row tile is 2 image rows x 16 columns: lane l31 < 16 -> (row, l31),
-// lane l31 >= 16 -> (row + 1, (l31 - K) & 15) - the second row rotated by K columns, which makes (col + K row) mod 16 a function of
-// l31 & 15 alone: conflict-free for every tap (conv3x3_bf16_c64.hip's first layout - swizzle by linear pixel index, plain second
-// row - was 2-way on every read).
-//   * the intermediate: K = 8 (second row: columns XOR 8; sw = (col >> 1) ^ 4 (row & 1));
-//   * the patch of x: K = 2, because conv1's sixth tile - the two columns of the intermediate left of the five 2 x 16 tiles, ten
-//     rows of them - reads one patch column over many rows: with K = 2 its lanes (row i >> 1, column 16 + (i & 1)) see
-//     (col + 2 row) mod 16 = i mod 16.
-__device__ __forceinline__ int tile_col2(int i) { return i < 16 ? i : ((i + 14) & 15); }   // K = 2
-__device__ __forceinline__ int tile_col8(int i) { return i < 16 ? i : ((i & 15) ^ 8); }    // K = 8
-
-// NT row tiles, one after the other, nine taps x four k-steps each: A = shifted 16-byte reads of an image (pix0[j] = LDS row of the
-// lane's pixel of tile j for tap (0, 0), key0[j] = its col + K row), B = the wave's register-resident weights.  The (tile, tap)
-// steps form ONE software-pipelined sequence: the four fragment reads of step n + 1 are issued before the four MFMAs of step n, so
-// no MFMA waits on the read issued just before it (with all taps of two tiles in one scheduling region the compiler, short of
-// registers beside the 144 weight registers, had every ds_read_b128 followed by s_waitcnt lgkmcnt(0) and its MFMA).  One
-// accumulator (16 registers) at a time: epi(j, acc) takes tile j's sums when its ninth tap is done.
-template <int NT, int PITCH, int K, typename Epi>
-__device__ __forceinline__ void conv_tiles(const unsigned char* img, const int (&pix0)[NT], const int (&key0)[NT], const bf16x8 (&wreg)[9][4], int half,
-                                           Epi&& epi) {
-  // the fragment addresses are block-invariant per lane: an opaque zero keeps them computed where they are used instead of hoisted
-  // into registers the weights need
-  int opaque = 0;
-  asm volatile("" : "+v"(opaque));
-  bf16x8 a[2][4];
-  auto fetch = [&](int step, bf16x8(&dst)[4]) {
-    const int j = step / 9, t = step % 9;
-    const int pix = pix0[j] + (t / 3) * PITCH + (t % 3) + opaque;
-    const unsigned char* row = img + pix * 128;
-    const int sw = ((key0[j] + K * (t / 3) + (t % 3) + opaque) >> 1) & 7;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (BB_ABL & 1) dst[s] = wreg[(step + 1) % 9][s];
-      else dst[s] = *reinterpret_cast<const bf16x8*>(row + (((2 * s + half) ^ sw) << 4));
-    }
-  };
-  fetch(0, a[0]);
-  f32x16 acc;
-#pragma unroll
-  for (int step = 0; step < 9 * NT; ++step) {
-    if (step + 1 < 9 * NT) fetch(step + 1, a[(step + 1) & 1]);
-    if (step % 9 == 0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (BB_ABL & 2) acc[s] += __builtin_bit_cast(f32x4, a[step & 1][s])[0];
-      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step & 1][s], wreg[step % 9][s], acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (step % 9 == 8) epi(step / 9, acc);
-  }
-}
 
 __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -189,19 +122,19 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       const int py = px / XW, pxx = px - py * XW;
       const int yy = py0 - 2 + py, xx = px0 - 2 + pxx;
       const bool inside = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const int chunk = slot ^ (((pxx >> 1) + py) & 7);
+      const int chunk = slot ^ ((pxx >> 1) & 7) ^ ((py & 1) << 2);
       const unsigned off = inside ? (unsigned)((((pn * p.H + yy) * p.W + xx) * 64 + chunk * 8) * 2) : OOB;
       if (!(BB_ABL & 4)) dma16(x_rsrc, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * PATCH_BYTES + k * 1024)), off, 0);
     }
   };
 
-  // conv1: the 10 x 18 intermediate in six row tiles: T = 0 .. 4 rows 2 T, 2 T + 1 x columns 0 .. 15 (K = 2 map); T = 5 the two columns
-  // left over, row i >> 1 (of ten), column 16 + (i & 1) - rows i = 20 .. 31 of that tile compute pixels eight rows up again (same
-  // bank slots) and are not stored.  Wave rp takes tiles 3 rp .. 3 rp + 2
+  // conv1: the 10 x 18 intermediate in six row tiles: T = 0 .. 4 rows 2 T, 2 T + 1 x columns 0 .. 15; T = 5 the two columns
+  // left over, row i >> 1 (of ten), column 16 + (i & 1) - rows i = 20 .. 31 of that tile compute pixels eight rows up again and are
+  // not stored.  Wave rp takes tiles 3 rp .. 3 rp + 2
   auto mid_pixel = [&](int T, int i, int& mrow, int& mcol, bool& valid) {
     if (T < 5) {
       mrow = 2 * T + (i >> 4);
-      mcol = tile_col2(i);
+      mcol = tile_col8(i);
       valid = true;
     } else {
       const int r = i >> 1;
@@ -219,28 +152,26 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
   };
 
   // folded BN + ReLU + bf16 of a row tile of the intermediate: 2-byte stores, pixel-major.  Element e of a lane is tile row
-  // i = u + 4 half, u = (e & 3) + 8 (e >> 2), channel ch1 = 32 ct + l31; its LDS address is one of a few lane offsets (the XOR of the
+  // i = u + 4 half, u = (e & 3) + 8 (e >> 2), channel ch1 = 32 ct + l31; its LDS address is one of four lane offsets (the XOR of the
   // channel's chunk with the pixel's swizzle, which depends on e only through (e >> 1) & 1 and (e >> 2) & 1) + an immediate:
-  //   full tile, i < 16:  pixel (2 T, u + 4 half), sw = (u >> 1) ^ (half << 1)
-  //   full tile, i >= 16: pixel (2 T + 1, (u - 16 + 4 half + 14) & 15), sw = (col >> 1) ^ 4; u and u + 1 are neighbours
-  //   sixth tile:         pixel ((u >> 1) + 2 half, 16 + (u & 1)), sw = 4 ((u >> 1) & 1); stored while i < 20
+  //   full tile, i < 16:  pixel (2 T, u + 4 half),                  sw = (u >> 1) ^ (half << 1)
+  //   full tile, i >= 16: pixel (2 T + 1, ((u - 16) ^ 8) + 4 half), sw = ((u - 16) >> 1) ^ (half << 1)
+  //   sixth tile:         pixel ((u >> 1) + 2 half, 16 + (u & 1)),  sw = 4 ((u >> 1) & 1); stored while i < 20
   const int ch1 = 32 * ct + l31, cg1 = ch1 >> 3, cb1 = (ch1 & 7) * 2;
   auto store_full = [&](const f32x16& acc, int j, unsigned char* mid) {
-    int offa[4], offb[4];
+    int offa[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int cc = (c & 1) | ((c & 2) << 1);   // u >> 1 of the element: 0, 1, 4, 5
+      const int cc = (c & 1) | ((c & 2) << 1);   // u >> 1 (mod 8) of the element: 0, 1, 4, 5
       offa[c] = ((cg1 ^ (half << 1) ^ cc) << 4) + cb1 + half * 4 * 128;
-      const int col = (2 * cc + 4 * half + 14) & 15;
-      offb[c] = (MW + col) * 128 + ((cg1 ^ (col >> 1) ^ 4) << 4) + cb1;
     }
     unsigned char* base = mid + (3 * rp + j) * (2 * MW * 128);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = ((e >> 1) & 1) | (((e >> 2) & 1) << 1);
+      const int u = (e & 3) + 8 * (e >> 2);
       const float v = fmaxf(__builtin_fmaf(acc[e], sc, bi), 0.f);
-      if (e < 8) *reinterpret_cast<__bf16*>(base + offa[c] + ((e & 3) + 8 * (e >> 2)) * 128) = (__bf16)v;
-      else *reinterpret_cast<__bf16*>(base + offb[c] + (e & 1) * 128) = (__bf16)v;
+      *reinterpret_cast<__bf16*>(base + offa[c] + (e < 8 ? u : MW + ((u - 16) ^ 8)) * 128) = (__bf16)v;
     }
   };
   auto store_left = [&](const f32x16& acc, unsigned char* mid) {
@@ -277,17 +208,22 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
     coords(bb, n, y0, x0);
     const unsigned char* patch = patch0 + buf * PATCH_BYTES;
     unsigned char* mid = mid0 + buf * MID_BYTES;
-    int pix1[3], key1[3];
+    // this lane's pixels: tiles 3 rp, + 1 (, + 2 for rp = 0) are 2 x 16 tiles - one column map and row parity for all of them;
+    // the sixth tile (rp = 1, j = 2) has its own
     const int lz = l31 + opaque_zero();
+    int pixb[3], xb[3][2], xbl[3][2];
+    xor_bases(tile_col8(lz), lz >> 4, half, xb);
+    xor_bases(16 + (lz & 1), (lz >> 1) & 1, half, xbl);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int mrow, mcol;
       bool valid;
       mid_pixel(3 * rp + j, lz, mrow, mcol, valid);
-      pix1[j] = mrow * XW + mcol;   // tap (ty, tx) of intermediate pixel (mrow, mcol) = patch pixel (mrow + ty, mcol + tx)
-      key1[j] = mcol + 2 * mrow;
+      pixb[j] = (mrow * XW + mcol) * 128;   // tap (ty, tx) of intermediate pixel (mrow, mcol) = patch pixel (mrow + ty, mcol + tx)
     }
-    conv_tiles<3, XW, 2>(patch, pix1, key1, wreg, half, [&](int j, const f32x16& acc) {
+    const bool left = rp == 1;
+    conv_tiles<3, XW>(patch, pixb, [&](int j, int tx, int q) { return j == 2 && left ? xbl[tx][q] : xb[tx][q]; }, wreg,
+                      [&](int j, const f32x16& acc) {
       if (BB_ABL & 8) {
         if (acc[0] == 123.456f) p.y[j] = (__bf16)1.f;
       } else if (j < 2 || rp == 0) {
@@ -311,17 +247,14 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       if (BB_ABL & 16) res[k] = u32x4{0u, 0u, 0u, 0u};
       else res[k] = load16_async(x_rsrc, (yy < p.H && xx < p.W) ? (unsigned)((((n * p.H + yy) * p.W + xx) * 64 + c8) * 2) : OOB);
     }
-    // row tile r of the wave = output rows 4 rp + 2 r, + 1 of the block (K = 8 map)
-    int pix2[2], key2[2];
+    // row tile r of the wave = output rows 4 rp + 2 r, + 1 of the block
     const int lz = l31 + opaque_zero();
+    int pixb[2], xb[3][2];
+    xor_bases(tile_col8(lz), lz >> 4, half, xb);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int orow = 4 * rp + 2 * r + (lz >> 4), ocol = tile_col8(lz);
-      pix2[r] = orow * MW + ocol;
-      key2[r] = ocol + 8 * orow;
-    }
+    for (int r = 0; r < 2; ++r) pixb[r] = ((4 * rp + 2 * r + (lz >> 4)) * MW + tile_col8(lz)) * 128;
     // folded BN, then pixel-major through this wave's own LDS rows: row = 32 r + tile row, column = channel l31
-    conv_tiles<2, MW, 8>(mid0 + buf * MID_BYTES, pix2, key2, wreg, half, [&](int r, const f32x16& acc) {
+    conv_tiles<2, MW>(mid0 + buf * MID_BYTES, pixb, [&](int, int tx, int q) { return xb[tx][q]; }, wreg, [&](int r, const f32x16& acc) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -354,27 +287,36 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
   };
 
   if (first >= end) return;   // (uniform over the workgroup)
-  if (!second) {
+#ifndef BB_NO_PRIO
+  if (!second) __builtin_amdgcn_s_setprio(3);   // the conv1 waves' instruction stream is the longer one: theirs first (3 % of the launch)
+#endif
+#ifndef BB_DMA_BY_CONV1
+  // the patches are fetched by the conv2 waves - the group with less to do per block (72 MFMAs against 108 and the stores of the
+  // intermediate): eight DMA instructions off the longer of the two instruction streams
+  const bool loader = second;
+#else
+  const bool loader = !second;
+#endif
+  if (loader) {
     issue_patch(first, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if (!second) {
-    if (first + step < end) issue_patch(first + step, 1);
-    conv1(first, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  }
+  if (loader && first + step < end) issue_patch(first + step, 1);
+  if (!second) conv1(first, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int buf = 0;
   for (int blk = first; blk < end; blk += step, buf ^= 1) {
+    // patch i + 2 into the buffer conv1 read in the previous iteration
+    if (loader && blk + 2 * step < end) issue_patch(blk + 2 * step, buf);
     if (!second) {
-      // patch i + 2 into the buffer conv1 read in the previous iteration; intermediate i + 1 from the patch that landed before the barrier
-      if (blk + 2 * step < end) issue_patch(blk + 2 * step, buf);
+      // intermediate i + 1 from the patch that landed before the barrier
       if (blk + step < end && !(BB_ABL & 32)) conv1(blk + step, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else {
       if (!(BB_ABL & 64)) conv2(blk, buf);
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // intermediate i + 1 and patch i + 2 complete; intermediate i free
   }
 #endif

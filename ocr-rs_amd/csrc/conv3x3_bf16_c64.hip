@@ -4,11 +4,9 @@
 // at best for 64 output channels: 460-620 TFLOP/s measured, neither roofline).  Here the input is staged ONCE:
 //   * a workgroup owns an 8 x 16 pixel block and all 64 output channels; its 10 x 18 x 64 bf16 patch (23 KB, one
 //     128-byte LDS row per pixel) arrives by LDS-DMA, double-buffered across the blocks of a persistent workgroup;
-//   * the nine taps are nine shifted reads of that patch (ds_read_b128).  Pixel (row, col) of the patch sits in LDS row row * 18 + col,
-//     its 16-byte chunk c in slot c ^ sw, sw = ((col >> 1) & 7) ^ 4 (row & 1); an MFMA row tile is 2 patch rows x 16 columns with the
-//     second row's columns XOR 8 (lane l31 >= 16 -> column (l31 & 15) ^ 8).  A ds_read_b128 is served in the lane groups {0-3, 12-15,
-//     20-27}, {4-11, 16-19, 28-31} (+ 32): with this map a group's sixteen lanes read sixteen different 16-byte bank slots for every
-//     tap - 4 LDS cycles per read, where the first layout (swizzle by linear pixel index, plain second row) took 8;
+//   * the nine taps are nine shifted reads of that patch (ds_read_b128): layout, swizzle and the lane -> pixel map that keep every
+//     read free of bank conflicts, and the software-pipelined (tile, tap) sequence with one v_xor of address arithmetic per read, are
+//     bf16_c64_tiles.hpp's (shared with basic_block_bf16_c64.hip);
 //   * the weights live in REGISTERS for the whole launch: wave w owns output channels 32 (w & 1) .. + 31 and pixel
 //     rows 4 (w >> 1) .. + 3 of the block (two 32-pixel MFMA row tiles): 9 taps x 4 k-steps x 4 VGPRs = 144 VGPRs.
 // HBM traffic is the compulsory one (+ 40 % halo from L2): the kernel is bound by HBM, not by operand staging.
@@ -16,15 +14,12 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "bf16_c64_tiles.hpp"
 
 namespace ocr {
 namespace {
+using namespace bf16_c64;
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
 
 template <typename R>
 __device__ __forceinline__ void dma16(R rsrc, unsigned lds_addr, unsigned voff, int soff) {
@@ -108,16 +103,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
     }
   };
 
-  // this lane's pixels: row tile r of the wave covers block rows 4 rp + 2 r, + 1; lane -> (row l31 >> 4, column l31 & 15, XOR 8 in
-  // the second row); key = col + 8 row: the swizzle of the pixel a tap reads is ((key + 8 ty + tx) >> 1) & 7
-  int pix0[2], key0[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = 4 * rp + 2 * r + (l31 >> 4), col = l31 < 16 ? l31 : ((l31 & 15) ^ 8);
-    pix0[r] = row * PWD + col;
-    key0[r] = col + 8 * row;
-  }
-
   float* ex = reinterpret_cast<float*>(lds + 2 * PATCH_BYTES);
   issue_patch(blockIdx.x, 0);
   int buf = 0;
@@ -142,42 +127,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
     if (has_next) issue_patch(blk + (int)gridDim.x, buf ^ 1);
 
     const unsigned char* patch = lds + buf * PATCH_BYTES;
-    // the 72 fragment addresses are block-invariant per lane: left alone, the compiler hoists them out of the block
-    // loop into 72 registers and spills the weights.  An opaque zero keeps them computed where they are used (VALU
-    // work beside bf16 MFMAs is free, registers are not).
-    int opaque = 0;
-    asm volatile("" : "+v"(opaque));
-    f32x16 acc[2];
+    // this lane's pixels: row tile r of the wave covers block rows 4 rp + 2 r, + 1; lane -> (row l31 >> 4, column l31 & 15, XOR 8 in
+    // the second row).  Computed per block behind an opaque zero: block-invariant values the compiler would otherwise keep in
+    // registers - or spill - beside the 144 weight registers
+    int lz = l31;
+    asm volatile("" : "+v"(lz));
+    int pixb[2], xb[3][2];
+    xor_bases(tile_col8(lz), lz >> 4, half, xb);
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int toff = (t / 3) * PWD + (t % 3);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int pix = pix0[r] + toff + opaque;
-        const unsigned char* row = patch + pix * 128;
-        const int sw = ((key0[r] + 8 * (t / 3) + (t % 3) + opaque) >> 1) & 7;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(row + (((2 * s + half) ^ sw) << 4));
-          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wreg[t][s], acc[r], 0, 0, 0);
-        }
-      }
-      // one tap's eight fragment reads at a time: hoisting all 72 (or double-buffering them by hand: tried, 48 bytes of
-      // scratch and 0.09-0.12 ms instead of 0.076-0.087) spills the register-resident weights
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // folded BN, then through LDS: row = 32 x row tile + tile row, column = output channel
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 2; ++r) pixb[r] = ((4 * rp + 2 * r + (lz >> 4)) * PWD + tile_col8(lz)) * 128;
+    // the two row tiles one after the other, (tile, tap) steps software-pipelined (bf16_c64_tiles.hpp); folded BN of a tile's sums,
+    // then through LDS: row = 32 x row tile + tile row, column = output channel
+    conv_tiles<2, PWD>(patch, pixb, [&](int, int tx, int q) { return xb[tx][q]; }, wreg, [&](int r, const f32x16& acc) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * half;   // pixel of the row tile
-        ex[(32 * (2 * rp + r) + i) * EXROW + 32 * ct + l31] = acc[r][e] * sc + bi;
+        ex[(32 * (2 * rp + r) + i) * EXROW + 32 * ct + l31] = __builtin_fmaf(acc[e], sc, bi);
       }
+    });
     // the residual loads are older than the (at most six) patch DMA instructions of this wave: a counted wait leaves
     // those in flight
     if (!p.residual) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 for N in "$@"; do
   D=$ROOT/ocr-rs_amd/lib_bb$N
   rm -rf "$D" && mkdir -p "$D/obj" && cp "$ROOT"/ocr-rs_amd/lib/obj/*.o "$D/obj/"
-  (cd "$ROOT/ocr-rs_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBB_ABL=$N -c basic_block_bf16_c64.hip -o "$D/obj/basic_block_bf16_c64.o" 2>/dev/null)
+  (cd "$ROOT/ocr-rs_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBB_ABL=$N $BB_EXTRA -c basic_block_bf16_c64.hip -o "$D/obj/basic_block_bf16_c64.o" 2>/dev/null)
   OBJS=$(ls "$D"/obj/*.o | grep -v test_hooks)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$D/libocr_amd_test.so" "$D/obj/test_hooks.o" $OBJS -ldl
   cp "$D/libocr_amd_test.so" "$D/libocr_amd.so"
