@@ -16,6 +16,7 @@
 //     (16-byte loads issued before the matrix phase), ReLU, bf16, 16-byte stores.
 // Matrix work is 1.25 x the two launches' (the halo of the intermediate is computed by every block that needs it): 180 MFMAs of
 // 32 cycles per SIMD and block.
+#include <cstdio>
 #include <cstring>
 
 #include "common.hpp"
@@ -41,6 +42,14 @@ __device__ __forceinline__ u32x4 load16_async(R rsrc, unsigned voff) {
   return v;
 }
 __device__ __forceinline__ void settle(u32x4& v) { asm volatile("" : "+v"(v)::"memory"); }
+
+#if defined(BB_STAMPS)
+// diagnostic build: s_memtime at the phases of block iterations 4 and 5 of workgroups 0 .. 3, lane 0 of every wave (profiles/r06_bf16_block_stamps.txt)
+__device__ unsigned long long bb_stamp_buf[4 * 8 * 2 * 16];
+#define BB_STAMP(k) do { if (blockIdx.x < 4 && (bb_it == 4 || bb_it == 5) && lane == 0) bb_stamp_buf[((blockIdx.x * 8 + wave) * 2 + (bb_it - 4)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BB_STAMP(k) do { } while (0)
+#endif
 
 struct BlockArgs {
   const __bf16* x;        // [N][H][W][64]
@@ -73,6 +82,7 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
   const bool second = wave >= 4;                  // waves 4-7: conv2 (wave w shares its SIMD with wave w - 4)
   const int w4 = wave & 3, ct = w4 & 1, rp = w4 >> 1;
   const int half = lane >> 5, l31 = lane & 31;
+  [[maybe_unused]] int bb_it = 0;
   const unsigned lds0 = (unsigned)(size_t)(lds_void*)lds;
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, p.x_bytes, 0x00020000);
   unsigned char* const patch0 = lds;
@@ -112,18 +122,36 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
     y0_ = 8 * (bb % p.bh);
     n_ = bb / p.bh;
   };
-  // the 12 x 20 patch of block bb: 30 DMA instructions of 8 pixels over the four conv1 waves (zero padding = out-of-range lanes)
+  // (block-invariant lane values are computed per block behind an opaque zero: the compiler would otherwise keep them in registers -
+  // or spill them - across the loop beside the 144 weight registers)
+  auto opaque_zero = [] {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+  };
+  // the 12 x 20 patch of block bb: 30 DMA instructions of 8 pixels (zero padding = out-of-range lanes), instructions w, w + 8, ... by
+  // wave w - an LDS-DMA instruction costs its wave 100 - 300 cycles of issue, so all eight waves share them.  A lane's pixel is
+  // (py, pxx) = divmod(8 k + lane / 8, 20): the quotient and remainder of 8 k are scalar
   auto issue_patch = [&](int bb, int buf) {
     int pn, py0, px0;
     coords(bb, pn, py0, px0);
-    const int sub = lane >> 3, slot = lane & 7;
-    for (int k = w4; k < 30; k += 4) {
-      const int px = 8 * k + sub;
-      const int py = px / XW, pxx = px - py * XW;
-      const int yy = py0 - 2 + py, xx = px0 - 2 + pxx;
-      const bool inside = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+    const int lz = lane + opaque_zero();
+    const int sub = lz >> 3, slot = lz & 7;
+    const bool interior = py0 >= 2 && py0 + 10 <= p.H && px0 >= 2 && px0 + 18 <= p.W;   // (uniform) no lane of this patch is padding
+    const int base = ((pn * p.H + py0 - 2) * p.W + px0 - 2) * 128;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = wave + 8 * m;
+      if (k >= 30) break;   // (uniform) waves 6 and 7 have three
+      const int ka = (8 * k) / XW, kb = (8 * k) % XW;
+      const int t = kb + sub;
+      const int py = ka + (t >= XW ? 1 : 0), pxx = t >= XW ? t - XW : t;
       const int chunk = slot ^ ((pxx >> 1) & 7) ^ ((py & 1) << 2);
-      const unsigned off = inside ? (unsigned)((((pn * p.H + yy) * p.W + xx) * 64 + chunk * 8) * 2) : OOB;
+      unsigned off = (unsigned)(base + (py * p.W + pxx) * 128 + chunk * 16);
+      if (!interior) {
+        const int yy = py0 - 2 + py, xx = px0 - 2 + pxx;
+        if (!((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)) off = OOB;
+      }
       if (!(BB_ABL & 4)) dma16(x_rsrc, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * PATCH_BYTES + k * 1024)), off, 0);
     }
   };
@@ -143,14 +171,6 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       mcol = 16 + (i & 1);
     }
   };
-  // (the lanes' pixel rows and swizzle keys are computed per block, behind an opaque zero: block-invariant values the compiler would
-  // otherwise keep in registers - or spill - across the loop beside the 144 weight registers)
-  auto opaque_zero = [] {
-    int z = 0;
-    asm volatile("" : "+v"(z));
-    return z;
-  };
-
   // folded BN + ReLU + bf16 of a row tile of the intermediate: 2-byte stores, pixel-major.  Element e of a lane is tile row
   // i = u + 4 half, u = (e & 3) + 8 (e >> 2), channel ch1 = 32 ct + l31; its LDS address is one of four lane offsets (the XOR of the
   // channel's chunk with the pixel's swizzle, which depends on e only through (e >> 1) & 1 and (e >> 2) & 1) + an immediate:
@@ -224,6 +244,7 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
     const bool left = rp == 1;
     conv_tiles<3, XW>(patch, pixb, [&](int j, int tx, int q) { return j == 2 && left ? xbl[tx][q] : xb[tx][q]; }, wreg,
                       [&](int j, const f32x16& acc) {
+      BB_STAMP(2 + 2 * j);
       if (BB_ABL & 8) {
         if (acc[0] == 123.456f) p.y[j] = (__bf16)1.f;
       } else if (j < 2 || rp == 0) {
@@ -231,8 +252,10 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       } else {
         store_left(acc, mid);
       }
+      BB_STAMP(3 + 2 * j);
     });
     if (!(BB_ABL & 8)) clear_outside(mid, y0, x0);
+    BB_STAMP(8);
   };
   auto conv2 = [&](int bb, int buf) {
     int n, y0, x0;
@@ -247,6 +270,7 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       if (BB_ABL & 16) res[k] = u32x4{0u, 0u, 0u, 0u};
       else res[k] = load16_async(x_rsrc, (yy < p.H && xx < p.W) ? (unsigned)((((n * p.H + yy) * p.W + xx) * 64 + c8) * 2) : OOB);
     }
+    BB_STAMP(2);
     // row tile r of the wave = output rows 4 rp + 2 r, + 1 of the block
     const int lz = l31 + opaque_zero();
     int pixb[2], xb[3][2];
@@ -255,6 +279,7 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
     for (int r = 0; r < 2; ++r) pixb[r] = ((4 * rp + 2 * r + (lz >> 4)) * MW + tile_col8(lz)) * 128;
     // folded BN, then pixel-major through this wave's own LDS rows: row = 32 r + tile row, column = channel l31
     conv_tiles<2, MW>(mid0 + buf * MID_BYTES, pixb, [&](int, int tx, int q) { return xb[tx][q]; }, wreg, [&](int r, const f32x16& acc) {
+      BB_STAMP(3 + 2 * r);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -263,7 +288,9 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       }
     });
     if (BB_ABL & 16) return;
+    BB_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the residual loads (and the exchange rows of this wave)
+    BB_STAMP(8);
 #pragma unroll
     for (int k = 0; k < 4; ++k) settle(res[k]);
     __builtin_amdgcn_wave_barrier();
@@ -283,6 +310,7 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
       for (int e = 0; e < 8; ++e) h[e] = (__bf16)fmaxf(v[e] + (float)rr[e], 0.f);
       if (yy < p.H && xx < p.W) *reinterpret_cast<bf16x8*>(p.y + ((((size_t)n * p.H + yy) * p.W + xx) * 64 + 32 * ct + c8)) = h;
     }
+    BB_STAMP(9);
     // the next iteration's exchange rows are written after its matrix phase, by this wave, after these reads (LDS runs in order)
   };
 
@@ -290,39 +318,50 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
 #ifndef BB_NO_PRIO
   if (!second) __builtin_amdgcn_s_setprio(3);   // the conv1 waves' instruction stream is the longer one: theirs first (3 % of the launch)
 #endif
-#ifndef BB_DMA_BY_CONV1
-  // the patches are fetched by the conv2 waves - the group with less to do per block (72 MFMAs against 108 and the stores of the
-  // intermediate): eight DMA instructions off the longer of the two instruction streams
-  const bool loader = second;
-#else
-  const bool loader = !second;
-#endif
-  if (loader) {
-    issue_patch(first, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  issue_patch(first, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (loader && first + step < end) issue_patch(first + step, 1);
+  if (first + step < end) issue_patch(first + step, 1);
   if (!second) conv1(first, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int buf = 0;
-  for (int blk = first; blk < end; blk += step, buf ^= 1) {
+  for (int blk = first; blk < end; blk += step, buf ^= 1, ++bb_it) {
+    BB_STAMP(0);
     // patch i + 2 into the buffer conv1 read in the previous iteration
-    if (loader && blk + 2 * step < end) issue_patch(blk + 2 * step, buf);
+    if (blk + 2 * step < end) issue_patch(blk + 2 * step, buf);
+    BB_STAMP(1);
     if (!second) {
       // intermediate i + 1 from the patch that landed before the barrier
       if (blk + step < end && !(BB_ABL & 32)) conv1(blk + step, buf ^ 1);
     } else {
       if (!(BB_ABL & 64)) conv2(blk, buf);
     }
+    BB_STAMP(10);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BB_STAMP(11);
     __builtin_amdgcn_s_barrier();   // intermediate i + 1 and patch i + 2 complete; intermediate i free
   }
 #endif
 }
 
 }  // namespace
+
+#if defined(BB_STAMPS)
+static void basic_block_dump_stamps() {
+  static unsigned long long h[4 * 8 * 2 * 16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bb_stamp_buf), sizeof(h)) != hipSuccess) return;
+  for (int wg = 0; wg < 4; ++wg)
+    for (int w = 0; w < 8; ++w)
+      for (int it = 0; it < 2; ++it) {
+        const unsigned long long* q = &h[((wg * 8 + w) * 2 + it) * 16];
+        fprintf(stderr, "STAMP wg %d wave %d (%s) it %d:", wg, w, w < 4 ? "conv1" : "conv2", it);
+        for (int k = 1; k <= 11; ++k) fprintf(stderr, " %lld", q[k] ? (long long)(q[k] - q[0]) : -1ll);
+        if (it == 1) fprintf(stderr, "  | block period %lld", (long long)(q[0] - h[((wg * 8 + w) * 2) * 16]));
+        fprintf(stderr, "\n");
+      }
+}
+#endif
 
 bool basic_block_bf16_c64_applicable(int N, int H, int W) {
   return N > 0 && H > 0 && W > 0 && (long long)N * H * W * 128 < (1ll << 31);
@@ -352,6 +391,13 @@ void launch_basic_block_bf16_c64(const void* x, const void* wfrag1, const float*
   const unsigned grid = blocks > resident ? (unsigned)resident : (unsigned)blocks;
   hipLaunchKernelGGL(basic_block_bf16_c64_kernel, dim3(grid), dim3(512), 0, s, a);
   OCR_HIP(hipGetLastError());
+#if defined(BB_STAMPS)
+  static int launches = 0;
+  if (++launches == 15) {
+    (void)hipStreamSynchronize(s);
+    basic_block_dump_stamps();
+  }
+#endif
 }
 
 }  // namespace ocr

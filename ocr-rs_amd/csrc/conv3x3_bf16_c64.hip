@@ -11,6 +11,7 @@
 //     rows 4 (w >> 1) .. + 3 of the block (two 32-pixel MFMA row tiles): 9 taps x 4 k-steps x 4 VGPRs = 144 VGPRs.
 // HBM traffic is the compulsory one (+ 40 % halo from L2): the kernel is bound by HBM, not by operand staging.
 // Epilogue: folded batch norm on the accumulators, through LDS into pixel-major order, residual add, ReLU, bf16, 16-byte stores.
+#include <cstdio>
 #include <cstring>
 
 #include "common.hpp"
@@ -39,6 +40,14 @@ __device__ __forceinline__ u32x4 load16_async(R rsrc, unsigned voff) {
   return v;
 }
 __device__ __forceinline__ void settle(u32x4& v) { asm volatile("" : "+v"(v)::"memory"); }
+
+#if defined(C64_STAMPS)
+// diagnostic build: s_memtime at the phases of block iterations 4 and 5 of workgroups 0 .. 7, every wave's lane 0 (tools/bf16_stamps.py)
+__device__ unsigned long long c64_stamp_buf[8 * 4 * 2 * 16];
+#define C64_STAMP(k) do { if (blockIdx.x < 8 && (it == 4 || it == 5) && lane == 0) c64_stamp_buf[((blockIdx.x * 4 + wave) * 2 + (it - 4)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C64_STAMP(k) do { } while (0)
+#endif
 
 struct C64Args {
   const __bf16* x;         // [N][H][W][64]
@@ -106,11 +115,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
   float* ex = reinterpret_cast<float*>(lds + 2 * PATCH_BYTES);
   issue_patch(blockIdx.x, 0);
   int buf = 0;
-  for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x, buf ^= 1) {
+  [[maybe_unused]] int it = 0;
+  for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x, buf ^= 1, ++it) {
     int n, y0, x0;
     coords(blk, n, y0, x0);
+    C64_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // this block's patch is complete; every wave has left the previous block's store phase
+    C64_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    C64_STAMP(2);  // this block's patch is complete; every wave has left the previous block's store phase
     // residual rows of this thread's store items first, then the NEXT block's patch: both fly under this block's MFMAs
     const bool has_next = blk + (int)gridDim.x < p.nblocks;
     u32x4 res[4];
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
       }
     }
     if (has_next) issue_patch(blk + (int)gridDim.x, buf ^ 1);
+    C64_STAMP(3);
 
     const unsigned char* patch = lds + buf * PATCH_BYTES;
     // this lane's pixels: row tile r of the wave covers block rows 4 rp + 2 r, + 1; lane -> (row l31 >> 4, column l31 & 15, XOR 8 in
@@ -139,20 +153,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
     // the two row tiles one after the other, (tile, tap) steps software-pipelined (bf16_c64_tiles.hpp); folded BN of a tile's sums,
     // then through LDS: row = 32 x row tile + tile row, column = output channel
     conv_tiles<2, PWD>(patch, pixb, [&](int, int tx, int q) { return xb[tx][q]; }, wreg, [&](int r, const f32x16& acc) {
+      C64_STAMP(4 + 2 * r);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * half;   // pixel of the row tile
         ex[(32 * (2 * rp + r) + i) * EXROW + 32 * ct + l31] = __builtin_fmaf(acc[e], sc, bi);
       }
+      C64_STAMP(5 + 2 * r);
     });
     // the residual loads are older than the (at most six) patch DMA instructions of this wave: a counted wait leaves
     // those in flight
     if (!p.residual) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else if (has_next) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    C64_STAMP(8);
 #pragma unroll
     for (int k = 0; k < 4; ++k) settle(res[k]);
     __builtin_amdgcn_s_barrier();
+    C64_STAMP(9);
     // 128 pixels x 8 chunks of 8 channels: residual, ReLU, bf16, 16-byte stores
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -177,11 +195,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_c64_kernel(C64Args p) {
         *reinterpret_cast<bf16x8*>(p.y + o) = h;
       }
     }
+    C64_STAMP(10);
   }
 #endif
 }
 
 }  // namespace
+
+#if defined(C64_STAMPS)
+void conv3x3_bf16_c64_dump_stamps() {
+  static unsigned long long h[8 * 4 * 2 * 16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(c64_stamp_buf), sizeof(h)) != hipSuccess) return;
+  for (int wg = 0; wg < 8; ++wg)
+    for (int w = 0; w < 4; ++w)
+      for (int it = 0; it < 2; ++it) {
+        const unsigned long long* q = &h[((wg * 4 + w) * 2 + it) * 16];
+        fprintf(stderr, "STAMP wg %d wave %d it %d:", wg, w, it);
+        for (int k = 1; k <= 10; ++k) fprintf(stderr, " %lld", (long long)(q[k] - q[0]));
+        if (it == 1) fprintf(stderr, "  | block period %lld", (long long)(q[0] - h[((wg * 4 + w) * 2) * 16]));
+        fprintf(stderr, "\n");
+      }
+}
+#endif
 
 // [Cout 64][9][Cin 64] f32 -> bf16 MFMA B fragments [2 ct][9 taps][4 s][64 lanes][8]: element j of lane (n = l & 31,
 // h = l >> 5) is w[32 ct + n][tap][16 s + 8 h + j]
@@ -227,6 +262,13 @@ void launch_conv3x3_bf16_c64(const void* x, const void* wfrag, const float* scal
   const unsigned grid = blocks > resident ? (unsigned)resident : (unsigned)blocks;
   hipLaunchKernelGGL(conv3x3_bf16_c64_kernel, dim3(grid), dim3(256), 0, s, a);
   OCR_HIP(hipGetLastError());
+#if defined(C64_STAMPS)
+  static int launches = 0;
+  if (++launches == 30) {
+    (void)hipStreamSynchronize(s);
+    conv3x3_bf16_c64_dump_stamps();
+  }
+#endif
 }
 
 }  // namespace ocr
