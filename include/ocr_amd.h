@@ -94,6 +94,9 @@ int ocr_det_create(const void* weights, size_t weights_bytes, int device, ocr_de
  *   x3_wide=0|1          (0)    the split-bf16 convs with plain NHWC stores and Cout % 128 == 0 (stride-2 3x3, 1x1, the Winograd GEMMs) as 256 x 128 tiles
  *                               on one persistent workgroup per CU (conv_x3w.hip): 30 % fewer operand bytes per MFMA, bit-identical, and measured 0-35 %
  *                               SLOWER than the 128-wide tiles at two workgroups per CU: kept for A/B
+ *   bf16_block_fuse=0|1  (1)    bf16 precision: each BasicBlock of layer1 (conv3x3 + BN + ReLU, conv3x3 + BN, + x, ReLU: model.rs:40-55) as ONE launch, the
+ *                               activation between its two convs held in LDS (basic_block_bf16_c64.hip): half the HBM traffic of the two launches, 1.25 x
+ *                               their matrix work, 5-10 % less time; 0 = two conv3x3_bf16_c64 launches.  The same bits either way
  *   w43_cus=<n>          (0)    tuning: size of the fused Winograd kernel's persistent grid in CUs (two workgroups each); 0 = every CU of the device.
  *   w43_side_cus=<n>     (0)    the same for the fused Winograd launches that overlap=3 puts on the side stream; 0 = every CU.  Both 0..4096; any
  *                               grid size gives the same bits (tests/test_gpu_conv_kernel.py)

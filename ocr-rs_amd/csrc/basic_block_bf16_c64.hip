@@ -315,9 +315,10 @@ __global__ __launch_bounds__(512, 1) void basic_block_bf16_c64_kernel(BlockArgs 
   };
 
   if (first >= end) return;   // (uniform over the workgroup)
-#ifndef BB_NO_PRIO
-  if (!second) __builtin_amdgcn_s_setprio(3);   // the conv1 waves' instruction stream is the longer one: theirs first (3 % of the launch)
+#ifndef BB_PRIO
+#define BB_PRIO 1
 #endif
+  if ((BB_PRIO == 1 && !second) || (BB_PRIO == 2 && second)) __builtin_amdgcn_s_setprio(3);
   issue_patch(first, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
