@@ -98,3 +98,17 @@ def test_bf16_bin_conv1_forms_meet_the_same_bars(det_w):
     assert np.abs(maps[0] - maps[1]).max() <= DRIFT_FACTOR * d_ref.max()
     # the side-stream schedule (bin_conv1's p2 term rounded to bf16 BEFORE the pyramid's sum is added instead of after) against the one-stream one
     assert np.abs(maps[0] - maps[2]).max() <= DRIFT_FACTOR * d_ref.max()
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 64, 96), (1, 320, 320), (3, 32, 32)])
+def test_bf16_fused_basic_blocks_give_the_same_map_bit_for_bit(det_w, n, h, w):
+    """bf16_block_fuse=1 (default: each BasicBlock of layer1 one launch, basic_block_bf16_c64.hip) against =0 (two conv3x3_bf16_c64
+    launches per block): identical probability maps, to the last bit (model.rs:40-55)"""
+    x = W.synth_image_batch(21, n, h, w)
+    maps = []
+    for opt in ("", "bf16_block_fuse=0"):
+        d = capi.Detector(W.pack_blob(det_w), 0, options=opt)
+        d.set_precision(capi.PRECISION_BF16)
+        maps.append(d.forward_host(x))
+        d.close()
+    assert np.array_equal(maps[0], maps[1])
