@@ -44,6 +44,8 @@ rocprofv3 --kernel-trace --stats -d $O/stats_chain -o t -- python3 tools/pipelin
 rocprofv3 --kernel-trace --stats -d $O/stats_fwd -o t -- python3 tools/pipeline_trace.py forward > $O/pipeline_forward.txt 2>/dev/null || exit 1
 # the 256 x 128 persistent split-bf16 form against the 128-wide tiles, launch shape by launch shape
 python3 tools/bench_x3w.py > $O/x3w_ab.txt 2>/dev/null || exit 1
+# bf16 precision: a BasicBlock of layer1 as one launch against its two launches
+python3 tools/bench_bf16_block.py > $O/bf16_block_ab.txt 2>/dev/null || exit 1
 echo "chain / wide-form passes done"
 python3 bench.py --steps 20 --warmup 3 > $O/bench_line_plain.json 2>/dev/null || exit 1
 echo "all done"

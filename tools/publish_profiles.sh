@@ -22,6 +22,7 @@ python3 tools/rocprof_stats_csv.py $O/stats_chain > $P/${T}_pipeline_chain_kerne
 python3 tools/rocprof_stats_csv.py $O/stats_fwd > $P/${T}_pipeline_forward_kernel_stats.csv
 grep -h "images/s" $O/pipeline_chain.txt $O/pipeline_forward.txt > $P/${T}_pipeline_rates.txt
 cp $O/x3w_ab.txt $P/${T}_x3w_ab.txt
+cp $O/bf16_block_ab.txt $P/${T}_bf16_block_ab.txt
 # the dominant kernels' average duration IN THE SHIPPED SCHEDULE (two streams), from the headline rocprof pass: bench.py's
 # roofline.avg_launch_ms_in_schedule
 python3 - $P/${T}_bench_kernel_stats_headline.csv <<'PY'
